@@ -1,0 +1,170 @@
+/*
+ * reed_hip.h — C ABI of libreed_hip.so, the MI355X (gfx950) kernel library behind the
+ * reed_amd drop-in for REED's image/ SiT training + sampling path.
+ *
+ * The reference (ChenyuWang-Monica/REED, image/) has no FFI of its own: it is pure PyTorch.
+ * Each entry point below replaces the arithmetic of the reference lines cited next to it; the
+ * Python host (reed_amd/) binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library never
+ *    allocates, frees or retains memory past the call); tensors are contiguous row-major unless
+ *    a leading dimension argument says otherwise;
+ *  - `stream` is a hipStream_t passed as void* (PyTorch's current stream); all work is enqueued
+ *    there and the call returns immediately;
+ *  - return value 0 = OK, otherwise an argument-check code (1001/1002) or a hipError_t;
+ *    reed_last_error() returns a thread-local message;
+ *  - dtypes are fixed per entry point: "bf16" = __bf16 / torch.bfloat16, f32, f64, i64.
+ */
+#ifndef REED_HIP_H
+#define REED_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* reed_last_error(void);
+int reed_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contractions (every nn.Linear on the path: sit.py:17-24 projector, :38-42 t-MLP,
+ * :114-124 attention qkv/proj + Mlp fc1/fc2 (timm), :126-129 & :146-150 adaLN; and their autograd).
+ *   layout 0 NT: C[M,N] = P[M,K] Q[N,K]^T     (forward  y = x W^T)
+ *   layout 1 NN: C[M,N] = P[M,K] Q[K,N]       (dgrad    dx = dy W)
+ *   layout 2 TN: C[M,N] = P[K,M]^T Q[K,N]     (wgrad    dW = dy^T x), optional dbias[M] = colsum(P)
+ * epilogue codes: see reed_amd/csrc/gemm.h (0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
+ *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic).  N%128==0; K%64==0 (NT/NN);
+ *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0.
+ * ------------------------------------------------------------------------------------------- */
+int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* Q, int64_t ldq,
+              int M, int N, int K, void* C, int64_t ldc, void* C2, int64_t ldc2, const void* R,
+              int64_t ldr, const void* bias, const void* gate, int64_t ldgate, int rows_per_gate,
+              float* dbias, int accumulate, int split_k, int64_t slab_stride, void* stream);
+
+/* sum split-K slabs: out[i] (+)= sum_z slabs[z*stride + i], i < n */
+int reed_reduce_slabs(const float* slabs, int64_t stride, int nslabs, float* out, int64_t n,
+                      int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm(eps, no affine) + modulate  (sit.py:26-27,113,119,132-135,143,152)
+ *   h[m,:] = bf16( LN(x[m,:]) * bf16(1+scale[b,:]) + shift[b,:] ),  b = m / T
+ * x f32 [M,D]; shift/scale bf16 with row stride ldmod; h bf16 [M,D]; mean/rstd f32 [M] (optional).
+ * scale==NULL -> plain cast f32->bf16 of x (projector input cast, sit.py:292).
+ * ------------------------------------------------------------------------------------------- */
+int reed_ln_modulate_fwd(const float* x, const void* shift, const void* scale, int64_t ldmod,
+                         void* h, float* mean, float* rstd, int M, int D, int T, float eps,
+                         void* stream);
+/* backward: dx[m,:] += LNbwd(dh * bf16(1+scale)); partial column sums over each 16-row chunk:
+ *   part[(m/16), 0, :] = sum dh, part[(m/16), 1, :] = sum dh*xhat        (f32 [M/16, 2, D]) */
+int reed_ln_modulate_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
+                         const void* scale, int64_t ldmod, float* dx, float* part, int M, int D,
+                         int T, void* stream);
+
+/* gate backward (sit.py:134-135): dg = bf16(dx); dy = bf16(dg*gate[b]); part[(m/16),:] = sum bf16(dg*y) */
+int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,
+                  float* part, int M, int D, int T, void* stream);
+
+/* reduce per-chunk partials to bf16 modulation grads:
+ *   dmod[b, col0 + j*D + d] = bf16( sum_{c<T/16} part_j[(b*T/16 + c)*stride_j + d] ) for the listed parts */
+int reed_reduce_mod_parts(const float* const* parts, const int64_t* strides, const int64_t* offs,
+                          int nparts, void* dmod, int64_t lddmod, int B, int D, int chunks,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention (timm Attention under sit.py:114-118; softmax(q k^T / sqrt(hd)) v), head_dim 64 or 72.
+ * qkv bf16 [B, T, 3, H, hd] as produced by the qkv Linear; o bf16 [B, T, H*hd]; lse f32 [B,H,T].
+ * ------------------------------------------------------------------------------------------- */
+int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int hd,
+                       void* stream);
+int reed_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
+                       void* dqkv, int B, int T, int H, int hd, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedders and the final layer
+ * ------------------------------------------------------------------------------------------- */
+/* PatchEmbed (timm, sit.py:198-200,279): tokens f32 [B,T,D] = bf16(conv_p(x bf16, W bf16)+b) + pos_embed f32 */
+int reed_patch_embed_fwd(const float* x, const void* w, const void* bias, const float* pos,
+                         float* tokens, int B, int C, int HW, int P, int D, void* stream);
+/* dW f32 [D, C*P*P], db f32 [D] (+)= from dtokens f32 [B,T,D] */
+int reed_patch_embed_bwd(const float* x, const float* dtokens, float* dw, float* db, int B, int C,
+                         int HW, int P, int D, int accumulate, void* stream);
+/* TimestepEmbedder.positional_embedding (sit.py:45-64): out bf16 [B, dim] = [cos(t f) | sin(t f)] */
+int reed_timestep_sinusoid(const float* t, void* out, int B, int dim, float max_period, void* stream);
+/* LabelEmbedder (sit.py:84-99): labels_out = drop ? num_classes : labels; c_out f32 [B,D] = t_emb bf16 + table f32[label];
+ * silu_c bf16 [B,D] = bf16(silu(c)) (input of every adaLN linear, sit.py:126-129) */
+int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, const float* table,
+                    const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int B, int D,
+                    void* stream);
+/* backward of the conditioning vector: dc f32 [B,D] -> dt_emb bf16, dtable f32 [rows,D] (deterministic scatter) */
+int reed_label_cond_bwd(const float* dsilu_c, const float* c, const int64_t* labels_eff, void* dt_emb,
+                        float* dtable, int B, int D, int accumulate, void* stream);
+/* FinalLayer + unpatchify (sit.py:140-158,256-269): out f32 [B,C,HW,HW] */
+int reed_final_layer_fwd(const float* x, const void* shift, const void* scale, int64_t ldmod,
+                         const void* w, const void* bias, float* out, float* mean, float* rstd,
+                         int B, int T, int D, int C, int P, float eps, void* stream);
+int reed_final_layer_bwd(const float* dout, const float* x, const float* mean, const float* rstd,
+                         const void* shift, const void* scale, int64_t ldmod, const void* w,
+                         float* dx, float* part, float* dw, float* db, int B, int T, int D, int C,
+                         int P, int accumulate, void* stream);
+/* mean over tokens for the text projector (sit.py:292,301): out bf16 [B,D] = bf16(mean_t x f32 [B,T,D]) */
+int reed_token_mean_fwd(const float* x, void* out, int B, int T, int D, void* stream);
+int reed_token_mean_bwd(const void* dmean, float* dx, int B, int T, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SILoss arithmetic (loss.py:49-64,153-237)
+ * ------------------------------------------------------------------------------------------- */
+/* path_type 0 linear, 1 cosine: xt = a x + s n, target = da x + ds n */
+int reed_interpolant(const float* x, const float* noise, const float* t, float* xt, float* target,
+                     int B, int64_t per, int path_type, void* stream);
+/* loss[b] = mean((out-target)^2) */
+int reed_mse_fwd(const float* out, const float* target, float* loss, int B, int64_t per, void* stream);
+/* dout = gscale[b] * 2 (out-target) / per */
+int reed_mse_bwd(const float* out, const float* target, const float* gscale, float* dout, int B,
+                 int64_t per, void* stream);
+/* cosine alignment: loss[b] = -mean_t <normalize(z), normalize(zt)>;  zt bf16 [B*T,Z] (projector out), z f32 */
+int reed_cosine_fwd(const void* zt, const float* z, float* loss, int B, int T, int Z, void* stream);
+int reed_cosine_bwd(const void* zt, const float* z, const float* gscale, void* dzt, int B, int T,
+                    int Z, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser side (train.py:94-105 update_ema, :402-409 clip + AdamW)
+ * ------------------------------------------------------------------------------------------- */
+/* partial[i] = sum of squares of chunk i (nblocks partials); finalize: norm_clip[0]=||g||, [1]=min(1,max_norm/(||g||+1e-6)) */
+int reed_grad_sqnorm(const float* g, int64_t n, float* partial, int nblocks, void* stream);
+int reed_clip_finalize(const float* partial, int nblocks, float max_norm, float* norm_clip, void* stream);
+/* fused clip * AdamW + EMA + bf16 shadow over a flat arena; norm_clip may be NULL (no clipping) */
+int reed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow,
+                   int64_t n_train, int64_t n_total, const float* norm_clip, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float bc1, float bc2, float ema_decay,
+                   void* stream);
+int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Samplers (samplers.py:46-104,107-187): fp64 state updates
+ * ------------------------------------------------------------------------------------------- */
+/* d = cfg ? d_u + s (d_c - d_u) : d_c  (model out f32 [2n or n]); x_next = x_cur + dt * (w0 d + w1 d_prev)
+ * d_store (f64, optional) receives d for Heun's second stage. */
+int reed_sampler_update(const double* x_cur, const float* model_out, const double* d_prev,
+                        double* d_store, double* x_next, int64_t n_elems, int cfg, double cfg_scale,
+                        double dt, double w0, double w1, void* stream);
+/* SDE step (samplers.py:146-156): drift from velocity + score, Euler-Maruyama update */
+int reed_sde_update(const double* x_cur, const float* model_out, const double* eps, double* x_next,
+                    int64_t n_elems, int cfg, double cfg_scale, double t_cur, double dt,
+                    int path_type, int last_step, void* stream);
+/* model input f32 [2n or n] = f32(x f64) (duplicated when cfg) */
+int reed_sampler_input(const double* x, float* out, int64_t n_elems, int dup, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gradient all-reduce over RCCL/xGMI (replaces accelerate->DDP bucketed all-reduce, train.py:293-295,401)
+ * ------------------------------------------------------------------------------------------- */
+int reed_comm_unique_id(void* out128);                       /* 128-byte ncclUniqueId */
+int reed_comm_init(const void* id128, int rank, int world, void** comm_out);
+int reed_comm_allreduce_avg(void* comm, float* buf, int64_t count, void* compute_stream); /* async on the comm stream, ordered after compute_stream */
+int reed_comm_sync(void* comm, void* compute_stream);       /* compute_stream waits for all pending reductions */
+int reed_comm_broadcast(void* comm, float* buf, int64_t count, int root, void* compute_stream);
+int reed_comm_destroy(void* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""ctypes binding of libreed_hip.so (C ABI in include/reed_hip.h).
+
+The product path has no fallback: if the shared object is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreed_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "reed_hip.h")
+
+_lib = None
+
+_CT = {
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "double": ctypes.c_double,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """Return {name: (restype, [(ctype, argname), ...])} for every prototype in reed_hip.h."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(reed_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    alist.append((ctypes.c_void_p, a.split("*")[-1].strip()))
+                else:
+                    toks = a.replace("const ", "").split()
+                    alist.append((_CT[toks[0]], toks[-1]))
+        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, alist)
+    return protos
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"reed_amd: {LIB_PATH} not found. Build it with `python -m reed_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = []
+    for name, (restype, args) in parse_header().items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = restype
+        fn.argtypes = [t for t, _ in args]
+    lib._reed_missing = missing  # tests assert this is empty; calling a missing symbol raises
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().reed_last_error()
+        raise RuntimeError(f"reed_hip {what} failed (code {rc}): {msg.decode() if msg else ''}")

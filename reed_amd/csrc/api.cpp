@@ -1,0 +1,54 @@
+// C-ABI glue: error reporting, version, and the GEMM entry point (see include/reed_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/reed_hip.h"
+#include "common.hpp"
+#include "gemm.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void reed_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* reed_last_error(void) { return g_err; }
+extern "C" int reed_version(void) { return 100; }
+
+extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* Q,
+                         int64_t ldq, int M, int N, int K, void* C, int64_t ldc, void* C2,
+                         int64_t ldc2, const void* R, int64_t ldr, const void* bias,
+                         const void* gate, int64_t ldgate, int rows_per_gate, float* dbias,
+                         int accumulate, int split_k, int64_t slab_stride, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = (const bf16*)P;
+  a.Q = (const bf16*)Q;
+  a.ldp = ldp;
+  a.ldq = ldq;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.C = C;
+  a.ldc = ldc;
+  a.C2 = C2;
+  a.ldc2 = ldc2;
+  a.R = R;
+  a.ldr = ldr;
+  a.bias = (const bf16*)bias;
+  a.gate = (const bf16*)gate;
+  a.ldgate = ldgate;
+  a.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
+  a.dbias = dbias;
+  a.accumulate = accumulate;
+  a.slab_stride = slab_stride;
+  REED_CHECK_ARG(P && Q && C, "reed_gemm: null operand");
+  if (epilogue == EPI_GELU || epilogue == EPI_SILU) REED_CHECK_ARG(C2, "reed_gemm: activation epilogue needs C2");
+  if (epilogue == EPI_GATE_RES) REED_CHECK_ARG(R && gate, "reed_gemm: gate-residual epilogue needs R and gate");
+  if (epilogue == EPI_DGELU || epilogue == EPI_DSILU) REED_CHECK_ARG(R, "reed_gemm: activation-grad epilogue needs R");
+  return reed_gemm_launch(layout, epilogue, a, split_k, (hipStream_t)stream);
+}

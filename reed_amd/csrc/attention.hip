@@ -1,0 +1,477 @@
+// Multi-head self-attention for the SiT block (timm Attention called at image/models/sit.py:114-118,134):
+//   o = softmax(q k^T / sqrt(hd)) v      q,k,v = qkv.reshape(B,T,3,H,hd).permute(2,0,3,1,4)
+// head_dim 64 (S/B/L) or 72 (XL: 1152/16), T = 256 tokens at 256x256 / patch 2.
+//
+// MI355X design: the whole K and V of one (batch, head) fit in LDS (256 x 72 bf16 = 36 KiB each,
+// rows padded to 72 elements = 144 B for both head sizes, which also spreads the banks), so a
+// workgroup of 8 waves loads them once and every wave owns 32 query rows.  Scores are computed
+// "transposed" (S^T = K Q^T) so that one query's scores live in ONE lane's registers + its 3
+// partner lanes (lane>>4): row max / sum are in-register plus two cross-lane steps, and the
+// accumulator tile is already the B operand of the next MFMA (O^T = V^T P^T); the other operand
+// (V^T, K^T, Q^T, dO^T) comes straight from row-major LDS tiles through ds_read_b64_tr_b16.
+// No S x S matrix, no transposed copies, qkv is consumed in the layout the qkv GEMM wrote.
+// head_dim 72 is handled on chip: the third k-step (cols 64..95) uses zeroed register fragments
+// for the padded slots; the output's fifth 16-column tile is computed and only cols 64..71 stored.
+//
+// Backward recomputes P from the saved log-sum-exp and is split in two deterministic phases inside
+// one workgroup (no atomics): phase 1 gives each wave 32 query rows (dQ), phase 2 gives each wave
+// 32 key rows (dK, dV); Q, K, V, dO stay resident in LDS (147 KiB) for both.
+#include "../../include/reed_hip.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int ROWB = 144;            // LDS row stride in bytes (72 bf16)
+constexpr int TILE_B = 256 * ROWB;   // one 256-row tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int HD>
+struct Cfg {
+  static constexpr int KS = (HD + 31) / 32;  // k-steps of 32 over head_dim
+  static constexpr int DT = (HD + 15) / 16;  // 16-wide output tiles over head_dim
+  static constexpr int NCH = HD / 8;         // 16-byte chunks per row
+};
+
+template <int HD>
+__device__ __forceinline__ void load_tile(char* lds, const bf16* src, long row_stride, int rows_valid,
+                                          int tid, int nthreads) {
+  constexpr int NCH = Cfg<HD>::NCH;
+  for (int idx = tid; idx < 256 * NCH; idx += nthreads) {
+    int row = idx / NCH, c = idx - row * NCH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < rows_valid) v = *(const uint4*)(src + (long)row * row_stride + c * 8);
+    *(uint4*)(lds + row * ROWB + c * 16) = v;
+  }
+}
+
+// lane (i = lane&15, g = lane>>4): X[row0 + i][ks*32 + 8g .. +7]
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
+  return *(const bf16x8*)(tile + (row0 + (lane & 15)) * ROWB + (ks * 32 + 8 * (lane >> 4)) * 2);
+}
+// lane (i, g): X[rbase + 16*(j>>2) + 4g + (j&3)][d0 + i], j = 0..7 — the k-slot order in which an
+// MFMA accumulator tile pair (rows 4g+r of two stacked 16-row tiles) serves as the other operand.
+__device__ __forceinline__ bf16x8 frag_trT(const char* tile, int rbase, int d0, int lane) {
+  int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+  const char* a0 = tile + (rbase + 4 * g + q) * ROWB + (d0 + 4 * p) * 2;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 16 * ROWB));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 load_frag_global(const bf16* rowptr, bool row_ok, int ks, int lane) {
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+  int col = ks * 32 + 8 * (lane >> 4);
+  if (row_ok && col < HD) z = *(const bf16x8*)(rowptr + col);
+  return z;
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows_z(const char* tile, int row0, int ks, int lane) {
+  // register-resident operand: padded k-slots (col >= HD) must be exact zeros
+  bf16x8 f = frag_rows(tile, row0, ks, lane);
+  if (HD % 32 != 0 && ks * 32 + 8 * (lane >> 4) >= HD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
+  }
+  return f;
+}
+__device__ __forceinline__ bf16x8 pack2(f32x4 a, f32x4 b) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = f2bf(a[j]); r[4 + j] = f2bf(b[j]); }
+  return r;
+}
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                       float* __restrict__ lse, int B, int T, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long tok = 3l * D;
+  const bf16* base = qkv + (long)b * T * tok + h * HD;
+  char* Kt = smem;
+  char* Vt = smem + TILE_B;
+  if (tid < 16) *(uint4*)(smem + 2 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);  // finite pad
+  const int q0 = blockIdx.y * 256 + wave * 32;
+  const bool active = q0 < T;
+  const float sc2 = rsqrtf((float)HD) * LOG2E;
+
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int row = q0 + 16 * qt + i;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = load_frag_global<HD>(base + (long)row * tok, row < T, ks, lane);
+  }
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  f32x4 ot[2][DT];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) ot[qt][dt] = zero4();
+
+  for (int kv0 = 0; kv0 < T; kv0 += 256) {
+    __syncthreads();
+    const int rows = min(256, T - kv0);
+    load_tile<HD>(Kt, base + (long)kv0 * tok + D, tok, rows, tid, 512);
+    load_tile<HD>(Vt, base + (long)kv0 * tok + 2 * D, tok, rows, tid, 512);
+    __syncthreads();
+    if (!active) continue;
+    const int nsub = (rows + 63) >> 6;
+    for (int sub = 0; sub < nsub; ++sub) {
+      const int kvs = sub * 64;
+      f32x4 st[2][4];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) st[qt][kt] = zero4();
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 kf = frag_rows(Kt, kvs + 16 * kt, ks, lane);
+          st[0][kt] = MFMA(kf, qf[0][ks], st[0][kt]);
+          st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
+        }
+      bf16x8 pb[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int kv = kv0 + kvs + 16 * kt + 4 * g + r;
+            float s = kv < T ? st[qt][kt][r] * sc2 : -INFINITY;
+            st[qt][kt][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
+        m[qt] = mnew;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(st[qt][kt][r] - mnew);
+            st[qt][kt][r] = p;
+            sum += p;
+          }
+        l[qt] = l[qt] * alpha + sum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[qt][dt] *= alpha;
+        pb[qt][0] = pack2(st[qt][0], st[qt][1]);
+        pb[qt][1] = pack2(st[qt][2], st[qt][3]);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          bf16x8 vf = frag_trT(Vt, kvs + 32 * s, 16 * dt, lane);
+          ot[0][dt] = MFMA(vf, pb[0][s], ot[0][dt]);
+          ot[1][dt] = MFMA(vf, pb[1][s], ot[1][dt]);
+        }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float lt = l[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = 1.f / lt;
+    const int q = q0 + 16 * qt + i;
+    if (q < T) {
+      bf16* orow = o + ((long)b * T + q) * D + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        int d = 16 * dt + 4 * g;
+        if (d < HD) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(ot[qt][dt][r] * inv);
+          *(bf16x4*)(orow + d) = v;
+        }
+      }
+      if (g == 0 && lse) lse[((long)b * H + h) * T + q] = m[qt] * LN2 + __logf(lt);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                       const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                       bf16* __restrict__ dqkv, int B, int T, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int D = H * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long tok = 3l * D;
+  const bf16* base = qkv + (long)b * T * tok + h * HD;
+  bf16* dbase = dqkv + (long)b * T * tok + h * HD;
+  char* Qt = smem;
+  char* Kt = smem + TILE_B;
+  char* Vt = smem + 2 * TILE_B;
+  char* Gt = smem + 3 * TILE_B;  // dO
+  float* lse2 = (float*)(smem + 4 * TILE_B + 256);
+  float* dlt = lse2 + 256;
+  if (tid < 16) *(uint4*)(smem + 4 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);
+  const float scale = rsqrtf((float)HD);
+  const float sc2 = scale * LOG2E;
+
+  load_tile<HD>(Qt, base, tok, T, tid, 512);
+  load_tile<HD>(Kt, base + D, tok, T, tid, 512);
+  load_tile<HD>(Vt, base + 2 * D, tok, T, tid, 512);
+  load_tile<HD>(Gt, d_o + (long)b * T * D + h * HD, D, T, tid, 512);
+  {
+    // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per row
+    const int row = tid >> 1, half = tid & 1;
+    float acc = 0.f;
+    if (row < T) {
+      const bf16* orow = o + ((long)b * T + row) * D + h * HD;
+      const bf16* grow = d_o + ((long)b * T + row) * D + h * HD;
+      for (int c = half; c < NCH; c += 2) {
+        bf16x8 a = *(const bf16x8*)(orow + c * 8), bb = *(const bf16x8*)(grow + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(bb[j]);
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) {
+      dlt[row] = row < T ? acc : 0.f;
+      lse2[row] = row < T ? lse[((long)b * H + h) * T + row] * LOG2E : INFINITY;
+    }
+  }
+  __syncthreads();
+
+  const int r0 = wave * 32;  // this wave's 32 rows (queries in phase 1, keys in phase 2)
+  if (r0 < T) {
+    // ---------------- phase 1: dQ for queries [r0, r0+32) ----------------
+    bf16x8 qf[2][KS], gf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qf[qt][ks] = frag_rows_z<HD>(Qt, r0 + 16 * qt, ks, lane);
+        gf[qt][ks] = frag_rows_z<HD>(Gt, r0 + 16 * qt, ks, lane);
+      }
+    float lq[2], dq_[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) { lq[qt] = lse2[r0 + 16 * qt + i]; dq_[qt] = dlt[r0 + 16 * qt + i]; }
+    f32x4 dq[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = zero4();
+    const int nblk = (T + 31) >> 5;
+    for (int kb = 0; kb < nblk; ++kb) {
+      const int kv0 = kb * 32;
+      f32x4 st[2][2], dp[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { st[qt][kt] = zero4(); dp[qt][kt] = zero4(); }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 kf = frag_rows(Kt, kv0 + 16 * kt, ks, lane);
+          bf16x8 vf = frag_rows(Vt, kv0 + 16 * kt, ks, lane);
+          st[0][kt] = MFMA(kf, qf[0][ks], st[0][kt]);
+          st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
+          dp[0][kt] = MFMA(vf, gf[0][ks], dp[0][kt]);
+          dp[1][kt] = MFMA(vf, gf[1][ks], dp[1][kt]);
+        }
+      bf16x8 dsb[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int kv = kv0 + 16 * kt + 4 * g + r;
+            float p = kv < T ? __builtin_amdgcn_exp2f(st[qt][kt][r] * sc2 - lq[qt]) : 0.f;
+            st[qt][kt][r] = p * (dp[qt][kt][r] - dq_[qt]);
+          }
+        dsb[qt] = pack2(st[qt][0], st[qt][1]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x8 ktf = frag_trT(Kt, kv0, 16 * dt, lane);
+        dq[0][dt] = MFMA(ktf, dsb[0], dq[0][dt]);
+        dq[1][dt] = MFMA(ktf, dsb[1], dq[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = r0 + 16 * qt + i;
+      if (q < T) {
+        bf16* row = dbase + (long)q * tok;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          int d = 16 * dt + 4 * g;
+          if (d < HD) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[qt][dt][r] * scale);
+            *(bf16x4*)(row + d) = v;
+          }
+        }
+      }
+    }
+  }
+  if (r0 < T) {
+    // ---------------- phase 2: dK, dV for keys [r0, r0+32) ----------------
+    bf16x8 kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
+        vf[ct][ks] = frag_rows_z<HD>(Vt, r0 + 16 * ct, ks, lane);
+      }
+    f32x4 dk[2][DT], dv[2][DT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
+    const int nblk = (T + 31) >> 5;
+    for (int qb = 0; qb < nblk; ++qb) {
+      const int qq0 = qb * 32;
+      f32x4 st[2][2], dp[2][2];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 qa = frag_rows(Qt, qq0 + 16 * qt, ks, lane);
+          bf16x8 ga = frag_rows(Gt, qq0 + 16 * qt, ks, lane);
+          st[qt][0] = MFMA(qa, kf[0][ks], st[qt][0]);
+          st[qt][1] = MFMA(qa, kf[1][ks], st[qt][1]);
+          dp[qt][0] = MFMA(ga, vf[0][ks], dp[qt][0]);
+          dp[qt][1] = MFMA(ga, vf[1][ks], dp[qt][1]);
+        }
+      f32x4 lq4[2], dl4[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
+        dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
+      }
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 p0, p1, s0, s1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0[r] = __builtin_amdgcn_exp2f(st[0][ct][r] * sc2 - lq4[0][r]);
+          p1[r] = __builtin_amdgcn_exp2f(st[1][ct][r] * sc2 - lq4[1][r]);
+          s0[r] = p0[r] * (dp[0][ct][r] - dl4[0][r]);
+          s1[r] = p1[r] * (dp[1][ct][r] - dl4[1][r]);
+        }
+        pb[ct] = pack2(p0, p1);
+        dsb[ct] = pack2(s0, s1);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x8 gtf = frag_trT(Gt, qq0, 16 * dt, lane);
+        bf16x8 qtf = frag_trT(Qt, qq0, 16 * dt, lane);
+        dv[0][dt] = MFMA(gtf, pb[0], dv[0][dt]);
+        dv[1][dt] = MFMA(gtf, pb[1], dv[1][dt]);
+        dk[0][dt] = MFMA(qtf, dsb[0], dk[0][dt]);
+        dk[1][dt] = MFMA(qtf, dsb[1], dk[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int kv = r0 + 16 * ct + i;
+      if (kv < T) {
+        bf16* krow = dbase + (long)kv * tok + D;
+        bf16* vrow = dbase + (long)kv * tok + 2 * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          int d = 16 * dt + 4 * g;
+          if (d < HD) {
+            bf16x4 a, c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = f2bf(dk[ct][dt][r] * scale); c[r] = f2bf(dv[ct][dt][r]); }
+            *(bf16x4*)(krow + d) = a;
+            *(bf16x4*)(vrow + d) = c;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { reed_set_error("hipFuncSetAttribute(LDS=%d): %s", bytes, hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int hd,
+                                  void* stream) {
+  REED_CHECK_ARG(qkv && o, "attention_fwd: null pointer");
+  REED_CHECK_ARG(hd == 64 || hd == 72, "attention: head_dim %d unsupported (64 or 72)", hd);
+  REED_CHECK_ARG(B > 0 && T > 0 && H > 0, "attention: bad dims B=%d T=%d H=%d", B, T, H);
+  const int lds = 2 * TILE_B + 256;
+  dim3 grid(B * H, (T + 255) / 256);
+  if (hd == 64) {
+    static int once = set_lds(attn_fwd_kernel<64>, lds);
+    if (once) return once;
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+                       (bf16*)o, lse, B, T, H);
+  } else {
+    static int once = set_lds(attn_fwd_kernel<72>, lds);
+    if (once) return once;
+    hipLaunchKernelGGL(attn_fwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+                       (bf16*)o, lse, B, T, H);
+  }
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
+                                  void* dqkv, int B, int T, int H, int hd, void* stream) {
+  REED_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attention_bwd: null pointer");
+  REED_CHECK_ARG(hd == 64 || hd == 72, "attention: head_dim %d unsupported (64 or 72)", hd);
+  REED_CHECK_ARG(T > 0 && T <= 256, "attention_bwd: T=%d unsupported (training path is T <= 256)", T);
+  const int lds = 4 * TILE_B + 256 + 2048;
+  dim3 grid(B * H);
+  if (hd == 64) {
+    static int once = set_lds(attn_bwd_kernel<64>, lds);
+    if (once) return once;
+    hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+  } else {
+    static int once = set_lds(attn_bwd_kernel<72>, lds);
+    if (once) return once;
+    hipLaunchKernelGGL(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+  }
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}

@@ -1,0 +1,79 @@
+// Shared device/host helpers for the reed_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define REED_OK 0
+#define REED_ERR_ARG 1001       // bad argument (shape/alignment/unsupported dim)
+#define REED_ERR_UNSUPPORTED 1002
+
+// Error string storage lives in api.cpp.
+extern "C" void reed_set_error(const char* fmt, ...);
+
+#define REED_CHECK_ARG(cond, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      reed_set_error(__VA_ARGS__);       \
+      return REED_ERR_ARG;               \
+    }                                    \
+  } while (0)
+
+#define REED_LAUNCH_CHECK()                                        \
+  do {                                                             \
+    hipError_t e__ = hipGetLastError();                            \
+    if (e__ != hipSuccess) {                                       \
+      reed_set_error("HIP launch error: %s", hipGetErrorString(e__)); \
+      return (int)e__;                                             \
+    }                                                              \
+  } while (0)
+
+// ---- scalar helpers -------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float bfround(float x) { return (float)(bf16)x; }
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.f + tanhf(inner));
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float inner = k0 * (x + k1 * x * x2);
+  float t = tanhf(inner);
+  float dinner = k0 * (1.f + 3.f * k1 * x2);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * dinner;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+
+// ---- wave / block reductions (wave = 64 lanes) -----------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,39 @@
+// Internal GEMM interface (see gemm.hip). Public C ABI is in include/reed_hip.h.
+#pragma once
+#include "common.hpp"
+
+enum { LAY_NT = 0, LAY_NN = 1, LAY_TN = 2 };
+enum {
+  EPI_BF16 = 0,       // C bf16 = bf16(acc [+bias])
+  EPI_GELU = 1,       // C bf16 = pre = bf16(acc+bias) (optional), C2 bf16 = gelu_tanh(pre)
+  EPI_SILU = 2,       // same with SiLU
+  EPI_GATE_RES = 3,   // C f32 = R f32 + bf16(gate[m/rows_per_gate] * bf16(acc+bias)); C2 bf16 = y (optional)
+  EPI_DGELU = 4,      // C bf16 = bf16(bf16(acc) * gelu_tanh'(R bf16))
+  EPI_DSILU = 5,      // C bf16 = bf16(bf16(acc) * silu'(R bf16))
+  EPI_F32 = 6,        // C f32 (+)= acc [+bias]; split-K writes slabs C + z*slab_stride
+  EPI_ADDF32_RB = 7,  // C f32 += float(bf16(acc))
+  EPI_ATOMIC_F32 = 8  // atomicAdd(C f32, acc)   (split-K into a pre-zeroed / accumulating buffer)
+};
+
+struct GemmArgs {
+  const bf16* P;
+  const bf16* Q;
+  long ldp, ldq;
+  int M, N, K;
+  void* C;
+  long ldc;
+  void* C2;
+  long ldc2;
+  const void* R;
+  long ldr;
+  const bf16* bias;
+  const bf16* gate;
+  long ldgate;
+  int rows_per_gate;
+  float* dbias;  // TN only: dbias[m] (+)= sum_k P[k][m]
+  int accumulate;
+  int ksplit_len;
+  long slab_stride;
+};
+
+int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);

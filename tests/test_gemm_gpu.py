@@ -1,0 +1,144 @@
+"""GEMM parity on the GPU: HIP bf16-MFMA kernels vs a plain PyTorch fp32 reference of the same
+op on bf16-rounded operands (tolerance: fp32 accumulation-order noise + one bf16 output rounding)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 384, 1152), (200, 256, 128), (8, 128, 256), (1024, 1152, 4608)])
+def test_nt_bias(dev, M, N, K):
+    from reed_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.linear_fwd(x, w, b, out)
+    ref = (x.float() @ w.float().t() + b.float())
+    torch.testing.assert_close(out.float(), ref.to(torch.bfloat16).float(), atol=2e-2, rtol=2e-2)
+    # tighter: compare against fp32 ref with bf16 half-ulp slack
+    err = (out.float() - ref).abs().max().item()
+    assert err <= ref.abs().max().item() * 2 ** -7, err
+
+
+def test_nt_asymmetric_identity(dev):
+    """A = I against an asymmetric B catches transposed C writes / swapped fragment maps."""
+    from reed_amd import ops
+    N = K = 128
+    M = 128
+    x = torch.eye(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.arange(N * K, device=dev).reshape(N, K) % 251).float().to(torch.bfloat16)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ops.linear_fwd(x, w, None, out)
+    assert torch.equal(out.float(), w.float().t().contiguous())
+
+
+def test_epilogues(dev):
+    from reed_amd import ops
+    M, N, K, T = 512, 256, 128, 256
+    g = torch.Generator().manual_seed(1)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    pre_ref = _bf(x.float() @ w.float().t() + b.float())
+    # gelu / silu
+    for epi, fn in ((ops.EPI_GELU, _gelu), (ops.EPI_SILU, torch.nn.functional.silu)):
+        pre = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        act = torch.zeros_like(pre)
+        ops.linear_fwd(x, w, b, pre, epi=epi, act_out=act)
+        torch.testing.assert_close(pre.float(), pre_ref.float(), atol=2e-2, rtol=2e-2)
+        torch.testing.assert_close(act.float(), _bf(fn(pre.float())).float(), atol=1e-2, rtol=1e-2)
+    # gate + residual
+    gate = _bf(torch.randn(M // T, 3 * N, generator=g)).to(dev)
+    xin = torch.randn(M, N, generator=g).to(dev)
+    xout = torch.zeros(M, N, device=dev)
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    gv = gate[:, N:2 * N]
+    ops.linear_fwd(x, w, b, xout, epi=ops.EPI_GATE_RES, R=xin, gate=gv, ldgate=gate.stride(0),
+                   rows_per_gate=T, y_out=y)
+    torch.testing.assert_close(y.float(), pre_ref.float(), atol=2e-2, rtol=2e-2)
+    ref = xin + _bf(gv.float().repeat_interleave(T, 0) * y.float()).float()
+    torch.testing.assert_close(xout, ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 1152, 384), (8, 256, 1152)])
+def test_nn_dgrad(dev, M, N, K):
+    """dx[M,K] = dy[M,N] @ w[N,K]"""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(7)
+    dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    dx = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+    ops.linear_dgrad(dy, w, dx)
+    ref = dy.float() @ w.float()
+    err = (dx.float() - ref).abs().max().item()
+    assert err <= ref.abs().max().item() * 2 ** -7, err
+    # dgelu epilogue
+    pre = _bf(torch.randn(M, K, generator=g)).to(dev)
+    dx2 = torch.zeros_like(dx)
+    ops.linear_dgrad(dy, w, dx2, epi=ops.EPI_DGELU, R=pre)
+    p32 = pre.float().requires_grad_(True)
+    _gelu(p32).backward(_bf(ref).float())
+    torch.testing.assert_close(dx2.float(), p32.grad, atol=3e-2, rtol=3e-2)
+
+
+def test_nn_asymmetric(dev):
+    from reed_amd import ops
+    M = N = K = 128
+    dy = torch.eye(M, N, device=dev).to(torch.bfloat16)
+    w = (torch.arange(N * K, device=dev).reshape(N, K) % 251).float().to(torch.bfloat16)
+    dx = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+    ops.linear_dgrad(dy, w, dx)
+    assert torch.equal(dx.float(), w.float())
+
+
+@pytest.mark.parametrize("Mtok,N,K,split", [(256, 128, 128, 1), (1000, 384, 256, 1), (8, 128, 128, 1), (2048, 256, 128, 4)])
+def test_tn_wgrad(dev, Mtok, N, K, split):
+    """dw[N,K] = dy[Mtok,N]^T @ x[Mtok,K]; dbias = colsum(dy)"""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dy = _bf(torch.randn(Mtok, N, generator=g)).to(dev)
+    x = _bf(torch.randn(Mtok, K, generator=g)).to(dev)
+    dw = torch.zeros(N, K, device=dev)
+    db = torch.zeros(N, device=dev)
+    ops.linear_wgrad(dy, x, dw, dbias=db, split_k=split)
+    ref = dy.float().t() @ x.float()
+    torch.testing.assert_close(dw, ref, atol=1e-2, rtol=1e-3)
+    torch.testing.assert_close(db, dy.float().sum(0), atol=1e-2, rtol=1e-3)
+    if split == 1:
+        ops.linear_wgrad(dy, x, dw, dbias=db, accumulate=True)
+        torch.testing.assert_close(dw, 2 * ref, atol=2e-2, rtol=1e-3)
+        torch.testing.assert_close(db, 2 * dy.float().sum(0), atol=2e-2, rtol=1e-3)
+
+
+def test_tn_asymmetric(dev):
+    from reed_amd import ops
+    Mtok, N, K = 128, 128, 128
+    dy = torch.eye(Mtok, N, device=dev).to(torch.bfloat16)
+    x = (torch.arange(Mtok * K, device=dev).reshape(Mtok, K) % 251).float().to(torch.bfloat16)
+    dw = torch.zeros(N, K, device=dev)
+    ops.linear_wgrad(dy, x, dw)
+    assert torch.equal(dw, x.float())
+    # and the other way: x = I
+    x2 = torch.eye(Mtok, K, device=dev).to(torch.bfloat16)
+    dy2 = (torch.arange(Mtok * N, device=dev).reshape(Mtok, N) % 241).float().to(torch.bfloat16)
+    ops.linear_wgrad(dy2, x2, dw)
+    assert torch.equal(dw, dy2.float().t().contiguous())
+
+
+def test_gemm_arg_errors(dev):
+    from reed_amd import ops
+    x = torch.zeros(128, 64, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(100, 64, dtype=torch.bfloat16, device=dev)
+    out = torch.zeros(128, 100, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        ops.linear_fwd(x, w, None, out)
