@@ -1,0 +1,330 @@
+// HBM-bound row kernels around the GEMMs of a SiT block (image/models/sit.py:26-27,113,119,130-137):
+// LayerNorm(eps, no affine) + modulate forward/backward, the adaLN gate backward, the reduction of
+// per-chunk column partials into bf16 modulation gradients, token mean (text projector tap) and casts.
+// One wave (64 lanes) owns one token row; lanes own interleaved float4 columns, so every access is a
+// 16-byte (f32) or 8-byte (bf16) per-lane coalesced vector access.  D <= 1280, D % 4 == 0.
+#include "../../include/reed_hip.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXV = 5;  // float4 per lane: D <= 64*4*5 = 1280
+
+__device__ __forceinline__ f32x4 ld_bf4(const bf16* p) {
+  bf16x4 v = *(const bf16x4*)p;
+  return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+}
+__device__ __forceinline__ void st_bf4(bf16* p, f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+  *(bf16x4*)p = o;
+}
+
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const bf16* __restrict__ shift,
+                                                         const bf16* __restrict__ scale, long ldmod,
+                                                         bf16* __restrict__ h, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int M, int D, int T, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63, nv = D >> 2;
+  const float* xr = x + (long)row * D;
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+      v[k] = *(const f32x4*)(xr + idx * 4);
+      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+  }
+  bf16* hr = h + (long)row * D;
+  if (scale == nullptr) {  // plain cast
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) st_bf4(hr + idx * 4, v[k]);
+    }
+    return;
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float d = v[k][j] - mu; q += d * d; }
+    }
+  }
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = r; }
+  const bf16* sc = scale + (long)(row / T) * ldmod;
+  const bf16* sh = shift + (long)(row / T) * ldmod;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+      f32x4 a = ld_bf4(sc + idx * 4), b = ld_bf4(sh + idx * 4), o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mu) * r * bfround(1.f + a[j]) + b[j];
+      st_bf4(hr + idx * 4, o);
+    }
+  }
+}
+
+// 16 rows per block (4 per wave); all 16 rows belong to one sample (T % 16 == 0).
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict__ dh, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const bf16* __restrict__ scale, long ldmod,
+                                                         float* __restrict__ dx, float* __restrict__ part, int M,
+                                                         int D, int T) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][D]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
+  const int row0 = blockIdx.x * 16 + wave * 4;
+  const bf16* sc = scale + (long)((blockIdx.x * 16) / T) * ldmod;
+  f32x4 s1[MAXV], ps[MAXV], pq[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    ps[k] = f32x4{0, 0, 0, 0};
+    pq[k] = f32x4{0, 0, 0, 0};
+    if (idx < nv) {
+      f32x4 a = ld_bf4(sc + idx * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s1[k][j] = bfround(1.f + a[j]);
+    }
+  }
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    const float mu = mean[row], r = rstd[row];
+    f32x4 xh[MAXV], gy[MAXV];
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) {
+        f32x4 xv = *(const f32x4*)(x + (long)row * D + idx * 4);
+        f32x4 g = ld_bf4(dh + (long)row * D + idx * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[k][j] = (xv[j] - mu) * r;
+          gy[k][j] = g[j] * s1[k][j];
+          a1 += gy[k][j];
+          a2 += gy[k][j] * xh[k][j];
+          ps[k][j] += g[j];
+          pq[k][j] += g[j] * xh[k][j];
+        }
+      }
+    }
+    a1 = wave_sum(a1) / D;
+    a2 = wave_sum(a2) / D;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) {
+        float* dp = dx + (long)row * D + idx * 4;
+        f32x4 o = *(const f32x4*)dp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += r * (gy[k][j] - a1 - xh[k][j] * a2);
+        *(f32x4*)dp = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+      *(f32x4*)(red + (wave * 2 + 0) * D + idx * 4) = ps[k];
+      *(f32x4*)(red + (wave * 2 + 1) * D + idx * 4) = pq[k];
+    }
+  }
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * 2 * D;
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    out[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y,
+                                                       const bf16* __restrict__ gate, long ldgate,
+                                                       bf16* __restrict__ dy, float* __restrict__ part, int M, int D,
+                                                       int T) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][D]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
+  const int row0 = blockIdx.x * 16 + wave * 4;
+  const bf16* gp = gate + (long)((blockIdx.x * 16) / T) * ldgate;
+  f32x4 gv[MAXV], pg[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    pg[k] = f32x4{0, 0, 0, 0};
+    if (idx < nv) gv[k] = ld_bf4(gp + idx * 4);
+  }
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) {
+        f32x4 d = *(const f32x4*)(dx + (long)row * D + idx * 4);
+        f32x4 yv = ld_bf4(y + (long)row * D + idx * 4), o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float dg = bfround(d[j]);
+          o[j] = dg * gv[k][j];
+          pg[k][j] += bfround(dg * yv[j]);
+        }
+        st_bf4(dy + (long)row * D + idx * 4, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) *(f32x4*)(red + wave * D + idx * 4) = pg[k];
+  }
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * D;
+  for (int i = threadIdx.x; i < D; i += 256) out[i] = red[i] + red[D + i] + red[2 * D + i] + red[3 * D + i];
+}
+
+struct PartList {
+  const float* ptr[8];
+  long stride[8];
+  long off[8];
+  int n;
+};
+__global__ void reduce_mod_parts_kernel(PartList pl, bf16* __restrict__ dmod, long ld, int D, int chunks) {
+  const int b = blockIdx.y, j = blockIdx.z;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float* p = pl.ptr[j] + (long)b * chunks * pl.stride[j] + d;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += p[(long)c * pl.stride[j]];
+  dmod[(long)b * ld + pl.off[j] + d] = f2bf(s);
+}
+
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ out,
+                                                             int T, int D) {
+  const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float* p = x + (long)b * T * D + d;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += p[(long)t * D];
+  out[(long)b * D + d] = f2bf(s / T);
+}
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const bf16* __restrict__ dmean, float* __restrict__ dx,
+                                                             int T, int D) {
+  const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float g = bf2f(dmean[(long)b * D + d]) / T;
+  float* p = dx + (long)b * T * D + d;
+  for (int t = 0; t < T; ++t) p[(long)t * D] += g;
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n4,
+                                                        long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  for (; i < n4; i += stride) st_bf4(d + i * 4, *(const f32x4*)(s + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long k = (n4 << 2) + threadIdx.x;
+    d[k] = f2bf(s[k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride, int ns,
+                                                           float* __restrict__ out, long n, int accumulate) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.f;
+  for (int z = 0; z < ns; ++z) s += slabs[(long)z * stride + i];
+  out[i] = s;
+}
+
+}  // namespace
+
+extern "C" int reed_ln_modulate_fwd(const float* x, const void* shift, const void* scale, int64_t ldmod,
+                                    void* h, float* mean, float* rstd, int M, int D, int T, float eps,
+                                    void* stream) {
+  REED_CHECK_ARG(x && h, "ln_modulate_fwd: null pointer");
+  REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported (multiple of 4, <= %d)", D, 256 * MAXV);
+  REED_CHECK_ARG(M > 0 && T > 0, "ln_modulate: bad M=%d T=%d", M, T);
+  REED_CHECK_ARG((scale == nullptr) == (shift == nullptr), "ln_modulate: shift and scale must both be given or both NULL");
+  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, (const bf16*)shift,
+                     (const bf16*)scale, (long)ldmod, (bf16*)h, mean, rstd, M, D, T, eps);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_ln_modulate_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
+                                    const void* scale, int64_t ldmod, float* dx, float* part, int M, int D,
+                                    int T, void* stream) {
+  REED_CHECK_ARG(dh && x && mean && rstd && scale && dx && part, "ln_modulate_bwd: null pointer");
+  REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
+  REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd: T=%d, M=%d must be multiples of 16", T, M);
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
+                     (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, M, D, T);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,
+                             float* part, int M, int D, int T, void* stream) {
+  REED_CHECK_ARG(dx && y && gate && dy && part, "gate_bwd: null pointer");
+  REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "gate_bwd: D=%d unsupported", D);
+  REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "gate_bwd: T=%d, M=%d must be multiples of 16", T, M);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(M / 16), dim3(256), 4 * D * sizeof(float), (hipStream_t)stream, dx,
+                     (const bf16*)y, (const bf16*)gate, (long)ldgate, (bf16*)dy, part, M, D, T);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_reduce_mod_parts(const float* const* parts, const int64_t* strides, const int64_t* offs,
+                                     int nparts, void* dmod, int64_t lddmod, int B, int D, int chunks,
+                                     void* stream) {
+  REED_CHECK_ARG(nparts >= 1 && nparts <= 8, "reduce_mod_parts: nparts=%d out of range", nparts);
+  PartList pl;
+  pl.n = nparts;
+  for (int i = 0; i < nparts; ++i) { pl.ptr[i] = parts[i]; pl.stride[i] = strides[i]; pl.off[i] = offs[i]; }
+  hipLaunchKernelGGL(reduce_mod_parts_kernel, dim3(cdiv(D, 256), B, nparts), dim3(256), 0, (hipStream_t)stream, pl,
+                     (bf16*)dmod, (long)lddmod, D, chunks);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_token_mean_fwd(const float* x, void* out, int B, int T, int D, void* stream) {
+  hipLaunchKernelGGL(token_mean_fwd_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, T, D);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+extern "C" int reed_token_mean_bwd(const void* dmean, float* dx, int B, int T, int D, void* stream) {
+  hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)dmean, dx, T, D);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (n <= 0) return REED_OK;
+  REED_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "cast_bf16: misaligned");
+  long n4 = n >> 2;
+  int blocks = (int)(n4 / 256 + 1);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n4, (long)n);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_reduce_slabs(const float* slabs, int64_t stride, int nslabs, float* out, int64_t n,
+                                 int accumulate, void* stream) {
+  if (n <= 0) return REED_OK;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, slabs, (long)stride,
+                     nslabs, out, (long)n, accumulate);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}

@@ -67,3 +67,14 @@ def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1):
     epi = EPI_ATOMIC_F32 if split_k > 1 else EPI_F32
     gemm(TN, epi, dy, x, N, K, Mtok, dw, dy.stride(0), x.stride(0), dw.stride(0), dbias=dbias,
          accumulate=accumulate, split_k=split_k)
+
+
+def attention_fwd(qkv, o, lse, B, T, H, hd):
+    L = _lib.load()
+    _lib.check(L.reed_attention_fwd(_p(qkv), _p(o), _p(lse), B, T, H, hd, _stream()), "attention_fwd")
+
+
+def attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd):
+    L = _lib.load()
+    _lib.check(L.reed_attention_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream()),
+               "attention_bwd")

@@ -1,0 +1,75 @@
+"""Attention parity on the GPU vs a plain PyTorch fp32 softmax(q k^T / sqrt(hd)) v on the same
+bf16-rounded q, k, v (timm Attention semantics, qkv layout [B,T,3,H,hd])."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(qkv, B, T, H, hd):
+    q, k, v = qkv.float().reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    s = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B, T, H * hd)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 256, 16, 72), (3, 256, 6, 64), (2, 64, 4, 72), (1, 16, 2, 64),
+                                       (1, 100, 2, 72), (1, 1024, 2, 72), (1, 320, 3, 64)])
+def test_attention_fwd(dev, B, T, H, hd):
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(B * T + hd)
+    qkv = (torch.randn(B, T, 3, H, hd, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    o = torch.full((B, T, H * hd), float("nan"), dtype=torch.bfloat16, device=dev)
+    lse = torch.full((B, H, T), float("nan"), device=dev)
+    ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+    ro, rl = _ref(qkv, B, T, H, hd)
+    torch.testing.assert_close(lse, rl, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(o.float(), ro, atol=2e-2, rtol=2e-2)
+
+
+def test_attention_fwd_exact_pattern(dev):
+    """one-hot attention (huge logit on one key) must copy that key's value row exactly:
+    catches any k-slot / transposed-read permutation error."""
+    from reed_amd import ops
+    B, T, H, hd = 1, 256, 2, 72
+    qkv = torch.zeros(B, T, 3, H, hd)
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(3))
+    # q_t = e_{c(t)} * big ; k_s = e_{c'(s)} so q_t.k_s is big iff s == perm[t]
+    for t in range(T):
+        qkv[0, t, 0, :, t % hd] = 64.0 * (1 + t // hd)
+    for s in range(T):
+        qkv[0, s, 1, :, s % hd] = 8.0 * (1 + s // hd)
+    vals = (torch.arange(T * hd).reshape(T, hd) % 127).float()
+    qkv[0, :, 2, 0] = vals
+    qkv[0, :, 2, 1] = vals.flip(0)
+    qkv = qkv.to(torch.bfloat16).to(dev)
+    o = torch.zeros(B, T, H * hd, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B, H, T, device=dev)
+    ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+    ro, _ = _ref(qkv, B, T, H, hd)
+    torch.testing.assert_close(o.float(), ro, atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 256, 16, 72), (2, 256, 6, 64), (2, 64, 4, 72), (1, 16, 2, 64), (1, 100, 2, 72)])
+def test_attention_bwd(dev, B, T, H, hd):
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(5 + T)
+    qkv = (torch.randn(B, T, 3, H, hd, generator=g)).to(torch.bfloat16).to(dev)
+    do = (torch.randn(B, T, H * hd, generator=g)).to(torch.bfloat16).to(dev)
+    o = torch.zeros(B, T, H * hd, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B, H, T, device=dev)
+    ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+    dqkv = torch.full_like(qkv, float("nan"))
+    ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd)
+    q32 = qkv.float().requires_grad_(True)
+    ro, _ = _ref(q32, B, T, H, hd)
+    ro.backward(do.float())
+    ref = q32.grad
+    assert torch.isfinite(dqkv.float()).all()
+    for w, name in enumerate("qkv"):
+        a, r = dqkv[:, :, w].float(), ref[:, :, w]
+        err = (a - r).abs().max().item()
+        assert err <= 3e-2 * max(1.0, r.abs().max().item()), (name, err, r.abs().max().item())
+        cos = torch.nn.functional.cosine_similarity(a.flatten(), r.flatten(), dim=0).item()
+        assert cos > 0.9995, (name, cos)
