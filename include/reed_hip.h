@@ -85,9 +85,17 @@ int reed_attention_bwd(const void* qkv, const void* o, const void* d_o, const fl
 /* PatchEmbed (timm, sit.py:198-200,279): tokens f32 [B,T,D] = bf16(conv_p(x bf16, W bf16)+b) + pos_embed f32 */
 int reed_patch_embed_fwd(const float* x, const void* w, const void* bias, const float* pos,
                          float* tokens, int B, int C, int HW, int P, int D, void* stream);
-/* dW f32 [D, C*P*P], db f32 [D] (+)= from dtokens f32 [B,T,D] */
-int reed_patch_embed_bwd(const float* x, const float* dtokens, float* dw, float* db, int B, int C,
-                         int HW, int P, int D, int accumulate, void* stream);
+/* patchify to bf16 rows: out bf16 [B*T, C*P*P]; order 0 = (c,pi,pj) (conv input, timm PatchEmbed),
+ * order 1 = (pi,pj,c) (the unpatchify order of sit.py:256-269) */
+int reed_patchify_bf16(const float* x, void* out, int B, int C, int HW, int P, int order, void* stream);
+/* small-K weight gradient (patch-embed conv weight, final linear): deterministic two-stage reduction over M rows
+ *   out[layout 0: d*KS+k | layout 1: k*Dw+d] (+)= sum_m wide[m,d] * small[m,k]   (wide f32 is bf16-rounded first)
+ *   colsum_wide[d] (+)= sum_m wide[m,d];  colsum_small[k] (+)= sum_m small[m,k]   (either may be NULL)
+ * ws: caller workspace of reed_smallk_wgrad_ws_floats(Dw, KS) floats. */
+int64_t reed_smallk_wgrad_ws_floats(int Dw, int KS);
+int reed_smallk_wgrad(const void* wide, int wide_is_f32, const void* small, float* ws, float* out,
+                      float* colsum_wide, float* colsum_small, int M, int Dw, int KS, int layout,
+                      int accumulate, void* stream);
 /* TimestepEmbedder.positional_embedding (sit.py:45-64): out bf16 [B, dim] = [cos(t f) | sin(t f)] */
 int reed_timestep_sinusoid(const float* t, void* out, int B, int dim, float max_period, void* stream);
 /* LabelEmbedder (sit.py:84-99): labels_out = drop ? num_classes : labels; c_out f32 [B,D] = t_emb bf16 + table f32[label];
@@ -95,17 +103,20 @@ int reed_timestep_sinusoid(const float* t, void* out, int B, int dim, float max_
 int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, const float* table,
                     const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int B, int D,
                     void* stream);
-/* backward of the conditioning vector: dc f32 [B,D] -> dt_emb bf16, dtable f32 [rows,D] (deterministic scatter) */
+/* backward of the conditioning vector: dc f32 [B,D] -> dt_emb bf16, dtable f32 [rows,D] += (deterministic scatter;
+ * dsilu_c is the f32 grad w.r.t. silu(c), bf16-rounded inside) */
 int reed_label_cond_bwd(const float* dsilu_c, const float* c, const int64_t* labels_eff, void* dt_emb,
-                        float* dtable, int B, int D, int accumulate, void* stream);
+                        float* dtable, int B, int D, void* stream);
 /* FinalLayer + unpatchify (sit.py:140-158,256-269): out f32 [B,C,HW,HW] */
 int reed_final_layer_fwd(const float* x, const void* shift, const void* scale, int64_t ldmod,
                          const void* w, const void* bias, float* out, float* mean, float* rstd,
                          int B, int T, int D, int C, int P, float eps, void* stream);
-int reed_final_layer_bwd(const float* dout, const float* x, const float* mean, const float* rstd,
-                         const void* shift, const void* scale, int64_t ldmod, const void* w,
-                         float* dx, float* part, float* dw, float* db, int B, int T, int D, int C,
-                         int P, int accumulate, void* stream);
+/* backward, row part: recompute h = bf16(modulate(LN(x))) -> hbuf bf16 [M,D]; dlin bf16 [M, P*P*C] = patchify(dout);
+ * dh bf16 [M,D] = dlin @ W.  Follow with reed_ln_modulate_bwd(dh, ...) and reed_smallk_wgrad(hbuf, dlin) */
+int reed_final_layer_bwd_rows(const float* dout, const float* x, const float* mean, const float* rstd,
+                              const void* shift, const void* scale, int64_t ldmod, const void* w,
+                              void* hbuf, void* dlin, void* dh, int B, int T, int D, int C, int P,
+                              void* stream);
 /* mean over tokens for the text projector (sit.py:292,301): out bf16 [B,D] = bf16(mean_t x f32 [B,T,D]) */
 int reed_token_mean_fwd(const float* x, void* out, int B, int T, int D, void* stream);
 int reed_token_mean_bwd(const void* dmean, float* dx, int B, int T, int D, void* stream);
@@ -122,7 +133,8 @@ int reed_mse_fwd(const float* out, const float* target, float* loss, int B, int6
 int reed_mse_bwd(const float* out, const float* target, const float* gscale, float* dout, int B,
                  int64_t per, void* stream);
 /* cosine alignment: loss[b] = -mean_t <normalize(z), normalize(zt)>;  zt bf16 [B*T,Z] (projector out), z f32 */
-int reed_cosine_fwd(const void* zt, const float* z, float* loss, int B, int T, int Z, void* stream);
+int reed_cosine_fwd(const void* zt, const float* z, float* rowdot, float* loss, int B, int T, int Z,
+                    void* stream); /* rowdot: caller scratch f32 [B*T] */
 int reed_cosine_bwd(const void* zt, const float* z, const float* gscale, void* dzt, int B, int T,
                     int Z, void* stream);
 

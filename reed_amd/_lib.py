@@ -24,7 +24,7 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(reed_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(reed_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         alist = []
         if args and args != "void":
@@ -35,7 +35,7 @@ def parse_header(path=HEADER_PATH):
                 else:
                     toks = a.replace("const ", "").split()
                     alist.append((_CT[toks[0]], toks[-1]))
-        protos[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, alist)
+        protos[name] = (ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int), alist)
     return protos
 
 

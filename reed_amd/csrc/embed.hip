@@ -1,0 +1,379 @@
+// Embedders and the final layer of SiT (image/models/sit.py): PatchEmbed (:198-200,279, timm conv k=s=P),
+// TimestepEmbedder sinusoid (:45-64), LabelEmbedder + conditioning vector (:84-99,283-285),
+// FinalLayer + unpatchify (:140-158,256-269), and the small-K weight-gradient reduction they share.
+// All of it is HBM-bound bookkeeping around the MFMA GEMMs; the index maps (patchify order (c,pi,pj) on
+// the way in, (pi,pj,c) on the way out, row-major tokens) are bit-exact restatements of the reference.
+#include "../../include/reed_hip.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXV = 5;
+constexpr int NSL = 64;  // token slices of the two-stage small-K wgrad
+
+__device__ __forceinline__ f32x4 ld_bf4(const bf16* p) {
+  bf16x4 v = *(const bf16x4*)p;
+  return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+}
+
+// ---- patchify: out bf16 [B*T, K], K = C*P*P. order 0: k = (c,pi,pj) (conv input); 1: k = (pi,pj,c) (unpatchify) ----
+__device__ __forceinline__ long patch_src(int b, int t, int k, int C, int HW, int P, int order) {
+  const int G = HW / P, ph = t / G, pw = t - ph * G;
+  int c, pi, pj;
+  if (order == 0) { c = k / (P * P); int r = k - c * P * P; pi = r / P; pj = r - pi * P; }
+  else { c = k % C; int r = k / C; pi = r / P; pj = r - pi * P; }
+  return (((long)b * C + c) * HW + ph * P + pi) * HW + pw * P + pj;
+}
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, bf16* __restrict__ out, int B,
+                                                       int C, int HW, int P, int order) {
+  const int G = HW / P, T = G * G, K = C * P * P;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * T * K) return;
+  int k = (int)(i % K);
+  long bt = i / K;
+  out[i] = f2bf(x[patch_src((int)(bt / T), (int)(bt % T), k, C, HW, P, order)]);
+}
+
+// ---- patch embed forward: 8 tokens per block ----
+__global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ x, const bf16* __restrict__ w,
+                                                              const bf16* __restrict__ bias,
+                                                              const float* __restrict__ pos, float* __restrict__ tok,
+                                                              int B, int C, int HW, int P, int D) {
+  extern __shared__ float xs[];  // [8][K]
+  const int G = HW / P, T = G * G, K = C * P * P;
+  const long bt0 = (long)blockIdx.x * 8, BT = (long)B * T;
+  for (int i = threadIdx.x; i < 8 * K; i += 256) {
+    long bt = bt0 + i / K;
+    xs[i] = bt < BT ? bfround(x[patch_src((int)(bt / T), (int)(bt % T), i % K, C, HW, P, 0)]) : 0.f;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16* wr = w + (long)d * K;
+    for (int k = 0; k < K; k += 8) {
+      bf16x8 wv = *(const bf16x8*)(wr + k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float wf = bf2f(wv[j]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[s] += wf * xs[s * K + k + j];
+      }
+    }
+    const float bv = bias ? bf2f(bias[d]) : 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      long bt = bt0 + s;
+      if (bt < BT) tok[bt * D + d] = bfround(acc[s] + bv) + pos[(bt % T) * D + d];
+    }
+  }
+}
+
+// ---- small-K weight gradient, stage 1: ws[slice] holds partial out[.] (layout 0: d*KS+k, 1: k*Dw+d),
+//      then partial colsum(wide)[Dw], then partial colsum(small)[KS] ----
+template <bool WIDE_F32>
+__global__ __launch_bounds__(256) void smallk_wgrad_kernel(const void* __restrict__ wide, const bf16* __restrict__ small,
+                                                           float* __restrict__ ws, int M, int Dw, int KS,
+                                                           int layout) {
+  extern __shared__ float sm[];  // [64][KS]
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  const int slice = blockIdx.y;
+  const int per = (M + NSL - 1) / NSL;
+  const int mbeg = slice * per, mend = min(M, mbeg + per);
+  float* wout = ws + (long)slice * ((long)KS * Dw + Dw + KS);
+  const bool dok = d < Dw;
+  for (int k0 = 0; k0 < KS; k0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    float wsum = 0.f, ssum = 0.f;
+    for (int mc = mbeg; mc < mend; mc += 64) {
+      const int nr = min(64, mend - mc);
+      __syncthreads();
+      for (int i = threadIdx.x; i < nr * KS; i += 256) sm[i] = bf2f(small[(long)mc * KS + i]);
+      __syncthreads();
+      if (blockIdx.x == 0 && threadIdx.x < 16 && k0 + threadIdx.x < KS)
+        for (int r = 0; r < nr; ++r) ssum += sm[r * KS + k0 + threadIdx.x];
+      if (dok) {
+        for (int r = 0; r < nr; ++r) {
+          float wv;
+          if (WIDE_F32) wv = bfround(((const float*)wide)[(long)(mc + r) * Dw + d]);
+          else wv = bf2f(((const bf16*)wide)[(long)(mc + r) * Dw + d]);
+          wsum += wv;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (k0 + j < KS) acc[j] += wv * sm[r * KS + k0 + j];
+        }
+      }
+    }
+    if (dok) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (k0 + j < KS) wout[layout == 0 ? (long)d * KS + k0 + j : (long)(k0 + j) * Dw + d] = acc[j];
+      if (k0 == 0) wout[(long)KS * Dw + d] = wsum;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16 && k0 + threadIdx.x < KS)
+      wout[(long)KS * Dw + Dw + k0 + threadIdx.x] = ssum;
+  }
+}
+__global__ __launch_bounds__(256) void smallk_reduce_kernel(const float* __restrict__ ws, long stride,
+                                                            float* __restrict__ o0, long n0, float* __restrict__ o1,
+                                                            long n1, float* __restrict__ o2, long n2, int accumulate) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n0 + n1 + n2) return;
+  float* dst;
+  if (i < n0) dst = o0 ? o0 + i : nullptr;
+  else if (i < n0 + n1) dst = o1 ? o1 + (i - n0) : nullptr;
+  else dst = o2 ? o2 + (i - n0 - n1) : nullptr;
+  if (!dst) return;
+  float s = accumulate ? *dst : 0.f;
+  for (int z = 0; z < NSL; ++z) s += ws[(long)z * stride + i];
+  *dst = s;
+}
+
+// ---- timestep sinusoid ----
+__global__ void sinusoid_kernel(const float* __restrict__ t, bf16* __restrict__ out, int B, int dim, float max_period) {
+  const int half = dim / 2;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * half) return;
+  int b = i / half, k = i - b * half;
+  float a = (float)(-log((double)max_period)) * (float)k;
+  float f = expf(a / (float)half);
+  float arg = t[b] * f;
+  out[(long)b * dim + k] = f2bf(cosf(arg));
+  out[(long)b * dim + half + k] = f2bf(sinf(arg));
+  if ((dim & 1) && k == 0) out[(long)b * dim + dim - 1] = f2bf(0.f);
+}
+
+// ---- label embedding + conditioning ----
+__global__ void label_cond_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ drop, int num_classes,
+                                  const float* __restrict__ table, const bf16* __restrict__ t_emb,
+                                  int64_t* __restrict__ labels_out, float* __restrict__ c, bf16* __restrict__ silu_c,
+                                  int D) {
+  const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  int64_t lab = labels[b];
+  if (drop && drop[b]) lab = num_classes;
+  if (d == 0 && labels_out) labels_out[b] = lab;
+  if (d >= D) return;
+  float v = bf2f(t_emb[(long)b * D + d]) + table[lab * D + d];
+  c[(long)b * D + d] = v;
+  silu_c[(long)b * D + d] = f2bf(silu_f(v));
+}
+__global__ void label_cond_bwd_kernel(const float* __restrict__ dsilu, const float* __restrict__ c,
+                                      const int64_t* __restrict__ labels_eff, bf16* __restrict__ dt_emb,
+                                      float* __restrict__ dtable, int B, int D) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  for (int b = 0; b < B; ++b) {  // sequential over the batch: deterministic scatter-add
+    float g = bfround(dsilu[(long)b * D + d]) * silu_grad_f(c[(long)b * D + d]);
+    dt_emb[(long)b * D + d] = f2bf(g);
+    dtable[labels_eff[b] * D + d] += g;
+  }
+}
+
+// ---- final layer forward: wave per row ----
+__global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict__ x, const bf16* __restrict__ shift,
+                                                        const bf16* __restrict__ scale, long ldmod,
+                                                        const bf16* __restrict__ w, const bf16* __restrict__ bias,
+                                                        float* __restrict__ out, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int B, int T, int D, int C, int P,
+                                                        float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int M = B * T;
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63, nv = D >> 2;
+  const float* xr = x + (long)row * D;
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) { v[k] = *(const f32x4*)(xr + idx * 4); s += v[k][0] + v[k][1] + v[k][2] + v[k][3]; }
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float d = v[k][j] - mu; q += d * d; }
+    }
+  }
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = r; }
+  const int b = row / T, t = row - b * T;
+  const bf16* sc = scale + (long)b * ldmod;
+  const bf16* sh = shift + (long)b * ldmod;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+      f32x4 a = ld_bf4(sc + idx * 4), bb = ld_bf4(sh + idx * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[k][j] = bfround((v[k][j] - mu) * r * bfround(1.f + a[j]) + bb[j]);
+    }
+  }
+  const int NO = P * P * C, HW = (int)(sqrtf((float)T) + 0.5f) * P;
+  for (int j = 0; j < NO; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) {
+        f32x4 wv = ld_bf4(w + (long)j * D + idx * 4);
+        acc += v[k][0] * wv[0] + v[k][1] * wv[1] + v[k][2] * wv[2] + v[k][3] * wv[3];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[patch_src(b, t, j, C, HW, P, 1)] = bfround(acc + (bias ? bf2f(bias[j]) : 0.f));
+  }
+}
+
+// ---- final layer backward, row part: h (bf16), dlin (bf16), dh (bf16) ----
+__global__ __launch_bounds__(256) void final_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const bf16* __restrict__ shift,
+                                                             const bf16* __restrict__ scale, long ldmod,
+                                                             const bf16* __restrict__ w, bf16* __restrict__ hbuf,
+                                                             bf16* __restrict__ dlin, bf16* __restrict__ dh, int B,
+                                                             int T, int D, int C, int P) {
+  extern __shared__ float dl[];  // [4 waves][NO]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
+  const int row = blockIdx.x * 4 + wave;
+  const int M = B * T, NO = P * P * C, HW = (int)(sqrtf((float)T) + 0.5f) * P;
+  const bool ok = row < M;
+  const int b = ok ? row / T : 0, t = ok ? row - b * T : 0;
+  float* my = dl + wave * NO;
+  if (ok) {
+    for (int j = lane; j < NO; j += 64) {
+      float g = bfround(dout[patch_src(b, t, j, C, HW, P, 1)]);
+      my[j] = g;
+      dlin[(long)row * NO + j] = f2bf(g);
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  const float mu = mean[row], r = rstd[row];
+  const bf16* sc = scale + (long)b * ldmod;
+  const bf16* sh = shift + (long)b * ldmod;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    if (idx < nv) {
+      f32x4 xv = *(const f32x4*)(x + (long)row * D + idx * 4);
+      f32x4 a = ld_bf4(sc + idx * 4), bb = ld_bf4(sh + idx * 4);
+      bf16x4 hv, gv;
+      f32x4 acc = {0, 0, 0, 0};
+      for (int j = 0; j < NO; ++j) {
+        f32x4 wv = ld_bf4(w + (long)j * D + idx * 4);
+        float g = my[j];
+        acc[0] += g * wv[0]; acc[1] += g * wv[1]; acc[2] += g * wv[2]; acc[3] += g * wv[3];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hv[j] = f2bf((xv[j] - mu) * r * bfround(1.f + a[j]) + bb[j]);
+        gv[j] = f2bf(acc[j]);
+      }
+      *(bf16x4*)(hbuf + (long)row * D + idx * 4) = hv;
+      *(bf16x4*)(dh + (long)row * D + idx * 4) = gv;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int reed_patchify_bf16(const float* x, void* out, int B, int C, int HW, int P, int order, void* stream) {
+  REED_CHECK_ARG(HW % P == 0, "patchify: HW=%d not divisible by P=%d", HW, P);
+  long n = (long)B * C * HW * HW;
+  hipLaunchKernelGGL(patchify_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, B, C, HW, P, order);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_patch_embed_fwd(const float* x, const void* w, const void* bias, const float* pos,
+                                    float* tokens, int B, int C, int HW, int P, int D, void* stream) {
+  REED_CHECK_ARG(x && w && pos && tokens, "patch_embed_fwd: null pointer");
+  REED_CHECK_ARG(HW % P == 0 && (C * P * P) % 8 == 0, "patch_embed: HW=%d P=%d C=%d unsupported", HW, P, C);
+  const int T = (HW / P) * (HW / P), K = C * P * P;
+  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(cdiv((long)B * T, 8)), dim3(256), 8 * K * sizeof(float),
+                     (hipStream_t)stream, x, (const bf16*)w, (const bf16*)bias, pos, tokens, B, C, HW, P, D);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int64_t reed_smallk_wgrad_ws_floats(int Dw, int KS) { return (int64_t)NSL * ((int64_t)KS * Dw + Dw + KS); }
+
+extern "C" int reed_smallk_wgrad(const void* wide, int wide_is_f32, const void* small, float* ws, float* out,
+                                 float* colsum_wide, float* colsum_small, int M, int Dw, int KS, int layout,
+                                 int accumulate, void* stream) {
+  REED_CHECK_ARG(wide && small && ws, "smallk_wgrad: null pointer");
+  REED_CHECK_ARG(KS >= 1 && KS <= 256, "smallk_wgrad: KS=%d out of range", KS);
+  dim3 grid(cdiv(Dw, 256), NSL);
+  size_t lds = 64 * KS * sizeof(float);
+  if (wide_is_f32)
+    hipLaunchKernelGGL(smallk_wgrad_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+  else
+    hipLaunchKernelGGL(smallk_wgrad_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+  REED_LAUNCH_CHECK();
+  long n0 = (long)KS * Dw, n1 = Dw, n2 = KS;
+  hipLaunchKernelGGL(smallk_reduce_kernel, dim3(cdiv(n0 + n1 + n2, 256)), dim3(256), 0, (hipStream_t)stream, ws,
+                     n0 + n1 + n2, out, n0, colsum_wide, n1, colsum_small, n2, accumulate);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_timestep_sinusoid(const float* t, void* out, int B, int dim, float max_period, void* stream) {
+  REED_CHECK_ARG(t && out && dim >= 2, "timestep_sinusoid: bad args");
+  hipLaunchKernelGGL(sinusoid_kernel, dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t,
+                     (bf16*)out, B, dim, max_period);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, const float* table,
+                               const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int B, int D,
+                               void* stream) {
+  REED_CHECK_ARG(labels && table && t_emb && c && silu_c, "label_cond: null pointer");
+  hipLaunchKernelGGL(label_cond_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, labels, drop,
+                     num_classes, table, (const bf16*)t_emb, labels_out, c, (bf16*)silu_c, D);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_label_cond_bwd(const float* dsilu_c, const float* c, const int64_t* labels_eff, void* dt_emb,
+                                   float* dtable, int B, int D, void* stream) {
+  REED_CHECK_ARG(dsilu_c && c && labels_eff && dt_emb && dtable, "label_cond_bwd: null pointer");
+  hipLaunchKernelGGL(label_cond_bwd_kernel, dim3(cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, dsilu_c, c,
+                     labels_eff, (bf16*)dt_emb, dtable, B, D);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_final_layer_fwd(const float* x, const void* shift, const void* scale, int64_t ldmod,
+                                    const void* w, const void* bias, float* out, float* mean, float* rstd,
+                                    int B, int T, int D, int C, int P, float eps, void* stream) {
+  REED_CHECK_ARG(x && shift && scale && w && out, "final_layer_fwd: null pointer");
+  REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
+  int G = (int)(sqrtf((float)T) + 0.5f);
+  REED_CHECK_ARG(G * G == T, "final_layer: T=%d is not a square grid", T);
+  hipLaunchKernelGGL(final_fwd_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w, (const bf16*)bias, out, mean,
+                     rstd, B, T, D, C, P, eps);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_final_layer_bwd_rows(const float* dout, const float* x, const float* mean, const float* rstd,
+                                         const void* shift, const void* scale, int64_t ldmod, const void* w,
+                                         void* hbuf, void* dlin, void* dh, int B, int T, int D, int C, int P,
+                                         void* stream) {
+  REED_CHECK_ARG(dout && x && mean && rstd && shift && scale && w && hbuf && dlin && dh, "final_layer_bwd_rows: null pointer");
+  REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
+  const int NO = P * P * C;
+  hipLaunchKernelGGL(final_bwd_rows_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 4 * NO * sizeof(float),
+                     (hipStream_t)stream, dout, x, mean, rstd, (const bf16*)shift, (const bf16*)scale, (long)ldmod,
+                     (const bf16*)w, (bf16*)hbuf, (bf16*)dlin, (bf16*)dh, B, T, D, C, P);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}

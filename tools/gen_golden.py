@@ -1,0 +1,423 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE (ChenyuWang-Monica/REED, image/) in this container.
+
+Runs only where /root/reference exists (the authoring container); the fixtures it writes are committed and are
+the only thing that travels. The reference's models/sit.py imports three classes from `timm`, which is not
+installed and not vendored (image/requirements.txt:5, unpinned): this script supplies a minimal stand-in for
+exactly those classes with timm>=0.9 semantics in a temporary directory on sys.path.
+Weights and inputs come from oracle.detfill (hash of the element index), so tests regenerate them instead of
+shipping them. Random draws inside the reference (t, noise, label drop) are injected by temporarily replacing
+torch.rand / torch.randn_like.
+
+usage: python tools/gen_golden.py [--only NAME ...] [--skip-xl]
+"""
+import argparse
+import contextlib
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import detfill  # noqa: E402
+
+REF = "/root/reference/image"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+TIMM_STANDIN = '''
+import torch, torch.nn as nn, torch.nn.functional as F
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_norm=False):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.fused_attn = True
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.q_norm = nn.LayerNorm(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = nn.LayerNorm(self.head_dim) if qk_norm else nn.Identity()
+        self.proj = nn.Linear(dim, dim)
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        q, k = self.q_norm(q), self.k_norm(k)
+        if self.fused_attn:
+            x = F.scaled_dot_product_attention(q, k, v)
+        else:
+            attn = (q * self.scale) @ k.transpose(-2, -1)
+            x = attn.softmax(dim=-1) @ v
+        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+'''
+
+
+def import_reference():
+    d = tempfile.mkdtemp(prefix="timm_standin_")
+    os.makedirs(os.path.join(d, "timm", "models"))
+    open(os.path.join(d, "timm", "__init__.py"), "w").close()
+    open(os.path.join(d, "timm", "models", "__init__.py"), "w").close()
+    with open(os.path.join(d, "timm", "models", "vision_transformer.py"), "w") as f:
+        f.write(TIMM_STANDIN)
+    sys.path.insert(0, d)
+    sys.path.insert(0, REF)
+    import loss as ref_loss  # noqa
+    import samplers as ref_samplers  # noqa
+    from models import sit as ref_sit  # noqa
+    return ref_sit, ref_loss, ref_samplers
+
+
+@contextlib.contextmanager
+def inject(t=None, noise=None, drop_u=None, eps_list=None):
+    """Replace the reference's random draws: torch.rand((B,1,1,1)) -> t, torch.rand(B) -> drop_u,
+    torch.randn_like(x) -> noise (or successive eps_list entries)."""
+    o_rand, o_randn_like = torch.rand, torch.randn_like
+    it = iter(eps_list) if eps_list is not None else None
+
+    def rand(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+        if len(shape) == 4 and t is not None:
+            return t.reshape(shape).clone()
+        if len(shape) == 1 and drop_u is not None:
+            return drop_u.clone()
+        return o_rand(*size, **kw)
+
+    def randn_like(x, **kw):
+        if it is not None:
+            return next(it).to(x.dtype).clone()
+        if noise is not None:
+            return noise.to(x.dtype).clone()
+        return o_randn_like(x, **kw)
+
+    torch.rand, torch.randn_like = rand, randn_like
+    try:
+        yield
+    finally:
+        torch.rand, torch.randn_like = o_rand, o_randn_like
+
+
+def build_ref_model(ref_sit, name, seed=0, **kw):
+    if name.startswith("SiT-S"):
+        kw.setdefault("decoder_hidden_size", 384)
+    m = ref_sit.SiT_models[name](**kw) if name in ref_sit.SiT_models else ref_sit.SiT(**kw)
+    detfill.fill_state_dict(m.state_dict(), base_seed=seed)
+    return m
+
+
+def tiny_kwargs(D=128, heads=2, depth=3, **kw):
+    d = dict(input_size=8, patch_size=2, in_channels=4, hidden_size=D, decoder_hidden_size=D, depth=depth,
+             num_heads=heads, num_classes=10, z_dims=[64], z_types=["i"], encoder_depth=2, projector_dim=128,
+             fused_attn=True, qk_norm=False)
+    d.update(kw)
+    return d
+
+
+def inputs(B, C=4, HW=32, seed=0, zdims=(), T=256, num_classes=1000):
+    x = detfill.normal((B, C, HW, HW), 1000 + seed)
+    noise = detfill.normal((B, C, HW, HW), 2000 + seed)
+    t = detfill.uniform((B,), 3000 + seed, 0.02, 0.98)
+    y = (detfill.uniform((B,), 4000 + seed, 0.0, 1.0) * num_classes).long().clamp_(0, num_classes - 1)
+    drop_u = detfill.uniform((B,), 5000 + seed, 0.0, 1.0)
+    zs = [detfill.normal((B, T, z) if kind == "i" else (B, z), 6000 + seed + 17 * j)
+          for j, (z, kind) in enumerate(zdims)]
+    return x, noise, t, y, drop_u, zs
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    p = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(p, **out)
+    print(f"  wrote {p} ({os.path.getsize(p) / 1024:.1f} KiB)")
+
+
+# ---------------------------------------------------------------------------------------------
+def g_static(ref_sit, ref_loss, ref_samplers):
+    """G-a pos-embed, G-b patch index maps, G-c timestep sinusoid."""
+    pe384 = ref_sit.get_2d_sincos_pos_embed(384, 16).astype(np.float32)
+    pe1152 = ref_sit.get_2d_sincos_pos_embed(1152, 16).astype(np.float32)
+    pe128_4 = ref_sit.get_2d_sincos_pos_embed(128, 4).astype(np.float32)
+    m = ref_sit.SiT(**tiny_kwargs(input_size=32, D=64, heads=1, depth=1))
+    # unpatchify on arange
+    T, NO = 256, 16
+    un = m.unpatchify(torch.arange(T * NO, dtype=torch.float32).reshape(1, T, NO)).long()
+    # patchify order via one-hot conv weights: token feature k picks input element k of the patch
+    with torch.no_grad():
+        w = torch.zeros(64, 4, 2, 2)
+        for k in range(16):
+            w.view(64, 16)[k, k] = 1.0
+        m.x_embedder.proj.weight.copy_(w)
+        m.x_embedder.proj.bias.zero_()
+        xin = torch.arange(4 * 32 * 32, dtype=torch.float32).reshape(1, 4, 32, 32)
+        pat = m.x_embedder(xin)[0, :, :16].long()  # [T,16]: flat input index feeding (token, k)
+    tvals = torch.tensor([0.0, 1e-3, 0.04, 0.25, 0.5, 0.731, 0.999, 1.0])
+    sinus = ref_sit.TimestepEmbedder.positional_embedding(tvals, 256)
+    save("static", pos_embed_384=pe384, pos_embed_1152_rows=pe1152[::17], pos_embed_1152_sum=pe1152.astype(np.float64).sum(0),
+         pos_embed_128_g4=pe128_4, unpatchify_idx=un, patchify_idx=pat, sinus_t=tvals, sinus=sinus)
+
+
+def run_fwd_bwd(ref_sit, ref_loss, kw, B, seed, zspec, enc_names, coeffs, autocast=False, path_type="linear",
+                time_schedule="constant", train_mode=True):
+    m = build_ref_model(ref_sit, "custom", seed=seed, **kw)
+    m.train(train_mode)
+    T = (kw["input_size"] // kw["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(B, kw["in_channels"], kw["input_size"], seed, zspec, T, kw["num_classes"])
+    lf = ref_loss.SILoss(path_type=path_type, enc_names=list(enc_names),
+                         loss_weights={n: c for n, c in zip(enc_names, coeffs)}, time_schedule=time_schedule)
+
+    def model(xx, tt, **k):
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                o, z = m(xx, tt, **k)
+            return o.float(), [a.float() for a in z]
+        return m(xx, tt, **k)
+
+    with inject(t=t, noise=noise, drop_u=drop_u):
+        out = lf(model, x, dict(y=y), zs=zs)
+    total = out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+    total.backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    return m, out, total, grads, (x, noise, t, y, drop_u, zs)
+
+
+def g_tiny(ref_sit, ref_loss, ref_samplers):
+    """G-d / G-g: tiny SiT forward + grads in several structural variants (fp32)."""
+    cases = {
+        "hd64": dict(kw=tiny_kwargs(), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+        "hd72": dict(kw=tiny_kwargs(D=144), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+        "unfused": dict(kw=tiny_kwargs(fused_attn=False), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+        "qknorm": dict(kw=tiny_kwargs(qk_norm=True), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+        "two_same": dict(kw=tiny_kwargs(z_dims=[64, 32], z_types=["i", "t"]), zspec=[(64, "i"), (32, "t")],
+                         enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
+        "two_split": dict(kw=tiny_kwargs(z_dims=[64, 32], z_types=["i", "t"], encoder_depth=1, encoder_depth_text=3),
+                          zspec=[(64, "i"), (32, "t")], enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
+        "patch4": dict(kw=tiny_kwargs(input_size=16, patch_size=4), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+    }
+    out = {}
+    for name, c in cases.items():
+        m, o, total, grads, _ = run_fwd_bwd(ref_sit, ref_loss, c["kw"], 4, 11, c["zspec"], c["enc"], c["co"])
+        out[f"{name}.total"] = total
+        out[f"{name}.denoising_loss"] = o["denoising_loss"]
+        out[f"{name}.proj_loss"] = o["proj_loss"]
+        out[f"{name}.img_proj_loss"] = torch.as_tensor(o["img_proj_loss"])
+        out[f"{name}.text_proj_loss"] = torch.as_tensor(o["text_proj_loss"])
+        for k, g in grads.items():
+            out[f"{name}.gnorm.{k}"] = g.double().norm()
+        out[f"{name}.grad.final_layer.linear.weight"] = grads["final_layer.linear.weight"]
+        out[f"{name}.grad.blocks.0.attn.qkv.bias"] = grads["blocks.0.attn.qkv.bias"]
+        out[f"{name}.grad.x_embedder.proj.weight"] = grads["x_embedder.proj.weight"]
+        # eval-mode inference forward
+        m.eval()
+        x, _, t, y, _, _ = inputs(4, 4, c["kw"]["input_size"], 11, [], 0, 10)
+        with torch.no_grad():
+            out[f"{name}.infer"] = m(x, t, y)[0]
+    save("tiny", **out)
+
+
+def g_loss_units(ref_sit, ref_loss, ref_samplers):
+    """G-h: SILoss over time_schedule x path_type x weighting with a fixed stand-in model."""
+    B = 6
+    x, noise, t, y, _, zs = inputs(B, 4, 8, 21, [(32, "i"), (16, "t")], 16, 10)
+    zt = [detfill.normal((B, 16, 32), 901), detfill.normal((B, 16), 902)]
+    vel = detfill.normal((B, 4, 8, 8), 903)
+
+    def model(xx, tt, **k):
+        return vel + 0.1 * xx, zt
+
+    out = {}
+    for sched in ["constant", "linear", "cosine", "sigmoid", "loglinear", "cutoff"]:
+        for path in ["linear", "cosine"]:
+            lf = ref_loss.SILoss(path_type=path, enc_names=["clip", "text_embeds_qwenvl"],
+                                 loss_weights={"clip": 1.0, "text_embeds_qwenvl": 0.5}, time_schedule=sched,
+                                 cutoffs=[0.2, 0.8])
+            with inject(t=t, noise=noise):
+                o = lf(model, x, dict(y=y), zs=zs)
+            for k in ("denoising_loss", "proj_loss", "img_proj_loss", "text_proj_loss"):
+                out[f"{sched}.{path}.{k}"] = torch.as_tensor(o[k])
+    # zero-weight encoder branch + single-encoder keying
+    lf = ref_loss.SILoss(enc_names=["text_embeds_qwenvl"], loss_weights={"text_embeds_qwenvl": 0.0}, time_schedule="linear")
+    with inject(t=t, noise=noise):
+        o = lf(lambda xx, tt, **k: (vel, [zt[0]]), x, dict(y=y), zs=[zs[0]])
+    out["zero_weight.proj_loss"] = o["proj_loss"]
+    out["zero_weight.img_proj_loss"] = torch.as_tensor(o["img_proj_loss"])
+    # lognormal time sampling transform (weighting) with injected normal draws
+    rn = detfill.normal((B, 1, 1, 1), 77)
+    o_randn = torch.randn
+    for path in ["linear", "cosine"]:
+        cap = {}
+        torch.randn = lambda *s, **k: rn.clone()
+        try:
+            lf = ref_loss.SILoss(path_type=path, weighting="lognormal", enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+            with inject(noise=noise):
+                lf(lambda xx, tt, **k: (cap.setdefault("t", tt), (vel, [zt[0]]))[1], x, dict(y=y), zs=[zs[0]])
+        finally:
+            torch.randn = o_randn
+        out[f"lognormal.{path}.t"] = cap["t"]
+    save("loss_units", **out)
+
+
+def g_samplers(ref_sit, ref_loss, ref_samplers):
+    """G-i: Euler / Heun / Euler-Maruyama with and without (interval) CFG on a tiny SiT, fp32 model, fp64 state."""
+    kw = tiny_kwargs(num_classes=1000)
+    m = build_ref_model(ref_sit, "custom", seed=5, **kw).eval()
+    n = 3
+    z = detfill.normal((n, 4, 8, 8), 41)
+    y = torch.tensor([3, 500, 999])
+    out = {}
+    cfgs = {"euler": dict(heun=False, cfg_scale=1.0), "heun": dict(heun=True, cfg_scale=1.0),
+            "euler_cfg": dict(heun=False, cfg_scale=2.5), "heun_cfg": dict(heun=True, cfg_scale=1.5),
+            "heun_cfg_interval": dict(heun=True, cfg_scale=3.0, guidance_low=0.3, guidance_high=0.75)}
+    for name, c in cfgs.items():
+        out[name] = ref_samplers.euler_sampler(m, z, y, num_steps=6, **c)
+    eps = [detfill.normal((n, 4, 8, 8), 600 + i).double() for i in range(8)]
+    for name, c in {"sde": dict(cfg_scale=1.0), "sde_cfg": dict(cfg_scale=2.0, guidance_high=0.9),
+                    "sde_cosine": dict(cfg_scale=1.0, path_type="cosine")}.items():
+        with inject(eps_list=eps):
+            out[name] = ref_samplers.euler_maruyama_sampler(m, z, y, num_steps=6, **c)
+    save("samplers", **out)
+
+
+def ref_train_traj(ref_sit, ref_loss, model_name, kw, B, steps, zspec, enc_names, coeffs, autocast, proj_coeff=0.5,
+                   align=True, seed=0):
+    """Reference-equivalent optimisation steps (train.py:387-412): SILoss -> combine -> backward -> clip -> AdamW -> EMA."""
+    m = build_ref_model(ref_sit, model_name, seed=seed, **kw)
+    m.train()
+    ema = {k: v.detach().clone() for k, v in m.named_parameters()}
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8)
+    lf = ref_loss.SILoss(enc_names=list(enc_names), loss_weights={n: c for n, c in zip(enc_names, coeffs)})
+    T = (kw.get("input_size", 32) // 2) ** 2
+    rec = {k: [] for k in ("loss", "denoising_loss", "proj_loss", "grad_norm")}
+
+    def model(xx, tt, **k):
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                o, z = m(xx, tt, **k)
+            return o.float(), [a.float() for a in z]
+        return m(xx, tt, **k)
+
+    for s in range(steps):
+        t0 = time.time()
+        x, noise, t, y, drop_u, zs = inputs(B, 4, kw.get("input_size", 32), 100 * seed + s, zspec, T, kw.get("num_classes", 1000))
+        with inject(t=t, noise=noise, drop_u=drop_u):
+            o = lf(model, x, dict(y=y), zs=zs)
+        den = o["denoising_loss"].mean()
+        proj = o["proj_loss"].mean()
+        total = den * 1.0 + (proj * proj_coeff * 1.0 if align else 0.0)
+        opt.zero_grad(set_to_none=True)
+        total.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                ema[k].mul_(0.9999).add_(p.data, alpha=1 - 0.9999)
+        rec["loss"].append(float(total)); rec["denoising_loss"].append(float(den))
+        rec["proj_loss"].append(float(proj)); rec["grad_norm"].append(float(gn))
+        print(f"    step {s}: loss {float(total):.6f} den {float(den):.6f} proj {float(proj):.6f} gn {float(gn):.4f} ({time.time() - t0:.1f}s)")
+    sd = m.state_dict()
+    probe = {k: sd[k].flatten()[:64].clone() for k in ("blocks.0.attn.qkv.weight", "final_layer.linear.weight", "t_embedder.mlp.2.bias")}
+    return rec, probe, {k: ema[k].flatten()[:64].clone() for k in probe}
+
+
+def g_s2(ref_sit, ref_loss, ref_samplers):
+    """G-e: C1 — SiT-S/2, B=64, 10 fp32 steps, alignment contribution zeroed (denoising loss only)."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[768], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False)
+    rec, probe, ema = ref_train_traj(ref_sit, ref_loss, "SiT-S/2", kw, 64, 10, [(768, "i")], ["dinov2"], [1.0], False, align=False)
+    save("s2_c1", **{k: np.array(v) for k, v in rec.items()}, **{"w." + k: v for k, v in probe.items()},
+         **{"ema." + k: v for k, v in ema.items()})
+
+
+def g_b2(ref_sit, ref_loss, ref_samplers):
+    """SiT-B/2-shaped mid-size check with alignment on (bf16 autocast and fp32), B=8, 3 steps."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[768], z_types=["i"], encoder_depth=4, fused_attn=True, qk_norm=False)
+    out = {}
+    for tag, ac in (("fp32", False), ("bf16", True)):
+        rec, probe, _ = ref_train_traj(ref_sit, ref_loss, "SiT-B/2", kw, 8, 3, [(768, "i")], ["dinov2"], [1.0], ac)
+        out.update({f"{tag}.{k}": np.array(v) for k, v in rec.items()})
+        out.update({f"{tag}.w.{k}": v for k, v in probe.items()})
+    save("b2_align", **out)
+
+
+def g_xl(ref_sit, ref_loss, ref_samplers):
+    """G-f: C2 — SiT-XL/2 + 1024-d projector (DINOv2-L-shaped targets), B=8, 5 steps, fp32 and bf16-autocast."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[1024], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False)
+    out = {}
+    for tag, ac in (("bf16", True), ("fp32", False)):
+        print(f"  XL/2 {tag}")
+        rec, probe, _ = ref_train_traj(ref_sit, ref_loss, "SiT-XL/2", kw, 8, 5, [(1024, "i")], ["dinov2"], [1.0], ac)
+        out.update({f"{tag}.{k}": np.array(v) for k, v in rec.items()})
+        out.update({f"{tag}.w.{k}": v for k, v in probe.items()})
+    save("xl2_c2", **out)
+
+
+def g_xl_c4(ref_sit, ref_loss, ref_samplers):
+    """C4 — SiT-XL/2, CLIP-L image tokens (1024) at block 8 + pooled text vector (3584) at block 16, bf16, B=4, 2 steps."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[1024, 3584], z_types=["i", "t"], encoder_depth=8,
+              encoder_depth_text=16, fused_attn=True, qk_norm=False)
+    rec, probe, _ = ref_train_traj(ref_sit, ref_loss, "SiT-XL/2", kw, 4, 2, [(1024, "i"), (3584, "t")],
+                                   ["clip", "text_embeds_qwenvl_7b"], [1.0, 0.5], True)
+    save("xl2_c4", **{k: np.array(v) for k, v in rec.items()}, **{"w." + k: v for k, v in probe.items()})
+
+
+def g_sched(ref_sit, ref_loss, ref_samplers):
+    """G-j: optimiser toy (clip + AdamW + EMA on a 3-tensor toy) — schedules are pure python in train.py's main()
+    (not importable: needs diffusers/wandb), so they are pinned by hand-derived values in tests instead."""
+    ps = [torch.nn.Parameter(detfill.normal(s, 70 + i)) for i, s in enumerate([(5, 7), (11,), (3, 4, 2)])]
+    ema = [p.detach().clone() for p in ps]
+    opt = torch.optim.AdamW(ps, lr=1e-2, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+    out = {}
+    for s in range(3):
+        for i, p in enumerate(ps):
+            p.grad = detfill.normal(tuple(p.shape), 80 + 10 * s + i) * (3.0 if s == 0 else 0.1)
+        gn = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+        opt.step()
+        with torch.no_grad():
+            for e, p in zip(ema, ps):
+                e.mul_(0.99).add_(p.data, alpha=0.01)
+        out[f"gn{s}"] = gn
+        for i, p in enumerate(ps):
+            out[f"p{s}_{i}"] = p.detach().clone()
+            out[f"e{s}_{i}"] = ema[i].clone()
+    save("optim_toy", **out)
+
+
+ALL = {"static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--skip-xl", action="store_true")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    mods = import_reference()
+    for name, fn in ALL.items():
+        if a.only and name not in a.only:
+            continue
+        if a.skip_xl and name.startswith("xl2"):
+            continue
+        print(f"[gen_golden] {name}")
+        t0 = time.time()
+        fn(*mods)
+        print(f"  done in {time.time() - t0:.1f}s")
