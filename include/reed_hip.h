@@ -34,7 +34,8 @@ int reed_version(void);
  *   layout 2 TN: C[M,N] = P[K,M]^T Q[K,N]     (wgrad    dW = dy^T x), optional dbias[M] = colsum(P)
  * epilogue codes: see reed_amd/csrc/gemm.h (0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
  *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic).  N%128==0; K%64==0 (NT/NN);
- *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0.
+ *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
+ *   dbias likewise holds split_k slabs of M floats; reduce both with reed_reduce_slabs: deterministic).
  * ------------------------------------------------------------------------------------------- */
 int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* Q, int64_t ldq,
               int M, int N, int K, void* C, int64_t ldc, void* C2, int64_t ldc2, const void* R,

@@ -1,0 +1,118 @@
+"""Flat parameter arena for the SiT model.
+
+MI355X-first memory layout: every parameter lives in ONE contiguous fp32 master buffer; gradients, both Adam
+moments, the EMA copy and the bf16 compute shadow are separate arenas with the SAME offsets. Consequences:
+  * the optimiser side of the step (grad-norm, clip, AdamW, EMA, bf16 re-cast) is one pass over flat memory
+    instead of the reference's 298-tensor foreach loops (image/train.py:94-105,402-412);
+  * gradient all-reduce buckets are plain [begin, end) ranges, in backward completion order;
+  * all 28 blocks' adaLN linears + the final layer's are adjacent rows of one [N_all, D] matrix, so the whole
+    model's modulation is ONE GEMM on silu(c) (the reference runs 29 skinny GEMMs, sit.py:126-129,146-150).
+nn.Parameters of reed_amd.models.sit.SiT are views into the master arena, so state_dict()/load_state_dict()
+keep the reference's key names and shapes.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ALIGN = 8  # elements; keeps every segment 16-byte aligned in the bf16 shadow and 32-byte in fp32
+
+
+def _align(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+class ArenaLayout:
+    """Segment table: name -> (offset, shape). Order = storage order (see module docstring)."""
+
+    def __init__(self, shapes, depth, n_proj):
+        """shapes: OrderedDict name->shape in state_dict order."""
+        order = []
+        ada_w = [f"blocks.{i}.adaLN_modulation.1.weight" for i in range(depth)] + ["final_layer.adaLN_modulation.1.weight"]
+        ada_b = [n.replace("weight", "bias") for n in ada_w]
+        order += ada_w + ada_b
+        rest = [n for n in shapes if n not in set(order) and n != "pos_embed"]
+        emb = [n for n in rest if n.split(".")[0] in ("x_embedder", "t_embedder", "y_embedder")]
+        blocks = [n for n in rest if n.startswith("blocks.")]
+        proj = [n for n in rest if n.startswith("projectors.")]
+        fin = [n for n in rest if n.startswith("final_layer.")]
+        order += emb + blocks + proj + fin
+        assert len(order) == len(shapes) - 1, "unclassified parameter"
+        self.seg = OrderedDict()
+        off = 0
+        for n in order:
+            shp = tuple(shapes[n])
+            numel = int(np.prod(shp))
+            if n in ada_w or n in ada_b:
+                assert numel % ALIGN == 0, "hidden size must be a multiple of 8"
+            self.seg[n] = (off, shp)
+            off += _align(numel)
+        self.n_train = _align(off, 64)
+        self.seg["pos_embed"] = (self.n_train, tuple(shapes["pos_embed"]))
+        self.n_total = _align(self.n_train + int(np.prod(shapes["pos_embed"])), 64)
+        self.ada_w_off = self.seg[ada_w[0]][0]
+        self.ada_b_off = self.seg[ada_b[0]][0]
+        self.ada_rows = sum(shapes[n][0] for n in ada_w)
+        self.depth = depth
+
+    def off(self, name):
+        return self.seg[name][0]
+
+    def numel(self, name):
+        return int(np.prod(self.seg[name][1]))
+
+    def range_of(self, prefix):
+        """[begin, end) element range covering every segment whose name starts with prefix (must be adjacent)."""
+        names = [n for n in self.seg if n.startswith(prefix)]
+        b = min(self.seg[n][0] for n in names)
+        e = max(self.seg[n][0] + _align(self.numel(n)) for n in names)
+        return b, e
+
+    def buckets(self):
+        """Gradient all-reduce buckets in the order backward finishes them:
+        final layer, blocks L-1..0 (projectors fire when their tap block is reached; reported separately),
+        then embedders + the adaLN group."""
+        out = [("final", self.range_of("final_layer.linear"))]
+        for i in reversed(range(self.depth)):
+            out.append((f"block{i}", self.range_of(f"blocks.{i}.attn.qkv")[0:1] + (self.range_of(f"blocks.{i}.mlp.fc2")[1],)))
+        names = [n for n in self.seg if n.startswith("projectors.")]
+        if names:
+            out.append(("projectors", self.range_of("projectors.")))
+        b, _ = self.range_of("blocks.0.adaLN")  # adaLN group is first in the arena
+        e = self.range_of("y_embedder")[1]
+        out.append(("embed_adaln", (0, e)))
+        return out
+
+
+class ParamArena:
+    def __init__(self, layout, device, dtype=torch.float32):
+        self.layout = layout
+        self.device = torch.device(device)
+        self.master = torch.zeros(layout.n_total, dtype=dtype, device=device)
+        self.grad = None
+        self.shadow = None
+        self.shadow_version = -1
+
+    def view(self, buf, name):
+        off, shp = self.layout.seg[name]
+        return buf[off:off + int(np.prod(shp))].view(shp)
+
+    def ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros(self.layout.n_train, dtype=torch.float32, device=self.device)
+        return self.grad
+
+    def ensure_shadow(self):
+        """bf16 copy of the master weights (GEMM operands). Refreshed when the master changed through torch
+        (version counter) — the fused optimiser rewrites it itself and calls mark_shadow_fresh()."""
+        from . import ops
+        if self.shadow is None:
+            self.shadow = torch.empty(self.layout.n_total, dtype=torch.bfloat16, device=self.device)
+            self.shadow_version = -1
+        if self.shadow_version != self.master._version:
+            ops.cast_bf16(self.master, self.shadow, self.layout.n_total)
+            self.shadow_version = self.master._version
+        return self.shadow
+
+    def mark_shadow_fresh(self):
+        self.shadow_version = self.master._version

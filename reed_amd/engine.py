@@ -1,0 +1,428 @@
+"""Forward / backward of the SiT model as a sequence of HIP kernel launches (reference: image/models/sit.py:271-311
+and its autograd). Python here is orchestration only: shapes, pointers into the arenas, launch order, the
+activation tape. Numerics follow the reference under accelerate bf16 mixed precision (SURVEY.md §3.2 dtype map):
+fp32 residual stream / LayerNorm / loss, bf16 GEMM operands with fp32 MFMA accumulation, bf16 linear outputs.
+
+Per block the launch sequence is
+  fwd : LN+modulate -> qkv GEMM(+bias) -> attention -> proj GEMM(+bias, gate, residual) -> LN+modulate
+        -> fc1 GEMM(+bias, GELU) -> fc2 GEMM(+bias, gate, residual)                       (7 launches)
+  bwd : gate-bwd, 2x{wgrad, dgrad} for the MLP, LN-bwd, gate-bwd, proj {wgrad, dgrad}, attention-bwd,
+        qkv {wgrad, dgrad}, LN-bwd, modulation-grad reduce                                (14 launches)
+and the modulation of ALL blocks is one GEMM forward (silu(c) @ W_ada_all^T) and two backward.
+"""
+import types
+
+import torch
+
+from . import ops
+from .ops import NT, NN, TN, EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB
+
+
+class Engine:
+    def __init__(self, model):
+        self.m = model
+        self.L = model._layout
+        self.A = model._arena
+        if self.A.master.device.type != "cuda":
+            raise RuntimeError("reed_amd.SiT: parameters are on %s; move the model to an AMD GPU (model.cuda()). "
+                               "The hot path has no CPU fallback." % self.A.master.device)
+        self.D = model.hidden_size
+        self.H = model.num_heads
+        self.hd = self.D // self.H
+        self.Hm = int(self.D * model.mlp_ratio)
+        self.T = model.num_patches
+        self.P = model.patch_size
+        self.C = model.in_channels
+        self.depth = model.depth
+        self.NO = self.P * self.P * self.C
+        for n, v in (("hidden_size", self.D), ("mlp hidden", self.Hm), ("projector_dim", model.projector_dim)):
+            if v % 128:
+                raise ValueError(f"{n}={v} must be a multiple of 128 for the MFMA GEMM tiles")
+        for z in model.z_dims:
+            if z % 128:
+                raise ValueError(f"z_dim={z} must be a multiple of 128 for the MFMA GEMM tiles")
+        split = model.encoder_depth_text is not None and model.encoder_depth_text != model.encoder_depth
+        self.split = split
+        self.tap_depth = [model.encoder_depth if (zt == "i" or not split) else model.encoder_depth_text
+                          for zt in model.z_types]
+        self.reducer = None      # set by reed_amd.parallel.GradReducer
+        self._ws = None
+        self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
+
+    # ---- pointers into the arenas -------------------------------------------------
+    def W(self, name):
+        return self._shadow.data_ptr() + 2 * self.L.off(name)
+
+    def Wf(self, name):
+        return self.A.master.data_ptr() + 4 * self.L.off(name)
+
+    def G(self, name):
+        return self.A.grad.data_ptr() + 4 * self.L.off(name)
+
+    def ws(self, nfloats, dev):
+        if self._ws is None or self._ws.numel() < nfloats:
+            self._ws = torch.empty(int(nfloats), dtype=torch.float32, device=dev)
+        return self._ws
+
+    # ---- forward -------------------------------------------------------------------
+    def forward(self, x, t, y, inference, need_grad, drop):
+        m, L = self.m, self.L
+        ops.require_cuda(x, "x")
+        dev = x.device
+        B, C, HW = x.shape[0], x.shape[1], x.shape[-1]
+        D, H, hd, Hm, T, P = self.D, self.H, self.hd, self.Hm, self.T, self.P
+        if C != self.C or HW != m.input_size or x.shape[-2] != HW:
+            raise ValueError(f"input {tuple(x.shape)} does not match (N,{self.C},{m.input_size},{m.input_size})")
+        M = B * T
+        self._shadow = self.A.ensure_shadow()
+        x = x.contiguous().float()
+        t = t.contiguous().float()
+        y = y.contiguous().long()
+
+        def bf(*s):
+            return torch.empty(s, dtype=torch.bfloat16, device=dev)
+
+        def f32(*s):
+            return torch.empty(s, dtype=torch.float32, device=dev)
+
+        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x) if need_grad else None
+        # -- embedders
+        tok = f32(M, D)
+        ops.patch_embed_fwd(x, self.W("x_embedder.proj.weight"), self.W("x_embedder.proj.bias"), self.Wf("pos_embed"),
+                            tok, B, C, HW, P, D)
+        sin = bf(B, 256)
+        ops.timestep_sinusoid(t, sin, B)
+        t1p = bf(B, D) if need_grad else None
+        t1 = bf(B, D)
+        ops.gemm(NT, EPI_SILU, sin, self.W("t_embedder.mlp.0.weight"), B, D, 256, t1p, 256, 256, D, C2=t1, ldc2=D,
+                 bias=self.W("t_embedder.mlp.0.bias"))
+        temb = bf(B, D)
+        ops.gemm(NT, EPI_BF16, t1, self.W("t_embedder.mlp.2.weight"), B, D, D, temb, D, D, D,
+                 bias=self.W("t_embedder.mlp.2.bias"))
+        drop_u8 = None
+        if drop is not None:
+            drop_u8 = drop.to(device=dev, dtype=torch.uint8).contiguous()
+        labels_eff = torch.empty(B, dtype=torch.int64, device=dev)
+        c = f32(B, D)
+        silu_c = bf(B, D)
+        ops.label_cond(y, drop_u8, m.num_classes, self.Wf("y_embedder.embedding_table.weight"), temb, labels_eff, c,
+                       silu_c, B, D)
+        Nall = L.ada_rows
+        mod = bf(B, Nall)
+        sp = self._shadow.data_ptr()
+        ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * L.ada_w_off, B, Nall, D, mod, D, D, Nall, bias=sp + 2 * L.ada_b_off)
+        mp = mod.data_ptr()
+        if need_grad:
+            tp.sin, tp.t1p, tp.t1, tp.labels_eff, tp.c, tp.silu_c, tp.mod = sin, t1p, t1, labels_eff, c, silu_c, mod
+
+        # -- blocks
+        if not need_grad:  # inference: ping-pong buffers, nothing saved
+            xa, xb = tok, f32(M, D)
+            h, qkv, o, u = bf(M, D), bf(M, 3 * D), bf(M, D), bf(M, Hm)
+        xcur = tok
+        zs_by_proj = {}
+        for i in range(self.depth):
+            b = f"blocks.{i}."
+            mb = mp + 2 * (i * 6 * D)
+            if need_grad:
+                h, qkv, o, u = bf(M, D), bf(M, 3 * D), bf(M, D), bf(M, Hm)
+                h2, a1, y1, y2 = bf(M, D), bf(M, Hm), bf(M, D), bf(M, D)
+                mean1, rstd1, mean2, rstd2 = f32(M), f32(M), f32(M), f32(M)
+                lse = f32(B, H, T)
+                xmid, xout = f32(M, D), f32(M, D)
+            else:
+                h2, a1, y1, y2 = h, None, None, None
+                mean1 = rstd1 = mean2 = rstd2 = lse = None
+                xmid = xb if xcur is xa else xa
+                xout = xcur  # safe: fc2's epilogue reads R=xmid, writes xout; xcur is dead after proj
+            ops.ln_modulate_fwd(xcur, mb, mb + 2 * D, Nall, h, mean1, rstd1, M, D, T)
+            ops.gemm(NT, EPI_BF16, h, self.W(b + "attn.qkv.weight"), M, 3 * D, D, qkv, D, D, 3 * D,
+                     bias=self.W(b + "attn.qkv.bias"))
+            ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+            ops.gemm(NT, EPI_GATE_RES, o, self.W(b + "attn.proj.weight"), M, D, D, xmid, D, D, D, C2=y1, ldc2=D,
+                     R=xcur, ldr=D, bias=self.W(b + "attn.proj.bias"), gate=mb + 4 * D, ldgate=Nall, rows_per_gate=T)
+            ops.ln_modulate_fwd(xmid, mb + 6 * D, mb + 8 * D, Nall, h2, mean2, rstd2, M, D, T)
+            ops.gemm(NT, EPI_GELU, h2, self.W(b + "mlp.fc1.weight"), M, Hm, D, a1, D, D, Hm, C2=u, ldc2=Hm,
+                     bias=self.W(b + "mlp.fc1.bias"))
+            ops.gemm(NT, EPI_GATE_RES, u, self.W(b + "mlp.fc2.weight"), M, D, Hm, xout, Hm, Hm, D, C2=y2, ldc2=D,
+                     R=xmid, ldr=D, bias=self.W(b + "mlp.fc2.bias"), gate=mb + 10 * D, ldgate=Nall, rows_per_gate=T)
+            if need_grad:
+                tp.blocks.append(types.SimpleNamespace(x=xcur, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse,
+                                                       y1=y1, xmid=xmid, mean2=mean2, rstd2=rstd2, h2=h2, a1=a1, u=u,
+                                                       y2=y2))
+            xcur = xout
+            if not inference:
+                for j, dj in enumerate(self.tap_depth):
+                    if dj == i + 1:
+                        zs_by_proj[j] = self._projector_fwd(j, xcur, B, need_grad, tp)
+        # -- final layer
+        out = f32(B, C, HW, HW)
+        meanF = f32(M) if need_grad else None
+        rstdF = f32(M) if need_grad else None
+        mf = mp + 2 * (self.depth * 6 * D)
+        ops.final_layer_fwd(xcur, mf, mf + 2 * D, Nall, self.W("final_layer.linear.weight"),
+                            self.W("final_layer.linear.bias"), out, meanF, rstdF, B, T, D, C, P)
+        if need_grad:
+            tp.x_last, tp.meanF, tp.rstdF = xcur, meanF, rstdF
+        zs = None
+        if not inference:
+            if self.split:
+                ji, jt = m.z_types.index("i"), m.z_types.index("t")
+                zs = [zs_by_proj[ji], zs_by_proj[jt]]
+                if need_grad:
+                    tp.zs_order = [ji, jt]
+            else:
+                zs = [zs_by_proj[j] for j in range(len(m.z_dims))]
+                if need_grad:
+                    tp.zs_order = list(range(len(m.z_dims)))
+        return out, zs, tp
+
+    def _projector_fwd(self, j, x, B, need_grad, tp):
+        m, D, T = self.m, self.D, self.T
+        Pd, Z = m.projector_dim, m.z_dims[j]
+        dev = x.device
+        img = m.z_types[j] == "i"
+        R = B * T if img else B
+        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)  # noqa: E731
+        xin = bf(R, D)
+        if img:
+            ops.ln_modulate_fwd(x, None, None, 0, xin, None, None, R, D, T)  # f32 -> bf16 cast (autocast input cast)
+        else:
+            ops.token_mean_fwd(x, xin, B, T, D)
+        pre = f"projectors.{j}."
+        p1p, p1 = (bf(R, Pd) if need_grad else None), bf(R, Pd)
+        ops.gemm(NT, EPI_SILU, xin, self.W(pre + "0.weight"), R, Pd, D, p1p, D, D, Pd, C2=p1, ldc2=Pd,
+                 bias=self.W(pre + "0.bias"))
+        p2p, p2 = (bf(R, Pd) if need_grad else None), bf(R, Pd)
+        ops.gemm(NT, EPI_SILU, p1, self.W(pre + "2.weight"), R, Pd, Pd, p2p, Pd, Pd, Pd, C2=p2, ldc2=Pd,
+                 bias=self.W(pre + "2.bias"))
+        zt = bf(R, Z)
+        ops.gemm(NT, EPI_BF16, p2, self.W(pre + "4.weight"), R, Z, Pd, zt, Pd, Pd, Z, bias=self.W(pre + "4.bias"))
+        if need_grad:
+            tp.proj[j] = types.SimpleNamespace(xin=xin, p1p=p1p, p1=p1, p2p=p2p, p2=p2, R=R)
+        return zt.view(B, T, Z) if img else zt
+
+    # ---- backward ------------------------------------------------------------------
+    def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev):
+        tiles = (N // 128) * (K // 128)
+        split = 1
+        if tiles < 160 and Mtok >= 2048:
+            split = max(1, min(8, 256 // tiles, Mtok // 512))
+        ws = self.ws(split * (N * K + N), dev) if split > 1 else None
+        bname = wname.replace("weight", "bias")
+        ops.linear_wgrad(dy, x, self.G(wname), dbias=self.G(bname), accumulate=acc, split_k=split, Mtok=Mtok, N=N, K=K,
+                         ws=ws)
+
+    def backward(self, tp, dout, dzs):
+        m, L = self.m, self.L
+        D, H, hd, Hm, T, P, C = self.D, self.H, self.hd, self.Hm, self.T, self.P, self.C
+        B = tp.B
+        M = B * T
+        dev = dout.device
+        Nall = L.ada_rows
+        self.A.ensure_grad()
+        acc = self.grad_live
+        mp = tp.mod.data_ptr()
+        ch = T // 16  # 16-row chunks per sample
+
+        def bf(*s):
+            return torch.empty(s, dtype=torch.bfloat16, device=dev)
+
+        def f32(*s):
+            return torch.empty(s, dtype=torch.float32, device=dev)
+
+        dout = dout.contiguous().float()
+        # -- final layer
+        mf = mp + 2 * (self.depth * 6 * D)
+        hbuf, dlin, dh = bf(M, D), bf(M, self.NO), bf(M, D)
+        ops.final_layer_bwd_rows(dout, tp.x_last, tp.meanF, tp.rstdF, mf, mf + 2 * D, Nall,
+                                 self.W("final_layer.linear.weight"), hbuf, dlin, dh, B, T, D, C, P)
+        dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        partF = f32(M // 16, 2, D)
+        ops.ln_modulate_bwd(dh, tp.x_last, tp.meanF, tp.rstdF, mf + 2 * D, Nall, dx, partF, M, D, T)
+        wsf = self.ws(ops.smallk_ws_floats(D, max(self.NO, C * P * P)), dev)
+        ops.smallk_wgrad(hbuf, False, dlin, wsf, self.G("final_layer.linear.weight"), None,
+                         self.G("final_layer.linear.bias"), M, D, self.NO, 1, acc)
+        dmod = bf(B, Nall)
+        offF = self.depth * 6 * D
+        ops.reduce_mod_parts([(partF.data_ptr(), 2 * D, offF), (partF.data_ptr() + 4 * D, 2 * D, offF + D)], dmod, Nall,
+                             B, D, ch)
+        del hbuf, dlin, dh
+        if self.reducer is not None:
+            self.reducer.ready("final")
+        # which projectors fire after block i's output?
+        pending = {j: d for j, d in enumerate(self.tap_depth)}
+        dz_by_proj = {}
+        if dzs is not None:
+            for k, j in enumerate(tp.zs_order):
+                dz_by_proj[j] = dzs[k]
+        for i in reversed(range(self.depth)):
+            for j, dj in pending.items():
+                if dj == i + 1 and j in tp.proj:
+                    self._projector_bwd(j, tp, dz_by_proj.get(j), dx, B, acc, dev)
+            bk = tp.blocks[i]
+            b = f"blocks.{i}."
+            mb = mp + 2 * (i * 6 * D)
+            # MLP branch
+            pg2, dy2 = f32(M // 16, D), bf(M, D)
+            ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T)
+            self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev)
+            da1 = bf(M, Hm)
+            ops.gemm(NN, EPI_DGELU, dy2, self.W(b + "mlp.fc2.weight"), M, Hm, D, da1, D, Hm, Hm, R=bk.a1, ldr=Hm)
+            self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev)
+            dh2 = dy2  # reuse
+            ops.gemm(NN, EPI_BF16, da1, self.W(b + "mlp.fc1.weight"), M, D, Hm, dh2, Hm, D, D)
+            pl2 = f32(M // 16, 2, D)
+            ops.ln_modulate_bwd(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, M, D, T)
+            # attention branch
+            pg1, dy1 = f32(M // 16, D), bf(M, D)
+            ops.gate_bwd(dx, bk.y1, mb + 4 * D, Nall, dy1, pg1, M, D, T)
+            self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev)
+            do = bf(M, D)
+            ops.gemm(NN, EPI_BF16, dy1, self.W(b + "attn.proj.weight"), M, D, D, do, D, D, D)
+            dqkv = bf(M, 3 * D)
+            ops.attention_bwd(bk.qkv, bk.o, do, bk.lse, dqkv, B, T, H, hd)
+            self._wgrad(dqkv, bk.h, b + "attn.qkv.weight", M, 3 * D, D, acc, dev)
+            dh1 = do  # reuse
+            ops.gemm(NN, EPI_BF16, dqkv, self.W(b + "attn.qkv.weight"), M, D, 3 * D, dh1, 3 * D, D, D)
+            pl1 = f32(M // 16, 2, D)
+            ops.ln_modulate_bwd(dh1, bk.x, bk.mean1, bk.rstd1, mb + 2 * D, Nall, dx, pl1, M, D, T)
+            o6 = i * 6 * D
+            p1, p2 = pl1.data_ptr(), pl2.data_ptr()
+            ops.reduce_mod_parts([(p1, 2 * D, o6), (p1 + 4 * D, 2 * D, o6 + D), (pg1.data_ptr(), D, o6 + 2 * D),
+                                  (p2, 2 * D, o6 + 3 * D), (p2 + 4 * D, 2 * D, o6 + 4 * D),
+                                  (pg2.data_ptr(), D, o6 + 5 * D)], dmod, Nall, B, D, ch)
+            tp.blocks[i] = None  # free this block's activations
+            if self.reducer is not None:
+                self.reducer.ready(f"block{i}")
+        if m.z_dims and self.reducer is not None:
+            self.reducer.ready("projectors")
+        # -- adaLN (all blocks + final): dW = dmod^T silu(c); d silu(c) = dmod @ W   (one GEMM each)
+        sp = self._shadow.data_ptr()
+        gp = self.A.grad.data_ptr()
+        ops.gemm(TN, EPI_F32, dmod, tp.silu_c, Nall, D, B, gp + 4 * L.ada_w_off, Nall, D, D,
+                 dbias=gp + 4 * L.ada_b_off, accumulate=acc)
+        ksteps = Nall // 64
+        split = min(64, max(1, ksteps // 8))
+        slab = B * D
+        wsd = self.ws(split * slab, dev)
+        ops.gemm(NN, EPI_F32, dmod, sp + 2 * L.ada_w_off, B, D, Nall, wsd, Nall, D, D, split_k=split, slab_stride=slab)
+        per = (ksteps + split - 1) // split
+        eff = (ksteps + per - 1) // per
+        dsilu = f32(B, D)
+        ops.reduce_slabs(wsd, slab, eff, dsilu, slab, False)
+        # -- conditioning: label table + timestep MLP
+        dtemb = bf(B, D)
+        gt = self.A.view(self.A.grad, "y_embedder.embedding_table.weight")
+        if not acc:
+            gt.zero_()
+        ops.label_cond_bwd(dsilu, tp.c, tp.labels_eff, dtemb, gt, B, D)
+        ops.linear_wgrad(dtemb, tp.t1, self.G("t_embedder.mlp.2.weight"), dbias=self.G("t_embedder.mlp.2.bias"),
+                         accumulate=acc, Mtok=B, N=D, K=D)
+        dt1 = bf(B, D)
+        ops.gemm(NN, EPI_DSILU, dtemb, self.W("t_embedder.mlp.2.weight"), B, D, D, dt1, D, D, D, R=tp.t1p, ldr=D)
+        ops.linear_wgrad(dt1, tp.sin, self.G("t_embedder.mlp.0.weight"), dbias=self.G("t_embedder.mlp.0.bias"),
+                         accumulate=acc, Mtok=B, N=D, K=256)
+        # -- patch embed: dW[d,k] = sum_tokens bf16(dx)[token,d] * patch[token,k]
+        K = C * P * P
+        xb = bf(M, K)
+        ops.patchify_bf16(tp.x, xb, B, C, tp.x.shape[-1], P, 0)
+        wsf = self.ws(ops.smallk_ws_floats(D, max(self.NO, K)), dev)
+        ops.smallk_wgrad(dx, True, xb, wsf, self.G("x_embedder.proj.weight"), self.G("x_embedder.proj.bias"), None, M, D,
+                         K, 0, acc)
+        if self.reducer is not None:
+            self.reducer.ready("embed_adaln")
+        self.grad_live = True
+        self._attach_grads()
+
+    def _projector_bwd(self, j, tp, dz, dx, B, acc, dev):
+        m, D, T = self.m, self.D, self.T
+        Pd, Z = m.projector_dim, m.z_dims[j]
+        pj = tp.proj[j]
+        R = pj.R
+        pre = f"projectors.{j}."
+        if dz is None:  # projector output unused by the loss: zero grads (torch would leave them None)
+            if not acc:
+                b, e = self.L.range_of(pre)
+                self.A.grad[b:e].zero_()
+            return
+        dz = dz.reshape(R, Z)
+        if dz.dtype != torch.bfloat16:
+            dz = dz.to(torch.bfloat16)
+        dz = dz.contiguous()
+        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)  # noqa: E731
+        self._wgrad(dz, pj.p2, pre + "4.weight", R, Z, Pd, acc, dev)
+        d2 = bf(R, Pd)
+        ops.gemm(NN, EPI_DSILU, dz, self.W(pre + "4.weight"), R, Pd, Z, d2, Z, Pd, Pd, R=pj.p2p, ldr=Pd)
+        self._wgrad(d2, pj.p1, pre + "2.weight", R, Pd, Pd, acc, dev)
+        d1 = bf(R, Pd)
+        ops.gemm(NN, EPI_DSILU, d2, self.W(pre + "2.weight"), R, Pd, Pd, d1, Pd, Pd, Pd, R=pj.p1p, ldr=Pd)
+        self._wgrad(d1, pj.xin, pre + "0.weight", R, Pd, D, acc, dev)
+        if m.z_types[j] == "i":
+            ops.gemm(NN, EPI_ADDF32_RB, d1, self.W(pre + "0.weight"), R, D, Pd, dx, Pd, D, D)
+        else:
+            dmean = bf(R, D)
+            ops.gemm(NN, EPI_BF16, d1, self.W(pre + "0.weight"), R, D, Pd, dmean, Pd, D, D)
+            ops.token_mean_bwd(dmean, dx, B, T, D)
+        tp.proj[j] = None
+
+    def _attach_grads(self):
+        """Expose the grad arena through param.grad (views), for torch.optim / clip_grad_norm_ compatibility."""
+        g = self.A.grad
+        for name, p in self.m.named_parameters():
+            if p.requires_grad and p.grad is None:
+                p.grad = self.A.view(g, name)
+
+    def zero_grad(self):
+        """Equivalent of optimizer.zero_grad(set_to_none=True): the next backward overwrites."""
+        self.grad_live = False
+
+
+class _SiTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, x, t, y, inference, drop):
+        eng = model.engine()
+        out, zs, tape = eng.forward(x, t, y, inference, True, drop)
+        ctx.eng, ctx.tape = eng, tape
+        ctx.nz = 0 if zs is None else len(zs)
+        ctx.set_materialize_grads(False)
+        return (out,) + (tuple(zs) if zs else ())
+
+    @staticmethod
+    def backward(ctx, dout, *dzs):
+        if ctx.tape is None:
+            raise RuntimeError("reed_amd.SiT: backward called twice on the same forward")
+        eng, tape = ctx.eng, ctx.tape
+        ctx.tape = None
+        if dout is None:
+            dout = torch.zeros_like(tape.x)
+        # the user may have dropped p.grad (zero_grad(set_to_none=True)) -> overwrite semantics
+        sentinel = next(p for p in eng.m.parameters() if p.requires_grad)
+        if sentinel.grad is None:
+            eng.grad_live = False
+        eng.backward(tape, dout, list(dzs) if ctx.nz else None)
+        return (None,) * 7
+
+
+def sit_apply(model, x, t, y, inference=True):
+    ops.require_cuda(x, "x")
+    eng = model.engine()
+    drop = None
+    if model.class_dropout_prob > 0:
+        if model.force_drop_mask is not None:
+            drop = model.force_drop_mask
+        elif model.training:  # LabelEmbedder.token_drop (sit.py:84-93): device RNG draw
+            drop = torch.rand(y.shape[0], device=y.device) < model.class_dropout_prob
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in (model.x_embedder.proj.weight,))
+    if not need_grad:
+        out, zs, _ = eng.forward(x, t, y, inference, False, drop)
+        return out, zs
+    if not hasattr(model, "_anchor") or model._anchor.device != x.device:
+        model._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+    res = _SiTFunction.apply(model._anchor, model, x, t, y, inference, drop)
+    out, zs = res[0], (list(res[1:]) if len(res) > 1 else None)
+    if inference:
+        zs = None
+    elif zs is None:
+        zs = []
+    return out, zs

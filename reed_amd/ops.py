@@ -2,6 +2,7 @@
 
 PyTorch is used for device memory and streams only; every function here launches hand-written
 HIP kernels on torch's current stream and raises if the library is unavailable.
+Pointer arguments may be torch tensors or raw integer device addresses (for sub-views of arenas).
 """
 import ctypes
 
@@ -16,6 +17,8 @@ EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_A
 def _p(t):
     if t is None:
         return None
+    if isinstance(t, int):
+        return t
     return t.data_ptr()
 
 
@@ -23,58 +26,205 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _req(t, dtype, name):
+def _call(name, *args):
+    L = _lib.load()
+    _lib.check(getattr(L, name)(*args), name)
+
+
+def require_cuda(t, name="tensor"):
     if not t.is_cuda:
-        raise RuntimeError(f"reed_amd: {name} must be a CUDA(HIP) tensor; the hot path has no CPU fallback")
-    if t.dtype != dtype:
-        raise TypeError(f"reed_amd: {name} must be {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
-        raise ValueError(f"reed_amd: {name} must be contiguous")
+        raise RuntimeError(f"reed_amd: {name} is on {t.device}; the SiT hot path runs only on an AMD GPU through "
+                           "libreed_hip.so (no CPU / PyTorch fallback)")
 
 
+# ---------------- GEMM ----------------
 def gemm(layout, epi, P, Q, M, N, K, C, ldp, ldq, ldc, C2=None, ldc2=0, R=None, ldr=0, bias=None,
          gate=None, ldgate=0, rows_per_gate=1, dbias=None, accumulate=False, split_k=1,
          slab_stride=0):
-    L = _lib.load()
-    _lib.check(L.reed_gemm(layout, epi, _p(P), ldp, _p(Q), ldq, M, N, K, _p(C), ldc, _p(C2), ldc2,
-                           _p(R), ldr, _p(bias), _p(gate), ldgate, rows_per_gate, _p(dbias),
-                           int(accumulate), split_k, slab_stride, _stream()), "gemm")
+    _call("reed_gemm", layout, epi, _p(P), ldp, _p(Q), ldq, M, N, K, _p(C), ldc, _p(C2), ldc2,
+          _p(R), ldr, _p(bias), _p(gate), ldgate, rows_per_gate, _p(dbias), int(accumulate), split_k,
+          slab_stride, _stream())
 
 
 def linear_fwd(x, w, bias, out, epi=EPI_BF16, act_out=None, R=None, gate=None, ldgate=0,
-               rows_per_gate=1, y_out=None):
+               rows_per_gate=1, y_out=None, M=None, N=None, K=None, ldx=None, ldw=None, ldo=None):
     """out = epilogue(x @ w^T + bias). x bf16 [M,K], w bf16 [N,K]."""
-    M, K = x.shape
-    N = w.shape[0]
+    if M is None:
+        M, K = x.shape
+        N = w.shape[0]
+        ldx, ldw = x.stride(0), w.stride(0)
+        ldo = out.stride(0) if out is not None else 0
     C2 = act_out if act_out is not None else y_out
-    gemm(NT, epi, x, w, M, N, K, out, x.stride(0), w.stride(0), out.stride(0) if out is not None else 0,
-         C2=C2, ldc2=C2.stride(0) if C2 is not None else 0, R=R, ldr=R.stride(0) if R is not None else 0,
+    gemm(NT, epi, x, w, M, N, K, out, ldx, ldw, ldo,
+         C2=C2, ldc2=(N if isinstance(C2, int) else C2.stride(0)) if C2 is not None else 0,
+         R=R, ldr=(N if isinstance(R, int) else R.stride(0)) if R is not None else 0,
          bias=bias, gate=gate, ldgate=ldgate, rows_per_gate=rows_per_gate)
 
 
-def linear_dgrad(dy, w, dx, epi=EPI_BF16, R=None):
+def linear_dgrad(dy, w, dx, epi=EPI_BF16, R=None, M=None, N=None, K=None, ldw=None):
     """dx = epilogue(dy @ w). dy bf16 [M,N], w bf16 [N,K] -> dx [M,K]."""
-    M, N = dy.shape
-    K = w.shape[1]
-    gemm(NN, epi, dy, w, M, K, N, dx, dy.stride(0), w.stride(0), dx.stride(0), R=R,
-         ldr=R.stride(0) if R is not None else 0)
+    if M is None:
+        M, N = dy.shape
+        K = w.shape[1]
+        ldw = w.stride(0)
+    gemm(NN, epi, dy, w, M, K, N, dx, N, ldw, K, R=R, ldr=K if R is not None else 0)
 
 
-def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1):
-    """dw f32 [N,K] (+)= dy^T x ; dbias f32 [N] (+)= colsum(dy). dy bf16 [M,N], x bf16 [M,K]."""
-    Mtok, N = dy.shape
-    K = x.shape[1]
-    epi = EPI_ATOMIC_F32 if split_k > 1 else EPI_F32
-    gemm(TN, epi, dy, x, N, K, Mtok, dw, dy.stride(0), x.stride(0), dw.stride(0), dbias=dbias,
-         accumulate=accumulate, split_k=split_k)
+def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, N=None, K=None, ws=None):
+    """dw f32 [N,K] (+)= dy^T x ; dbias f32 [N] (+)= colsum(dy). dy bf16 [Mtok,N], x bf16 [Mtok,K].
+    split_k>1 goes through slabs in `ws` (f32, >= split_k*(N*K+N) floats) and a deterministic reduce."""
+    if Mtok is None:
+        Mtok, N = dy.shape
+        K = x.shape[1]
+    if split_k <= 1:
+        gemm(TN, EPI_F32, dy, x, N, K, Mtok, dw, N, K, K, dbias=dbias, accumulate=accumulate)
+        return
+    slab = N * K
+    bslab = ws.data_ptr() + split_k * slab * 4
+    gemm(TN, EPI_F32, dy, x, N, K, Mtok, ws, N, K, K, dbias=bslab if dbias is not None else None,
+         accumulate=False, split_k=split_k, slab_stride=slab)
+    # the launcher may round the split count down; it reports nothing back, so recompute it the same way
+    ksteps = (Mtok + 63) // 64
+    per = (ksteps + split_k - 1) // split_k
+    eff = (ksteps + per - 1) // per
+    reduce_slabs(ws, slab, eff, dw, slab, accumulate)
+    if dbias is not None:
+        reduce_slabs(bslab, N, eff, dbias, N, accumulate)
 
 
+def reduce_slabs(slabs, stride, n, out, count, accumulate=False):
+    _call("reed_reduce_slabs", _p(slabs), stride, n, _p(out), count, int(accumulate), _stream())
+
+
+# ---------------- row kernels ----------------
+def ln_modulate_fwd(x, shift, scale, ldmod, h, mean, rstd, M, D, T, eps=1e-6):
+    _call("reed_ln_modulate_fwd", _p(x), _p(shift), _p(scale), ldmod, _p(h), _p(mean), _p(rstd), M, D, T, eps, _stream())
+
+
+def ln_modulate_bwd(dh, x, mean, rstd, scale, ldmod, dx, part, M, D, T):
+    _call("reed_ln_modulate_bwd", _p(dh), _p(x), _p(mean), _p(rstd), _p(scale), ldmod, _p(dx), _p(part), M, D, T, _stream())
+
+
+def gate_bwd(dx, y, gate, ldgate, dy, part, M, D, T):
+    _call("reed_gate_bwd", _p(dx), _p(y), _p(gate), ldgate, _p(dy), _p(part), M, D, T, _stream())
+
+
+def reduce_mod_parts(parts, dmod, lddmod, B, D, chunks):
+    """parts: list of (ptr, stride, dmod column offset)."""
+    n = len(parts)
+    ptrs = (ctypes.c_void_p * n)(*[_p(p[0]) for p in parts])
+    strides = (ctypes.c_int64 * n)(*[p[1] for p in parts])
+    offs = (ctypes.c_int64 * n)(*[p[2] for p in parts])
+    _call("reed_reduce_mod_parts", ptrs, strides, offs, n, _p(dmod), lddmod, B, D, chunks, _stream())
+
+
+def token_mean_fwd(x, out, B, T, D):
+    _call("reed_token_mean_fwd", _p(x), _p(out), B, T, D, _stream())
+
+
+def token_mean_bwd(dmean, dx, B, T, D):
+    _call("reed_token_mean_bwd", _p(dmean), _p(dx), B, T, D, _stream())
+
+
+def cast_bf16(src, dst, n):
+    _call("reed_cast_bf16", _p(src), _p(dst), n, _stream())
+
+
+# ---------------- attention ----------------
 def attention_fwd(qkv, o, lse, B, T, H, hd):
-    L = _lib.load()
-    _lib.check(L.reed_attention_fwd(_p(qkv), _p(o), _p(lse), B, T, H, hd, _stream()), "attention_fwd")
+    _call("reed_attention_fwd", _p(qkv), _p(o), _p(lse), B, T, H, hd, _stream())
 
 
 def attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd):
-    L = _lib.load()
-    _lib.check(L.reed_attention_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream()),
-               "attention_bwd")
+    _call("reed_attention_bwd", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream())
+
+
+# ---------------- embedders / final layer ----------------
+def patch_embed_fwd(x, w, bias, pos, tokens, B, C, HW, P, D):
+    _call("reed_patch_embed_fwd", _p(x), _p(w), _p(bias), _p(pos), _p(tokens), B, C, HW, P, D, _stream())
+
+
+def patchify_bf16(x, out, B, C, HW, P, order):
+    _call("reed_patchify_bf16", _p(x), _p(out), B, C, HW, P, order, _stream())
+
+
+def smallk_ws_floats(Dw, KS):
+    return int(_lib.load().reed_smallk_wgrad_ws_floats(Dw, KS))
+
+
+def smallk_wgrad(wide, wide_is_f32, small, ws, out, colsum_wide, colsum_small, M, Dw, KS, layout, accumulate):
+    _call("reed_smallk_wgrad", _p(wide), int(wide_is_f32), _p(small), _p(ws), _p(out), _p(colsum_wide),
+          _p(colsum_small), M, Dw, KS, layout, int(accumulate), _stream())
+
+
+def timestep_sinusoid(t, out, B, dim=256, max_period=10000.0):
+    _call("reed_timestep_sinusoid", _p(t), _p(out), B, dim, max_period, _stream())
+
+
+def label_cond(labels, drop, num_classes, table, t_emb, labels_out, c, silu_c, B, D):
+    _call("reed_label_cond", _p(labels), _p(drop), num_classes, _p(table), _p(t_emb), _p(labels_out), _p(c),
+          _p(silu_c), B, D, _stream())
+
+
+def label_cond_bwd(dsilu_c, c, labels_eff, dt_emb, dtable, B, D):
+    _call("reed_label_cond_bwd", _p(dsilu_c), _p(c), _p(labels_eff), _p(dt_emb), _p(dtable), B, D, _stream())
+
+
+def final_layer_fwd(x, shift, scale, ldmod, w, bias, out, mean, rstd, B, T, D, C, P, eps=1e-6):
+    _call("reed_final_layer_fwd", _p(x), _p(shift), _p(scale), ldmod, _p(w), _p(bias), _p(out), _p(mean), _p(rstd),
+          B, T, D, C, P, eps, _stream())
+
+
+def final_layer_bwd_rows(dout, x, mean, rstd, shift, scale, ldmod, w, hbuf, dlin, dh, B, T, D, C, P):
+    _call("reed_final_layer_bwd_rows", _p(dout), _p(x), _p(mean), _p(rstd), _p(shift), _p(scale), ldmod, _p(w),
+          _p(hbuf), _p(dlin), _p(dh), B, T, D, C, P, _stream())
+
+
+# ---------------- loss ----------------
+def interpolant(x, noise, t, xt, target, B, per, path_type):
+    _call("reed_interpolant", _p(x), _p(noise), _p(t), _p(xt), _p(target), B, per, path_type, _stream())
+
+
+def mse_fwd(out, target, loss, B, per):
+    _call("reed_mse_fwd", _p(out), _p(target), _p(loss), B, per, _stream())
+
+
+def mse_bwd(out, target, gscale, dout, B, per):
+    _call("reed_mse_bwd", _p(out), _p(target), _p(gscale), _p(dout), B, per, _stream())
+
+
+def cosine_fwd(zt, z, rowdot, loss, B, T, Z):
+    _call("reed_cosine_fwd", _p(zt), _p(z), _p(rowdot), _p(loss), B, T, Z, _stream())
+
+
+def cosine_bwd(zt, z, gscale, dzt, B, T, Z):
+    _call("reed_cosine_bwd", _p(zt), _p(z), _p(gscale), _p(dzt), B, T, Z, _stream())
+
+
+# ---------------- optimiser ----------------
+def grad_sqnorm(g, n, partial, nblocks):
+    _call("reed_grad_sqnorm", _p(g), n, _p(partial), nblocks, _stream())
+
+
+def clip_finalize(partial, nblocks, max_norm, norm_clip):
+    _call("reed_clip_finalize", _p(partial), nblocks, max_norm, _p(norm_clip), _stream())
+
+
+def adamw_ema(p, g, m, v, ema, shadow, n_train, n_total, norm_clip, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay):
+    _call("reed_adamw_ema", _p(p), _p(g), _p(m), _p(v), _p(ema), _p(shadow), n_train, n_total, _p(norm_clip),
+          lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay, _stream())
+
+
+# ---------------- samplers ----------------
+def sampler_input(x, out, n, dup):
+    _call("reed_sampler_input", _p(x), _p(out), n, int(dup), _stream())
+
+
+def sampler_update(x_cur, model_out, d_prev, d_store, x_next, n, cfg, cfg_scale, dt, w0, w1):
+    _call("reed_sampler_update", _p(x_cur), _p(model_out), _p(d_prev), _p(d_store), _p(x_next), n, int(cfg),
+          float(cfg_scale), float(dt), float(w0), float(w1), _stream())
+
+
+def sde_update(x_cur, model_out, eps, x_next, n, cfg, cfg_scale, t_cur, dt, path_type, last):
+    _call("reed_sde_update", _p(x_cur), _p(model_out), _p(eps), _p(x_next), n, int(cfg), float(cfg_scale),
+          float(t_cur), float(dt), path_type, int(last), _stream())

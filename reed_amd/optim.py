@@ -1,0 +1,109 @@
+"""Fused clip_grad_norm_ + AdamW + EMA (+ bf16 weight re-cast) over the flat parameter arena — replaces
+image/train.py:402-412 (accelerator.clip_grad_norm_, torch.optim.AdamW.step, zero_grad, update_ema) with three
+HIP launches and no host synchronisation (the gradient norm stays on the device until someone asks for it).
+"""
+import torch
+
+from . import ops
+
+_NB = 2048  # partial-sum blocks of the squared-norm reduction
+
+
+class FusedAdamWEMA:
+    def __init__(self, model, ema=None, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8,
+                 max_grad_norm=1.0, ema_decay=0.9999):
+        self.model, self.ema = model, ema
+        self.lr, self.betas, self.weight_decay, self.eps = lr, tuple(betas), weight_decay, eps
+        self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
+        self.step_count = 0
+        A = model._arena
+        if A.master.device.type != "cuda":
+            raise RuntimeError("FusedAdamWEMA: move the model to the GPU first")
+        dev = A.master.device
+        n = model._layout.n_train
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.partial = torch.empty(_NB, dtype=torch.float32, device=dev)
+        self.norm_clip = torch.zeros(2, dtype=torch.float32, device=dev)  # [||g||, clip coefficient]
+        if ema is not None:
+            if ema._layout.n_total != model._layout.n_total or ema._arena.master.device != dev:
+                raise ValueError("EMA model must be a deepcopy of the model on the same device")
+
+    @property
+    def grad_norm(self):
+        """0-d device tensor: the pre-clip global gradient norm of the last step (no host sync until .item())."""
+        return self.norm_clip[0]
+
+    @torch.no_grad()
+    def step(self):
+        m = self.model
+        A, L = m._arena, m._layout
+        if A.grad is None:
+            raise RuntimeError("FusedAdamWEMA.step() called before any backward")
+        A.ensure_shadow()
+        nc = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            ops.grad_sqnorm(A.grad, L.n_train, self.partial, _NB)
+            ops.clip_finalize(self.partial, _NB, float(self.max_grad_norm), self.norm_clip)
+            nc = self.norm_clip
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        ema_buf = self.ema._arena.master if self.ema is not None else None
+        ops.adamw_ema(A.master, A.grad, self.exp_avg, self.exp_avg_sq, ema_buf, A.shadow, L.n_train, L.n_total, nc,
+                      self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay)
+        A.mark_shadow_fresh()
+        if self.ema is not None:
+            self.ema._arena.shadow_version = -1  # EMA master changed behind torch's back: re-cast on next use
+
+    def zero_grad(self, set_to_none=True):
+        """The next backward overwrites the gradient arena (no memset needed)."""
+        eng = self.model._engine
+        if eng is not None:
+            eng.zero_grad()
+        for p in self.model.parameters():
+            p.grad = None
+
+    # ---- checkpoint compatibility with torch.optim.AdamW.state_dict() (train.py:423) ----
+    def state_dict(self):
+        L = self.model._layout
+        state, idx = {}, []
+        for i, (name, p) in enumerate(self.model.named_parameters()):
+            idx.append(i)
+            if not p.requires_grad or self.step_count == 0:
+                continue
+            off, shp = L.seg[name]
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + n].view(shp).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shp).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": idx}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        L = self.model._layout
+        names = [n for n, _ in self.model.named_parameters()]
+        steps = 0
+        for i, st in sd["state"].items():
+            name = names[int(i)]
+            off, shp = L.seg[name]
+            n = int(torch.tensor(shp).prod())
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].flatten())
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].flatten())
+            steps = max(steps, int(float(st["step"])))
+        self.step_count = steps
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+
+
+@torch.no_grad()
+def update_ema(ema_model, model, decay=0.9999):
+    """train.py:94-105 as a single fused pass (used for the decay=0 initial sync; the per-step update is fused
+    into FusedAdamWEMA.step)."""
+    A, E = model._arena, ema_model._arena
+    ops.adamw_ema(A.master, None, None, None, E.master, None, 0, model._layout.n_total, None, 0.0, 0.9, 0.999, 1e-8,
+                  0.0, 1.0, 1.0, decay)
+    E.shadow_version = -1

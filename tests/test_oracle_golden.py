@@ -37,22 +37,24 @@ def inputs(B, C=4, HW=32, seed=0, zdims=(), T=256, num_classes=1000):
 
 def tiny_cfg(D=128, heads=2, depth=3, **kw):
     d = dict(input_size=8, patch_size=2, in_channels=4, hidden_size=D, depth=depth, num_heads=heads, num_classes=10,
-             z_dims=[64], z_types=["i"], encoder_depth=2, encoder_depth_text=None, projector_dim=128,
+             z_dims=[128], z_types=["i"], encoder_depth=2, encoder_depth_text=None, projector_dim=128,
              class_dropout_prob=0.1, mlp_ratio=4.0, fused_attn=True, qk_norm=False)
     d.update(kw)
     return d
 
 
 TINY_CASES = {
-    "hd64": dict(cfg=tiny_cfg(), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-    "hd72": dict(cfg=tiny_cfg(D=144), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-    "unfused": dict(cfg=tiny_cfg(fused_attn=False), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-    "qknorm": dict(cfg=tiny_cfg(qk_norm=True), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-    "two_same": dict(cfg=tiny_cfg(z_dims=[64, 32], z_types=["i", "t"]), zspec=[(64, "i"), (32, "t")],
-                     enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
-    "two_split": dict(cfg=tiny_cfg(z_dims=[64, 32], z_types=["i", "t"], encoder_depth=1, encoder_depth_text=3),
-                      zspec=[(64, "i"), (32, "t")], enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
-    "patch4": dict(cfg=tiny_cfg(input_size=16, patch_size=4), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+    "hd64": dict(cfg=tiny_cfg(), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=True),
+    "hd72": dict(cfg=tiny_cfg(D=144, z_dims=[64]), zspec=[(64, "i")], enc=["dinov2"], co=[1.0], hip=False),
+    "unfused": dict(cfg=tiny_cfg(fused_attn=False), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=True),
+    "qknorm": dict(cfg=tiny_cfg(qk_norm=True), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=False),
+    "two_same": dict(cfg=tiny_cfg(z_dims=[128, 256], z_types=["i", "t"]), zspec=[(128, "i"), (256, "t")],
+                     enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5], hip=True),
+    "two_split": dict(cfg=tiny_cfg(z_dims=[128, 256], z_types=["i", "t"], encoder_depth=1, encoder_depth_text=3),
+                      zspec=[(128, "i"), (256, "t")], enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5], hip=True),
+    "patch4": dict(cfg=tiny_cfg(input_size=16, patch_size=4), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=True),
+    "xl3": dict(cfg=tiny_cfg(D=1152, heads=16, input_size=16, projector_dim=256), zspec=[(128, "i")],
+                enc=["dinov2"], co=[1.0], hip=True),
 }
 
 
@@ -104,7 +106,9 @@ def test_tiny_forward_backward(name):
             np.testing.assert_allclose(float(v.grad.double().norm()), g[key], rtol=2e-4, atol=1e-7)
             nchecked += 1
     assert nchecked >= len(P) - 3
-    for k in ("final_layer.linear.weight", "blocks.0.attn.qkv.bias", "x_embedder.proj.weight"):
+    for k in ("final_layer.linear.weight", "blocks.0.attn.qkv.bias", "x_embedder.proj.weight", "x_embedder.proj.bias",
+              "blocks.1.adaLN_modulation.1.bias", "blocks.2.mlp.fc1.bias", "projectors.0.4.bias",
+              "final_layer.linear.bias"):
         np.testing.assert_allclose(P[k].grad.numpy(), g[f"{name}.grad.{k}"], rtol=2e-3, atol=2e-6)
     # eval-mode inference
     x, _, t, y, _, _ = inputs(4, 4, cfg["input_size"], 11, [], 0, 10)

@@ -124,7 +124,7 @@ def build_ref_model(ref_sit, name, seed=0, **kw):
 
 def tiny_kwargs(D=128, heads=2, depth=3, **kw):
     d = dict(input_size=8, patch_size=2, in_channels=4, hidden_size=D, decoder_hidden_size=D, depth=depth,
-             num_heads=heads, num_classes=10, z_dims=[64], z_types=["i"], encoder_depth=2, projector_dim=128,
+             num_heads=heads, num_classes=10, z_dims=[128], z_types=["i"], encoder_depth=2, projector_dim=128,
              fused_attn=True, qk_norm=False)
     d.update(kw)
     return d
@@ -205,15 +205,17 @@ def run_fwd_bwd(ref_sit, ref_loss, kw, B, seed, zspec, enc_names, coeffs, autoca
 def g_tiny(ref_sit, ref_loss, ref_samplers):
     """G-d / G-g: tiny SiT forward + grads in several structural variants (fp32)."""
     cases = {
-        "hd64": dict(kw=tiny_kwargs(), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-        "hd72": dict(kw=tiny_kwargs(D=144), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-        "unfused": dict(kw=tiny_kwargs(fused_attn=False), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-        "qknorm": dict(kw=tiny_kwargs(qk_norm=True), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
-        "two_same": dict(kw=tiny_kwargs(z_dims=[64, 32], z_types=["i", "t"]), zspec=[(64, "i"), (32, "t")],
+        "hd64": dict(kw=tiny_kwargs(), zspec=[(128, "i")], enc=["dinov2"], co=[1.0]),
+        "hd72": dict(kw=tiny_kwargs(D=144, z_dims=[64]), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+        "unfused": dict(kw=tiny_kwargs(fused_attn=False), zspec=[(128, "i")], enc=["dinov2"], co=[1.0]),
+        "qknorm": dict(kw=tiny_kwargs(qk_norm=True), zspec=[(128, "i")], enc=["dinov2"], co=[1.0]),
+        "two_same": dict(kw=tiny_kwargs(z_dims=[128, 256], z_types=["i", "t"]), zspec=[(128, "i"), (256, "t")],
                          enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
-        "two_split": dict(kw=tiny_kwargs(z_dims=[64, 32], z_types=["i", "t"], encoder_depth=1, encoder_depth_text=3),
-                          zspec=[(64, "i"), (32, "t")], enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
-        "patch4": dict(kw=tiny_kwargs(input_size=16, patch_size=4), zspec=[(64, "i")], enc=["dinov2"], co=[1.0]),
+        "two_split": dict(kw=tiny_kwargs(z_dims=[128, 256], z_types=["i", "t"], encoder_depth=1, encoder_depth_text=3),
+                          zspec=[(128, "i"), (256, "t")], enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5]),
+        "patch4": dict(kw=tiny_kwargs(input_size=16, patch_size=4), zspec=[(128, "i")], enc=["dinov2"], co=[1.0]),
+        "xl3": dict(kw=tiny_kwargs(D=1152, heads=16, input_size=16, projector_dim=256), zspec=[(128, "i")],
+                    enc=["dinov2"], co=[1.0]),
     }
     out = {}
     for name, c in cases.items():
@@ -228,6 +230,13 @@ def g_tiny(ref_sit, ref_loss, ref_samplers):
         out[f"{name}.grad.final_layer.linear.weight"] = grads["final_layer.linear.weight"]
         out[f"{name}.grad.blocks.0.attn.qkv.bias"] = grads["blocks.0.attn.qkv.bias"]
         out[f"{name}.grad.x_embedder.proj.weight"] = grads["x_embedder.proj.weight"]
+        out[f"{name}.grad.x_embedder.proj.bias"] = grads["x_embedder.proj.bias"]
+        out[f"{name}.grad.t_embedder.mlp.0.weight"] = grads["t_embedder.mlp.0.weight"][:, ::16]
+        out[f"{name}.grad.blocks.1.adaLN_modulation.1.bias"] = grads["blocks.1.adaLN_modulation.1.bias"]
+        out[f"{name}.grad.blocks.2.mlp.fc1.bias"] = grads["blocks.2.mlp.fc1.bias"]
+        out[f"{name}.grad.projectors.0.4.bias"] = grads["projectors.0.4.bias"]
+        out[f"{name}.grad.final_layer.linear.bias"] = grads["final_layer.linear.bias"]
+        out[f"{name}.grad.y_embedder.rows"] = grads["y_embedder.embedding_table.weight"][:, :8]
         # eval-mode inference forward
         m.eval()
         x, _, t, y, _, _ = inputs(4, 4, c["kw"]["input_size"], 11, [], 0, 10)
