@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py — SiT-XL/2 ImageNet-256 train images/sec on MI355X (BASELINE.json metric), HIP path only.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full optimisation step of image/train.py on one batch of synthetic inputs already resident in HBM:
+sample_posterior -> SILoss (interpolant, SiT-XL/2 forward with the 1024-d DINOv2-L-shaped projector tap, MSE +
+cosine alignment) -> backward -> [RCCL gradient all-reduce, overlapped] -> clip_grad_norm_(1.0) -> AdamW -> EMA.
+Global batch 256 is sharded over the N ranks (b = 256/N per GPU, train.py:263); scaling = "strong".
+Rank 0 prints ONE JSON line; `roofline` is the dominant kernel (the bf16 MFMA GEMM) timed live with events on the
+launch stream; `cpu_baseline` is the oracle (CPU restatement, fp32) timed on this box's host cores at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMG_STEP = 724.97e9   # 241.66 GFLOP forward x 3 (XL/2, z=1024 projector)
+PEAK_BF16 = 2.5e15             # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--model", type=str, default="SiT-XL/2")
+    ap.add_argument("--z-dim", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true")
+    return ap.parse_args()
+
+
+def random_fill(model, seed):
+    """Random-init weights of the architecture, adaLN/final layers non-zero so every block does real work
+    (at the reference's exact init all gates are 0 and most gradients vanish: SURVEY.md §8d)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    A, L = model._arena, model._layout
+    for name, (off, shp) in L.seg.items():
+        if name == "pos_embed":
+            continue
+        n = 1
+        for s in shp:
+            n *= s
+        v = A.master[off:off + n]
+        if name.endswith("bias"):
+            v.uniform_(-0.02, 0.02, generator=g)
+        elif "embedding_table" in name:
+            v.normal_(0, 0.02, generator=g)
+        else:
+            fan_in = n // shp[0]
+            gain = 0.5 if ("adaLN" in name or name.startswith("final_layer.linear")) else 1.0
+            a = gain * (3.0 / fan_in) ** 0.5
+            v.uniform_(-a, a, generator=g)
+    A.shadow_version = -1
+
+
+def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
+    """Per-shape timing of the block GEMMs (events on the launch stream). Returns rows + the dominant one."""
+    from reed_amd import ops
+    dev = torch.device("cuda")
+    M = b * T
+    bf = lambda *s: (torch.randn(*s, device=dev) * 0.05).to(torch.bfloat16)  # noqa: E731
+    x, w_qkv, w_proj, w1, w2 = bf(M, D), bf(3 * D, D), bf(D, D), bf(Hm, D), bf(D, Hm)
+    big, big2 = bf(M, Hm), bf(M, Hm)
+    o3 = bf(M, 3 * D)
+    ybuf = bf(M, D)
+    xo = torch.empty(M, D, device=dev)
+    xi = torch.randn(M, D, device=dev)
+    gate = bf(b, 6 * D)
+    gw = torch.empty(Hm, D, device=dev)
+    gb = torch.empty(Hm, device=dev)
+    bias = bf(Hm)
+    cases = [
+        ("fwd qkv  NT bias", 2.0 * M * 3 * D * D, lambda: ops.linear_fwd(x, w_qkv, bias[:3 * D], o3)),
+        ("fwd proj NT gate+res", 2.0 * M * D * D, lambda: ops.linear_fwd(x, w_proj, bias[:D], xo, epi=ops.EPI_GATE_RES, R=xi, gate=gate, ldgate=6 * D, rows_per_gate=T, y_out=ybuf)),
+        ("fwd fc1  NT gelu", 2.0 * M * Hm * D, lambda: ops.linear_fwd(x, w1, bias, big, epi=ops.EPI_GELU, act_out=big2)),
+        ("fwd fc2  NT gate+res", 2.0 * M * Hm * D, lambda: ops.linear_fwd(big, w2, bias[:D], xo, epi=ops.EPI_GATE_RES, R=xi, gate=gate, ldgate=6 * D, rows_per_gate=T)),
+        ("dgrad fc2 NN dgelu", 2.0 * M * Hm * D, lambda: ops.linear_dgrad(x, w2, big, epi=ops.EPI_DGELU, R=big2)),
+        ("dgrad fc1 NN", 2.0 * M * Hm * D, lambda: ops.linear_dgrad(big, w1, x)),
+        ("dgrad qkv NN", 2.0 * M * 3 * D * D, lambda: ops.linear_dgrad(o3, w_qkv, x)),
+        ("wgrad fc1 TN", 2.0 * M * Hm * D, lambda: ops.linear_wgrad(big, x, gw, dbias=gb)),
+        ("wgrad fc2 TN", 2.0 * M * Hm * D, lambda: ops.linear_wgrad(x, big, gw.view(D, Hm), dbias=gb[:D])),
+        ("wgrad qkv TN", 2.0 * M * 3 * D * D, lambda: ops.linear_wgrad(o3, x, gw[:3 * D], dbias=gb[:3 * D])),
+    ]
+    rows = []
+    for name, flop, fn in cases:
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        rows.append({"kernel": name, "ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1)})
+    return rows
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference step, fp32, torch CPU ops) on this box's host cores:
+    SiT-XL/2 + 1024-d projector, B=8, 1 warm-up at B=2 then one timed step."""
+    from oracle import sit as osit
+    from oracle import train_step as otrain
+    threads = torch.get_num_threads()
+    cfg = osit.make_config("SiT-XL/2", z_dims=[1024], z_types=["i"])
+    g = torch.Generator().manual_seed(0)
+    P = osit.init_params(cfg)
+    for k, v in P.items():
+        if k == "pos_embed":
+            continue
+        fan = v[0].numel() if v.ndim > 1 else 1
+        v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * (0.5 * (3.0 / max(fan, 1)) ** 0.5 if v.ndim > 1 else 0.02))
+    tr = otrain.Trainer(P, cfg, ["dinov2"], [1.0], diffusion_warm_up_steps=0)
+
+    def batch(B):
+        return (torch.randn(B, 4, 32, 32, generator=g), torch.randint(0, 1000, (B,), generator=g),
+                [torch.randn(B, 256, 1024, generator=g)])
+    x, y, zs = batch(2)
+    tr.step(x, y, zs)
+    B = 8
+    x, y, zs = batch(B)
+    t0 = time.time()
+    tr.step(x, y, zs)
+    dt = time.time() - t0
+    return {"value": round(B / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (CPU restatement of image/train.py step) SiT-XL/2 + 1024-d projector, fp32, B={B}, "
+                      f"1 step after a B=2 warm-up, {dt:.1f}s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import copy
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.optim import FusedAdamWEMA
+    from reed_amd.parallel import GradReducer, shard_batch, rank_seed
+    from reed_amd.trainer import TrainStep
+
+    b = shard_batch(args.global_batch, world)
+    torch.manual_seed(rank_seed(0, rank))
+    model = SiT_models[args.model](z_dims=[args.z_dim], z_types=["i"], encoder_depth=8).to(dev).train()
+    random_fill(model, 1234)  # identical on every rank (same seed); broadcast below anyway
+    ema = copy.deepcopy(model).requires_grad_(False).eval()
+    opt = FusedAdamWEMA(model, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(model, rank, world)
+        reducer.broadcast_params(0)
+    loss_fn = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
+    step = TrainStep(model, loss_fn, opt, reducer, proj_coeff=0.5, diffusion_warm_up_steps=0)
+
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    mean = torch.randn(b, 4, 32, 32, device=dev, generator=g) * 5.49
+    moments = torch.cat([mean, torch.full_like(mean, 0.5)], dim=1)
+    labels = torch.randint(0, 1000, (b,), device=dev, generator=g)
+    zs = [torch.randn(b, 256, args.z_dim, device=dev, generator=g)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step(None, labels, zs, moments=moments)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(None, labels, zs, moments=moments)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(res["loss"])
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        ips = args.global_batch * args.steps / dt
+        out = {
+            "metric": "SiT-XL/2 ImageNet-256 train images/sec", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)",
+            "config": {"workload": f"C{'2' if world == 1 else '3'}: {args.model} + {args.z_dim}-d alignment projector (REED loss), "
+                                   f"global batch {args.global_batch} (b={b}/GPU), full train step "
+                                   "(fwd+bwd+clip+AdamW+EMA), bf16 MFMA / fp32 master",
+                       "global_batch": args.global_batch, "local_batch": b, "parallelism": f"dp{world}"},
+            "final_loss": round(loss_val, 5),
+            "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
+        }
+        rows = None
+        if not args.no_kernel_table:
+            rows = time_gemms(b)
+            # dominant kernel = the MFMA GEMM family; report its flop-weighted aggregate
+            tot_ms = sum(r["ms"] for r in rows)
+            agg = sum(r["tflops"] * r["ms"] for r in rows) / tot_ms
+            dom = max(rows, key=lambda r: r["ms"])
+            out["roofline"] = {"bound": "mfma", "achieved": round(agg, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                               "frac": round(agg * 1e12 / PEAK_BF16, 4), "traffic": None,
+                               "kernel": "gemm_kernel<NT|NN|TN> 128x128x64 bf16 MFMA (time-weighted over the block's 10 GEMM shapes)",
+                               "slowest_shape": dom}
+            out["gemm_table"] = rows
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
+                                       "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        if reducer is not None:
+            reducer.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

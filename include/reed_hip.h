@@ -125,6 +125,9 @@ int reed_token_mean_bwd(const void* dmean, float* dx, int B, int T, int D, void*
 /* ---------------------------------------------------------------------------------------------
  * SILoss arithmetic (loss.py:49-64,153-237)
  * ------------------------------------------------------------------------------------------- */
+/* sample_posterior (train.py:84-91): out [B,half] = (moments[:, :half] + moments[:, half:] * eps) * scale + bias */
+int reed_sample_posterior(const float* moments, const float* eps, float* out, int B, int64_t half,
+                          float scale, float bias, void* stream);
 /* path_type 0 linear, 1 cosine: xt = a x + s n, target = da x + ds n */
 int reed_interpolant(const float* x, const float* noise, const float* t, float* xt, float* target,
                      int B, int64_t per, int path_type, void* stream);

@@ -47,6 +47,10 @@ def load():
         raise RuntimeError(
             f"reed_amd: {LIB_PATH} not found. Build it with `python -m reed_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / librccl. Import torch FIRST so that our NEEDED entries
+    # resolve (by SONAME) to the runtime torch already loaded: one HIP runtime and one RCCL per process. Loading
+    # /opt/rocm's copies first makes torch fail later with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     missing = []
     for name, (restype, args) in parse_header().items():

@@ -442,12 +442,12 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
   if (hd == 64) {
     static int once = set_lds(attn_fwd_kernel<64>, lds);
     if (once) return once;
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+    REED_KLAUNCH(attn_fwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
                        (bf16*)o, lse, B, T, H);
   } else {
     static int once = set_lds(attn_fwd_kernel<72>, lds);
     if (once) return once;
-    hipLaunchKernelGGL(attn_fwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+    REED_KLAUNCH(attn_fwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
                        (bf16*)o, lse, B, T, H);
   }
   REED_LAUNCH_CHECK();
@@ -464,12 +464,12 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
   if (hd == 64) {
     static int once = set_lds(attn_bwd_kernel<64>, lds);
     if (once) return once;
-    hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+    REED_KLAUNCH(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
                        (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   } else {
     static int once = set_lds(attn_bwd_kernel<72>, lds);
     if (once) return once;
-    hipLaunchKernelGGL(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
+    REED_KLAUNCH(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
                        (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   }
   REED_LAUNCH_CHECK();

@@ -25,6 +25,14 @@ extern "C" void reed_set_error(const char* fmt, ...);
     }                                    \
   } while (0)
 
+// hipGetLastError() is sticky per thread and shared with every other HIP user in the process (PyTorch): clear it
+// before our launch so that REED_LAUNCH_CHECK reports only our own launch failure.
+#define REED_KLAUNCH(...)              \
+  do {                                 \
+    (void)hipGetLastError();           \
+    hipLaunchKernelGGL(__VA_ARGS__);   \
+  } while (0)
+
 #define REED_LAUNCH_CHECK()                                        \
   do {                                                             \
     hipError_t e__ = hipGetLastError();                            \

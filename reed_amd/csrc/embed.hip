@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void final_bwd_rows_kernel(const float* __rest
 extern "C" int reed_patchify_bf16(const float* x, void* out, int B, int C, int HW, int P, int order, void* stream) {
   REED_CHECK_ARG(HW % P == 0, "patchify: HW=%d not divisible by P=%d", HW, P);
   long n = (long)B * C * HW * HW;
-  hipLaunchKernelGGL(patchify_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, B, C, HW, P, order);
+  REED_KLAUNCH(patchify_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, B, C, HW, P, order);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -296,7 +296,7 @@ extern "C" int reed_patch_embed_fwd(const float* x, const void* w, const void* b
   REED_CHECK_ARG(x && w && pos && tokens, "patch_embed_fwd: null pointer");
   REED_CHECK_ARG(HW % P == 0 && (C * P * P) % 8 == 0, "patch_embed: HW=%d P=%d C=%d unsupported", HW, P, C);
   const int T = (HW / P) * (HW / P), K = C * P * P;
-  hipLaunchKernelGGL(patch_embed_fwd_kernel, dim3(cdiv((long)B * T, 8)), dim3(256), 8 * K * sizeof(float),
+  REED_KLAUNCH(patch_embed_fwd_kernel, dim3(cdiv((long)B * T, 8)), dim3(256), 8 * K * sizeof(float),
                      (hipStream_t)stream, x, (const bf16*)w, (const bf16*)bias, pos, tokens, B, C, HW, P, D);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -312,12 +312,12 @@ extern "C" int reed_smallk_wgrad(const void* wide, int wide_is_f32, const void* 
   dim3 grid(cdiv(Dw, 256), NSL);
   size_t lds = 64 * KS * sizeof(float);
   if (wide_is_f32)
-    hipLaunchKernelGGL(smallk_wgrad_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+    REED_KLAUNCH(smallk_wgrad_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
   else
-    hipLaunchKernelGGL(smallk_wgrad_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+    REED_KLAUNCH(smallk_wgrad_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
   REED_LAUNCH_CHECK();
   long n0 = (long)KS * Dw, n1 = Dw, n2 = KS;
-  hipLaunchKernelGGL(smallk_reduce_kernel, dim3(cdiv(n0 + n1 + n2, 256)), dim3(256), 0, (hipStream_t)stream, ws,
+  REED_KLAUNCH(smallk_reduce_kernel, dim3(cdiv(n0 + n1 + n2, 256)), dim3(256), 0, (hipStream_t)stream, ws,
                      n0 + n1 + n2, out, n0, colsum_wide, n1, colsum_small, n2, accumulate);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -325,7 +325,7 @@ extern "C" int reed_smallk_wgrad(const void* wide, int wide_is_f32, const void* 
 
 extern "C" int reed_timestep_sinusoid(const float* t, void* out, int B, int dim, float max_period, void* stream) {
   REED_CHECK_ARG(t && out && dim >= 2, "timestep_sinusoid: bad args");
-  hipLaunchKernelGGL(sinusoid_kernel, dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t,
+  REED_KLAUNCH(sinusoid_kernel, dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t,
                      (bf16*)out, B, dim, max_period);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -335,7 +335,7 @@ extern "C" int reed_label_cond(const int64_t* labels, const uint8_t* drop, int n
                                const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int B, int D,
                                void* stream) {
   REED_CHECK_ARG(labels && table && t_emb && c && silu_c, "label_cond: null pointer");
-  hipLaunchKernelGGL(label_cond_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, labels, drop,
+  REED_KLAUNCH(label_cond_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, labels, drop,
                      num_classes, table, (const bf16*)t_emb, labels_out, c, (bf16*)silu_c, D);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -344,7 +344,7 @@ extern "C" int reed_label_cond(const int64_t* labels, const uint8_t* drop, int n
 extern "C" int reed_label_cond_bwd(const float* dsilu_c, const float* c, const int64_t* labels_eff, void* dt_emb,
                                    float* dtable, int B, int D, void* stream) {
   REED_CHECK_ARG(dsilu_c && c && labels_eff && dt_emb && dtable, "label_cond_bwd: null pointer");
-  hipLaunchKernelGGL(label_cond_bwd_kernel, dim3(cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, dsilu_c, c,
+  REED_KLAUNCH(label_cond_bwd_kernel, dim3(cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, dsilu_c, c,
                      labels_eff, (bf16*)dt_emb, dtable, B, D);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -357,7 +357,7 @@ extern "C" int reed_final_layer_fwd(const float* x, const void* shift, const voi
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
   int G = (int)(sqrtf((float)T) + 0.5f);
   REED_CHECK_ARG(G * G == T, "final_layer: T=%d is not a square grid", T);
-  hipLaunchKernelGGL(final_fwd_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, x,
+  REED_KLAUNCH(final_fwd_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, x,
                      (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w, (const bf16*)bias, out, mean,
                      rstd, B, T, D, C, P, eps);
   REED_LAUNCH_CHECK();
@@ -371,7 +371,7 @@ extern "C" int reed_final_layer_bwd_rows(const float* dout, const float* x, cons
   REED_CHECK_ARG(dout && x && mean && rstd && shift && scale && w && hbuf && dlin && dh, "final_layer_bwd_rows: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
   const int NO = P * P * C;
-  hipLaunchKernelGGL(final_bwd_rows_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 4 * NO * sizeof(float),
+  REED_KLAUNCH(final_bwd_rows_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 4 * NO * sizeof(float),
                      (hipStream_t)stream, dout, x, mean, rstd, (const bf16*)shift, (const bf16*)scale, (long)ldmod,
                      (const bf16*)w, (bf16*)hbuf, (bf16*)dlin, (bf16*)dh, B, T, D, C, P);
   REED_LAUNCH_CHECK();

@@ -285,7 +285,7 @@ int launch(const GemmArgs& a, int splits, hipStream_t stream) {
   }
   const int ntm = cdiv(a.M, BM), ntn = a.N / BN;
   dim3 grid(ntm * ntn, splits, 1);
-  hipLaunchKernelGGL((gemm_kernel<LAY, EPI>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
+  REED_KLAUNCH((gemm_kernel<LAY, EPI>), grid, dim3(256), 2 * STAGE_BYTES, stream, a);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -25,6 +25,17 @@ __global__ __launch_bounds__(256) void interpolant_kernel(const float* __restric
   }
 }
 
+// sample_posterior (train.py:84-91): z = (mean + std * eps) * scale + bias, moments = cat([mean, std], dim=1)
+__global__ __launch_bounds__(256) void sample_posterior_kernel(const float* __restrict__ mom, const float* __restrict__ eps,
+                                                               float* __restrict__ out, long half, float scale,
+                                                               float bias) {
+  const int b = blockIdx.y;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long)gridDim.x * 256) {
+    float mean = mom[(long)b * 2 * half + i], sd = mom[(long)b * 2 * half + half + i];
+    out[(long)b * half + i] = (mean + sd * eps[(long)b * half + i]) * scale + bias;
+  }
+}
+
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ o, const float* __restrict__ tg,
                                                       float* __restrict__ loss, long per) {
   __shared__ float red[4];
@@ -108,21 +119,29 @@ extern "C" int reed_interpolant(const float* x, const float* noise, const float*
                                 int B, int64_t per, int path_type, void* stream) {
   REED_CHECK_ARG(x && noise && t && xt && target, "interpolant: null pointer");
   REED_CHECK_ARG(path_type == 0 || path_type == 1, "interpolant: path_type %d (0 linear, 1 cosine)", path_type);
-  hipLaunchKernelGGL(interpolant_kernel, dim3(cdiv(per, 1024), B), dim3(256), 0, (hipStream_t)stream, x, noise, t, xt,
+  REED_KLAUNCH(interpolant_kernel, dim3(cdiv(per, 1024), B), dim3(256), 0, (hipStream_t)stream, x, noise, t, xt,
                      target, (long)per, path_type);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+extern "C" int reed_sample_posterior(const float* moments, const float* eps, float* out, int B, int64_t half,
+                                     float scale, float bias, void* stream) {
+  REED_CHECK_ARG(moments && eps && out, "sample_posterior: null pointer");
+  REED_KLAUNCH(sample_posterior_kernel, dim3(cdiv(half, 1024), B), dim3(256), 0, (hipStream_t)stream, moments, eps,
+                     out, (long)half, scale, bias);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
 extern "C" int reed_mse_fwd(const float* out, const float* target, float* loss, int B, int64_t per, void* stream) {
   REED_CHECK_ARG(out && target && loss, "mse_fwd: null pointer");
-  hipLaunchKernelGGL(mse_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, target, loss, (long)per);
+  REED_KLAUNCH(mse_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, target, loss, (long)per);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
 extern "C" int reed_mse_bwd(const float* out, const float* target, const float* gscale, float* dout, int B,
                             int64_t per, void* stream) {
   REED_CHECK_ARG(out && target && gscale && dout, "mse_bwd: null pointer");
-  hipLaunchKernelGGL(mse_bwd_kernel, dim3(cdiv(per, 1024), B), dim3(256), 0, (hipStream_t)stream, out, target, gscale,
+  REED_KLAUNCH(mse_bwd_kernel, dim3(cdiv(per, 1024), B), dim3(256), 0, (hipStream_t)stream, out, target, gscale,
                      dout, (long)per);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -132,9 +151,9 @@ extern "C" int reed_cosine_fwd(const void* zt, const float* z, float* rowdot, fl
   REED_CHECK_ARG(zt && z && rowdot && loss, "cosine_fwd: null pointer");
   REED_CHECK_ARG(Z % 4 == 0, "cosine: Z=%d must be a multiple of 4", Z);
   const int M = B * T;
-  hipLaunchKernelGGL(cosine_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)zt, z,
+  REED_KLAUNCH(cosine_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)zt, z,
                      rowdot, M, Z);
-  hipLaunchKernelGGL(cosine_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rowdot, loss, T);
+  REED_KLAUNCH(cosine_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rowdot, loss, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -143,7 +162,7 @@ extern "C" int reed_cosine_bwd(const void* zt, const float* z, const float* gsca
   REED_CHECK_ARG(zt && z && gscale && dzt, "cosine_bwd: null pointer");
   REED_CHECK_ARG(Z % 4 == 0, "cosine: Z=%d must be a multiple of 4", Z);
   const int M = B * T;
-  hipLaunchKernelGGL(cosine_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)zt, z,
+  REED_KLAUNCH(cosine_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)zt, z,
                      gscale, (bf16*)dzt, M, T, Z);
   REED_LAUNCH_CHECK();
   return REED_OK;

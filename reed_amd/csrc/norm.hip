@@ -255,7 +255,7 @@ extern "C" int reed_ln_modulate_fwd(const float* x, const void* shift, const voi
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported (multiple of 4, <= %d)", D, 256 * MAXV);
   REED_CHECK_ARG(M > 0 && T > 0, "ln_modulate: bad M=%d T=%d", M, T);
   REED_CHECK_ARG((scale == nullptr) == (shift == nullptr), "ln_modulate: shift and scale must both be given or both NULL");
-  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, (const bf16*)shift,
+  REED_KLAUNCH(ln_mod_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, (const bf16*)shift,
                      (const bf16*)scale, (long)ldmod, (bf16*)h, mean, rstd, M, D, T, eps);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -267,7 +267,7 @@ extern "C" int reed_ln_modulate_bwd(const void* dh, const float* x, const float*
   REED_CHECK_ARG(dh && x && mean && rstd && scale && dx && part, "ln_modulate_bwd: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd: T=%d, M=%d must be multiples of 16", T, M);
-  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
+  REED_KLAUNCH(ln_mod_bwd_kernel, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
                      (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, M, D, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -278,7 +278,7 @@ extern "C" int reed_gate_bwd(const float* dx, const void* y, const void* gate, i
   REED_CHECK_ARG(dx && y && gate && dy && part, "gate_bwd: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "gate_bwd: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "gate_bwd: T=%d, M=%d must be multiples of 16", T, M);
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(M / 16), dim3(256), 4 * D * sizeof(float), (hipStream_t)stream, dx,
+  REED_KLAUNCH(gate_bwd_kernel, dim3(M / 16), dim3(256), 4 * D * sizeof(float), (hipStream_t)stream, dx,
                      (const bf16*)y, (const bf16*)gate, (long)ldgate, (bf16*)dy, part, M, D, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -291,19 +291,19 @@ extern "C" int reed_reduce_mod_parts(const float* const* parts, const int64_t* s
   PartList pl;
   pl.n = nparts;
   for (int i = 0; i < nparts; ++i) { pl.ptr[i] = parts[i]; pl.stride[i] = strides[i]; pl.off[i] = offs[i]; }
-  hipLaunchKernelGGL(reduce_mod_parts_kernel, dim3(cdiv(D, 256), B, nparts), dim3(256), 0, (hipStream_t)stream, pl,
+  REED_KLAUNCH(reduce_mod_parts_kernel, dim3(cdiv(D, 256), B, nparts), dim3(256), 0, (hipStream_t)stream, pl,
                      (bf16*)dmod, (long)lddmod, D, chunks);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
 
 extern "C" int reed_token_mean_fwd(const float* x, void* out, int B, int T, int D, void* stream) {
-  hipLaunchKernelGGL(token_mean_fwd_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, T, D);
+  REED_KLAUNCH(token_mean_fwd_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out, T, D);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
 extern "C" int reed_token_mean_bwd(const void* dmean, float* dx, int B, int T, int D, void* stream) {
-  hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream,
+  REED_KLAUNCH(token_mean_bwd_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)dmean, dx, T, D);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -315,7 +315,7 @@ extern "C" int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stre
   long n4 = n >> 2;
   int blocks = (int)(n4 / 256 + 1);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n4, (long)n);
+  REED_KLAUNCH(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n4, (long)n);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -323,7 +323,7 @@ extern "C" int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stre
 extern "C" int reed_reduce_slabs(const float* slabs, int64_t stride, int nslabs, float* out, int64_t n,
                                  int accumulate, void* stream) {
   if (n <= 0) return REED_OK;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, slabs, (long)stride,
+  REED_KLAUNCH(reduce_slabs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, slabs, (long)stride,
                      nslabs, out, (long)n, accumulate);
   REED_LAUNCH_CHECK();
   return REED_OK;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
 extern "C" int reed_grad_sqnorm(const float* g, int64_t n, float* partial, int nblocks, void* stream) {
   REED_CHECK_ARG(g && partial && nblocks > 0 && n >= 0, "grad_sqnorm: bad args");
   REED_CHECK_ARG(((uintptr_t)g % 16) == 0, "grad_sqnorm: misaligned");
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, g, (long)(n >> 2), (long)n,
+  REED_KLAUNCH(sqnorm_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, g, (long)(n >> 2), (long)n,
                      partial);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -100,7 +100,7 @@ extern "C" int reed_grad_sqnorm(const float* g, int64_t n, float* partial, int n
 extern "C" int reed_clip_finalize(const float* partial, int nblocks, float max_norm, float* norm_clip,
                                   void* stream) {
   REED_CHECK_ARG(partial && norm_clip, "clip_finalize: null pointer");
-  hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblocks, max_norm,
+  REED_KLAUNCH(clip_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblocks, max_norm,
                      norm_clip);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -119,7 +119,7 @@ extern "C" int reed_adamw_ema(float* p, const float* g, float* m, float* v, floa
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema,
+  REED_KLAUNCH(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema,
                      (bf16*)shadow, (long)(n_train >> 2), n4, norm_clip, a);
   REED_LAUNCH_CHECK();
   return REED_OK;

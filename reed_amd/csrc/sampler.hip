@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void sde_update_kernel(const double* __restric
 
 extern "C" int reed_sampler_input(const double* x, float* out, int64_t n_elems, int dup, void* stream) {
   REED_CHECK_ARG(x && out && n_elems > 0, "sampler_input: bad args");
-  hipLaunchKernelGGL(sampler_input_kernel, dim3(cdiv(n_elems, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+  REED_KLAUNCH(sampler_input_kernel, dim3(cdiv(n_elems, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
                      (long)n_elems, dup);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -85,7 +85,7 @@ extern "C" int reed_sampler_update(const double* x_cur, const float* model_out, 
                                    double* d_store, double* x_next, int64_t n_elems, int cfg, double cfg_scale,
                                    double dt, double w0, double w1, void* stream) {
   REED_CHECK_ARG(x_cur && model_out && x_next && n_elems > 0, "sampler_update: bad args");
-  hipLaunchKernelGGL(sampler_update_kernel, dim3(cdiv(n_elems, 256)), dim3(256), 0, (hipStream_t)stream, x_cur,
+  REED_KLAUNCH(sampler_update_kernel, dim3(cdiv(n_elems, 256)), dim3(256), 0, (hipStream_t)stream, x_cur,
                      model_out, d_prev, d_store, x_next, (long)n_elems, cfg, cfg_scale, dt, w0, w1);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -94,7 +94,7 @@ extern "C" int reed_sde_update(const double* x_cur, const float* model_out, cons
                                int64_t n_elems, int cfg, double cfg_scale, double t_cur, double dt,
                                int path_type, int last_step, void* stream) {
   REED_CHECK_ARG(x_cur && model_out && x_next && n_elems > 0 && (last_step || eps), "sde_update: bad args");
-  hipLaunchKernelGGL(sde_update_kernel, dim3(cdiv(n_elems, 256)), dim3(256), 0, (hipStream_t)stream, x_cur, model_out,
+  REED_KLAUNCH(sde_update_kernel, dim3(cdiv(n_elems, 256)), dim3(256), 0, (hipStream_t)stream, x_cur, model_out,
                      eps, x_next, (long)n_elems, cfg, cfg_scale, t_cur, dt, path_type, last_step);
   REED_LAUNCH_CHECK();
   return REED_OK;

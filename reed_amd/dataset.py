@@ -1,0 +1,97 @@
+"""CustomDataset — the reference's on-disk training format (image/dataset.py:18-85, written by
+image/preprocessing/dataset_tools.py): <data>/images/**.png (uint8 RGB 256x256), <data>/vae-sd/**.npy (SD-VAE
+moments f32 [8,32,32]) + vae-sd/dataset.json {"labels": [[fname, int], ...]}, optional <data>/<text_embeds_dir>/**.npy.
+Item: (image u8[3,H,W], moments f32[8,h,w], label i64, text f32[Dt] or zeros_like(moments)).
+
+Additive (not in the reference): `features_dirs=[...]` loads precomputed frozen-encoder patch features
+<data>/<dir>/**.npy f32 [256, z] instead of running the encoder every step, and images are
+optional when no on-the-fly encoder needs them.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class CustomDataset(Dataset):
+    def __init__(self, data_dir, text_embeds_dir=None, features_dirs=None, need_images=True):
+        self.images_dir = os.path.join(data_dir, "images")
+        self.features_dir = os.path.join(data_dir, "vae-sd")
+        self.need_images = need_images and os.path.isdir(self.images_dir)
+        exts = {".png", ".jpg", ".jpeg", ".npy", ".bmp", ".webp"}
+
+        def walk(root):
+            return sorted(os.path.relpath(os.path.join(r, f), start=root) for r, _d, files in os.walk(root)
+                          for f in files if os.path.splitext(f)[1].lower() in exts)
+
+        self.image_fnames = walk(self.images_dir) if self.need_images else []
+        self.feature_fnames = walk(self.features_dir)
+        with open(os.path.join(self.features_dir, "dataset.json"), "rb") as f:
+            labels = dict(json.load(f)["labels"])
+        labels = np.array([labels[fn.replace("\\", "/")] for fn in self.feature_fnames])
+        self.labels = labels.astype({1: np.int64, 2: np.float32}[labels.ndim])
+        self.text_embeds_dir = text_embeds_dir
+        if text_embeds_dir is not None:
+            self.full_text_embeds_dir = os.path.join(data_dir, text_embeds_dir)
+            assert os.path.exists(self.full_text_embeds_dir), f"Text embeds dir {self.full_text_embeds_dir} does not exist"
+        self.z_dirs = [os.path.join(data_dir, d) for d in (features_dirs or [])]
+
+    def __len__(self):
+        if self.need_images:
+            assert len(self.image_fnames) == len(self.feature_fnames), \
+                "Number of feature files and label files should be same"
+        return len(self.feature_fnames)
+
+    @staticmethod
+    def _stem(feature_fname):
+        d, f = os.path.split(feature_fname)
+        return os.path.join(d, os.path.splitext(f)[0].replace("img-mean-std-", "img"))
+
+    def __getitem__(self, idx):
+        ffn = self.feature_fnames[idx]
+        features = np.load(os.path.join(self.features_dir, ffn))
+        if self.need_images:
+            ifn = self.image_fnames[idx]
+            ext = os.path.splitext(ifn)[1].lower()
+            if ext == ".npy":
+                image = np.load(os.path.join(self.images_dir, ifn))
+                image = image.reshape(-1, *image.shape[-2:])
+            else:
+                import PIL.Image
+                image = np.array(PIL.Image.open(os.path.join(self.images_dir, ifn)))
+                image = image.reshape(*image.shape[:2], -1).transpose(2, 0, 1)
+            image = torch.from_numpy(image)
+            stem = os.path.splitext(ifn)[0]
+        else:
+            image = torch.zeros(0, dtype=torch.uint8)
+            stem = self._stem(ffn)
+        if self.text_embeds_dir is not None:
+            text = torch.from_numpy(np.load(os.path.join(self.full_text_embeds_dir, stem + ".npy")))
+        else:
+            text = torch.zeros_like(torch.from_numpy(features))
+        out = (image, torch.from_numpy(features), torch.tensor(self.labels[idx]), text)
+        if self.z_dirs:
+            out = out + tuple(torch.from_numpy(np.load(os.path.join(d, stem + ".npy"))).float() for d in self.z_dirs)
+        return out
+
+
+class SyntheticLatents(Dataset):
+    """Random ImageNet-256-shaped items (SURVEY.md §8d synthetic inputs): for plumbing tests and throughput runs."""
+
+    def __init__(self, n, z_dims=(), z_types=(), num_classes=1000, seed=0, latent=32):
+        self.n, self.z_dims, self.z_types, self.nc, self.seed, self.latent = n, list(z_dims), list(z_types), num_classes, seed, latent
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
+        mean = torch.randn(4, self.latent, self.latent, generator=g) * 5.49
+        moments = torch.cat([mean, torch.full_like(mean, 0.5)], 0)
+        label = torch.randint(0, self.nc, (), generator=g)
+        T = (self.latent // 2) ** 2
+        zs = tuple(torch.randn(T, z, generator=g) if k == "i" else torch.randn(z, generator=g)
+                   for z, k in zip(self.z_dims, self.z_types))
+        return (torch.zeros(0, dtype=torch.uint8), moments, label, torch.zeros(0)) + zs

@@ -74,8 +74,9 @@ class SiT(nn.Module):
         self.projector_dim = projector_dim
         self.qk_norm = bool(block_kwargs.get("qk_norm", False))
         self.fused_attn = bool(block_kwargs.get("fused_attn", True))  # both settings run the same fused HIP kernel
-        if len(self.z_dims) != len(self.z_types):
-            raise ValueError("z_dims and z_types must have the same length")
+        if len(self.z_types) < len(self.z_dims):
+            raise ValueError("z_types must name the kind ('i' | 't') of every entry of z_dims")
+        self.z_types = self.z_types[:len(self.z_dims)]  # the reference zips projectors with z_types (sit.py:292)
         split = encoder_depth_text is not None and encoder_depth_text != encoder_depth
         if split and (self.z_types.count("i") != 1 or self.z_types.count("t") != 1):
             raise ValueError("encoder_depth_text != encoder_depth needs exactly one image ('i') and one text ('t') "

@@ -80,6 +80,8 @@ def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, 
         gemm(TN, EPI_F32, dy, x, N, K, Mtok, dw, N, K, K, dbias=dbias, accumulate=accumulate)
         return
     slab = N * K
+    if ws is None:
+        ws = torch.empty(split_k * (slab + N), dtype=torch.float32, device=dw.device if torch.is_tensor(dw) else "cuda")
     bslab = ws.data_ptr() + split_k * slab * 4
     gemm(TN, EPI_F32, dy, x, N, K, Mtok, ws, N, K, K, dbias=bslab if dbias is not None else None,
          accumulate=False, split_k=split_k, slab_stride=slab)
@@ -181,6 +183,10 @@ def final_layer_bwd_rows(dout, x, mean, rstd, shift, scale, ldmod, w, hbuf, dlin
 
 
 # ---------------- loss ----------------
+def sample_posterior(moments, eps, out, B, half, scale, bias):
+    _call("reed_sample_posterior", _p(moments), _p(eps), _p(out), B, half, float(scale), float(bias), _stream())
+
+
 def interpolant(x, noise, t, xt, target, B, per, path_type):
     _call("reed_interpolant", _p(x), _p(noise), _p(t), _p(xt), _p(target), B, per, path_type, _stream())
 

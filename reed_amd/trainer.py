@@ -1,0 +1,92 @@
+"""One optimisation step of image/train.py (:349 sample_posterior, :363-385 schedules, :387-412 loss combine,
+backward, clip, AdamW, EMA) on the HIP path, without per-step host synchronisation: every returned scalar is a
+device tensor; call .item() only when logging.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def repa_weight_decay(kind, global_step, repa_steps):
+    """train.py:364-371"""
+    if kind == "constant":
+        return 1.0
+    if kind == "linear":
+        return max(1.0 - global_step / repa_steps, 0.0)
+    if kind == "cosine":
+        return max((1.0 + np.cos(np.pi * global_step / repa_steps)) / 2, 0.0)
+    raise NotImplementedError(kind)
+
+
+def diffusion_loss_decay(kind, global_step, start_steps, warm_up_steps, max_train_steps):
+    """train.py:373-385 (the 'cosine' branch keeps the reference's operator precedence)."""
+    top = warm_up_steps + start_steps
+    if global_step < start_steps:
+        return 0.0
+    if start_steps <= global_step < top:
+        return (global_step - start_steps) / warm_up_steps
+    if kind == "constant":
+        return 1.0
+    if kind == "linear":
+        return 1.0 - (global_step - top) / (max_train_steps - top)
+    if kind == "cosine":
+        return (1.0 + np.cos(np.pi * (global_step - top) / max_train_steps - top)) / 2
+    raise NotImplementedError(kind)
+
+
+@torch.no_grad()
+def sample_posterior(moments, latents_scale=0.18215, latents_bias=0.0, noise=None):
+    """train.py:84-91 with scalar scale/bias (the reference uses the same value for all 4 channels)."""
+    ops.require_cuda(moments, "moments")
+    B, C2 = moments.shape[0], moments.shape[1]
+    moments = moments.contiguous().float()
+    half = moments.numel() // B // 2
+    if noise is None:
+        noise = torch.randn((B, C2 // 2) + tuple(moments.shape[2:]), device=moments.device)
+    out = torch.empty_like(noise)
+    ops.sample_posterior(moments, noise.contiguous(), out, B, half, latents_scale, latents_bias)
+    return out
+
+
+class TrainStep:
+    def __init__(self, model, loss_fn, optimizer, reducer=None, proj_coeff=0.5, repa_decay="constant",
+                 repa_steps=400000, start_diffusion_steps=0, diffusion_warm_up_steps=50000,
+                 diffusion_decay="constant", max_train_steps=400000, latents_scale=0.18215, latents_bias=0.0,
+                 grad_accum=1):
+        self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
+        self.proj_coeff = proj_coeff
+        self.sched = (repa_decay, repa_steps, start_diffusion_steps, diffusion_warm_up_steps, diffusion_decay,
+                      max_train_steps)
+        self.latents_scale, self.latents_bias = latents_scale, latents_bias
+        self.grad_accum = max(1, int(grad_accum))
+        self.global_step = 0
+        self._micro = 0
+
+    def __call__(self, x, labels, zs, moments=None, **inject):
+        """x: latents [b,4,32,32] (or pass moments=[b,8,32,32] to run sample_posterior). Returns device scalars."""
+        rd, rs, sd, wu, dd, mx = self.sched
+        w_repa = repa_weight_decay(rd, self.global_step, rs)
+        w_diff = diffusion_loss_decay(dd, self.global_step, sd, wu, mx)
+        if moments is not None:
+            x = sample_posterior(moments, self.latents_scale, self.latents_bias)
+        self._micro += 1
+        syncing = self._micro % self.grad_accum == 0
+        if self.reducer is not None:
+            self.reducer.enabled = syncing  # DDP no_sync on non-final micro-steps (accelerate accumulate())
+        out = self.loss_fn(self.model, x, dict(y=labels), zs=zs, **inject)
+        den = out["denoising_loss"].mean()
+        proj = out["proj_loss"]
+        proj_mean = proj.mean() if torch.is_tensor(proj) else torch.zeros((), device=x.device)
+        loss = den * w_diff + proj_mean * self.proj_coeff * w_repa
+        (loss / self.grad_accum).backward()
+        res = {"loss": loss.detach(), "denoising_loss": den.detach(), "proj_loss": proj_mean.detach(),
+               "img_proj_loss": out["img_proj_loss"], "text_proj_loss": out["text_proj_loss"]}
+        if syncing:
+            if self.reducer is not None:
+                self.reducer.sync()
+            self.opt.step()          # clip + AdamW + EMA + bf16 re-cast, fused
+            self.opt.zero_grad()
+            self.global_step += 1
+            res["grad_norm"] = self.opt.grad_norm
+        return res

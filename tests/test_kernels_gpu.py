@@ -1,0 +1,306 @@
+"""Kernel-level parity on the GPU: each HIP kernel against a plain PyTorch fp32 (fp64 for the samplers) restatement
+of the same op on the same inputs, plus bit-exact checks of the index bookkeeping against the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detfill
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 256, 1152), (3, 16, 128), (1, 64, 384), (2, 32, 1024)])
+def test_ln_modulate_fwd_bwd(dev, B, T, D):
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(D + T)
+    M = B * T
+    x = (torch.randn(M, D, generator=g) * 2 + 0.3).to(dev)
+    mod = (torch.randn(B, 3 * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    shift, scale = mod[:, :D], mod[:, D:2 * D]
+    h = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.ln_modulate_fwd(x, shift, scale, 3 * D, h, mean, rstd, M, D, T)
+    xr = x.clone().requires_grad_(True)
+    s1 = bfr(1 + scale.float()).repeat_interleave(T, 0).requires_grad_(True)
+    sh = shift.float().repeat_interleave(T, 0).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6) * s1 + sh
+    torch.testing.assert_close(h.float(), bfr(ref.detach()), atol=2e-2, rtol=1e-2)
+    torch.testing.assert_close(mean, x.mean(-1), atol=1e-5, rtol=1e-5)
+    # backward
+    dh = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+    ref.backward(dh.float())
+    dx = torch.full((M, D), 0.25, device=dev)
+    part = torch.empty(M // 16, 2, D, device=dev)
+    ops.ln_modulate_bwd(dh, x, mean, rstd, scale, 3 * D, dx, part, M, D, T)
+    torch.testing.assert_close(dx - 0.25, xr.grad, atol=2e-4, rtol=2e-3)
+    dmod = torch.zeros(B, 2 * D, dtype=torch.bfloat16, device=dev)
+    ops.reduce_mod_parts([(part.data_ptr(), 2 * D, 0), (part.data_ptr() + 4 * D, 2 * D, D)], dmod, 2 * D, B, D, T // 16)
+    torch.testing.assert_close(dmod[:, :D].float(), bfr(sh.grad.view(B, T, D).sum(1)), atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(dmod[:, D:].float(), bfr(s1.grad.view(B, T, D).sum(1)), atol=3e-2, rtol=2e-2)
+    # plain cast mode
+    ops.ln_modulate_fwd(x, None, None, 0, h, None, None, M, D, T)
+    assert torch.equal(h.float(), bfr(x))
+
+
+def test_gate_bwd(dev):
+    from reed_amd import ops
+    B, T, D = 2, 64, 384
+    M = B * T
+    g = torch.Generator().manual_seed(3)
+    dx = torch.randn(M, D, generator=g).to(dev)
+    y = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+    gate = torch.randn(B, D, generator=g).to(torch.bfloat16).to(dev)
+    dy = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+    part = torch.empty(M // 16, D, device=dev)
+    ops.gate_bwd(dx, y, gate, D, dy, part, M, D, T)
+    dg = bfr(dx)
+    assert torch.equal(dy.float(), bfr(dg * gate.float().repeat_interleave(T, 0)))
+    ref = bfr(dg * y.float()).view(B, T, D).sum(1)
+    torch.testing.assert_close(part.view(B, T // 16, D).sum(1), ref, atol=1e-3, rtol=1e-4)
+
+
+def test_patch_embed_and_final_layer_index_maps_bit_exact(dev):
+    """patchify order (c,pi,pj) on the way in, (pi,pj,c) on the way out, row-major tokens: exact vs the reference."""
+    from reed_amd import ops
+    gs = load("static")
+    B, C, HW, P, D = 1, 4, 32, 2, 128
+    T = 256
+    # one-hot conv weights: token feature k = input element k of the patch (values < 256 are exact in bf16)
+    w = torch.zeros(D, C * P * P)
+    for k in range(16):
+        w[k, k] = 1.0
+    pos = torch.zeros(T, D, device=dev)
+    flat = torch.arange(C * HW * HW)
+    for lo in range(0, 4096, 256):   # sweep the input in exact-in-bf16 slabs
+        x = torch.where((flat >= lo) & (flat < lo + 256), flat - lo + 1, torch.zeros_like(flat)).float().reshape(1, C, HW, HW)
+        tok = torch.empty(T, D, device=dev)
+        ops.patch_embed_fwd(x.to(dev), w.to(torch.bfloat16).to(dev), None, pos, tok, B, C, HW, P, D)
+        got = tok[:, :16].cpu()
+        src = torch.from_numpy(gs["patchify_idx"])          # [T,16] flat input index feeding (token,k)
+        exp = torch.where((src >= lo) & (src < lo + 256), src - lo + 1, torch.zeros_like(src)).float()
+        assert torch.equal(got, exp)
+    # patchify kernel (order 0) and unpatchify order through the final layer
+    xb = torch.empty(T, 16, dtype=torch.bfloat16, device=dev)
+    xs = (flat % 251).float().reshape(1, C, HW, HW)
+    ops.patchify_bf16(xs.to(dev), xb, B, C, HW, P, 0)
+    assert torch.equal(xb.float().cpu(), xs.flatten()[torch.from_numpy(gs["patchify_idx"])])
+    # final layer: zero modulation, W = one-hot rows -> out = unpatchify(bf16(LN(x))[:, :16])
+    xt = torch.randn(T, D, generator=torch.Generator().manual_seed(1)).to(dev)
+    mod = torch.zeros(1, 2 * D, dtype=torch.bfloat16, device=dev)
+    wf = torch.zeros(16, D)
+    for j in range(16):
+        wf[j, j] = 1.0
+    out = torch.empty(1, C, HW, HW, device=dev)
+    ops.final_layer_fwd(xt, mod, mod[:, D:], 2 * D, wf.to(torch.bfloat16).to(dev), None, out, None, None, 1, T, D, C, P)
+    hln = bfr(torch.nn.functional.layer_norm(xt, (D,), eps=1e-6))[:, :16].cpu()
+    un = torch.from_numpy(gs["unpatchify_idx"]).flatten()    # out.flat[i] = lin.flat[un[i]]
+    torch.testing.assert_close(out.cpu().flatten(), hln.flatten()[un], atol=2e-2, rtol=0)
+    idx_exact = (out.cpu().flatten() - hln.flatten()[un]).abs().max()
+    assert idx_exact < 2e-2
+
+
+def test_patch_embed_values_and_smallk_wgrad(dev):
+    from reed_amd import ops
+    B, C, HW, P, D = 3, 4, 16, 2, 384
+    T, K = 64, 16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, HW, HW, generator=g)
+    w = (torch.randn(D, C, P, P, generator=g) * 0.2).to(torch.bfloat16)
+    b = (torch.randn(D, generator=g) * 0.1).to(torch.bfloat16)
+    pos = torch.randn(T, D, generator=g)
+    tok = torch.empty(B * T, D, device=dev)
+    ops.patch_embed_fwd(x.to(dev), w.to(dev), b.to(dev), pos.to(dev), tok, B, C, HW, P, D)
+    ref = torch.nn.functional.conv2d(bfr(x), w.float(), b.float(), stride=P).flatten(2).transpose(1, 2)
+    ref = bfr(ref) + pos
+    torch.testing.assert_close(tok.cpu().view(B, T, D), ref, atol=2e-2, rtol=1e-2)
+    # wgrad: dW[d,k] = sum_m bf16(dtok)[m,d] * patch[m,k]
+    dtok = torch.randn(B * T, D, generator=g).to(dev)
+    xb = torch.empty(B * T, K, dtype=torch.bfloat16, device=dev)
+    ops.patchify_bf16(x.to(dev), xb, B, C, HW, P, 0)
+    ws = torch.empty(ops.smallk_ws_floats(D, K), device=dev)
+    dw, db = torch.zeros(D, K, device=dev), torch.zeros(D, device=dev)
+    ops.smallk_wgrad(dtok, True, xb, ws, dw, db, None, B * T, D, K, 0, False)
+    torch.testing.assert_close(dw, bfr(dtok).t() @ xb.float(), atol=2e-3, rtol=1e-3)
+    torch.testing.assert_close(db, bfr(dtok).sum(0), atol=2e-3, rtol=1e-3)
+    ops.smallk_wgrad(dtok, True, xb, ws, dw, db, None, B * T, D, K, 0, True)
+    torch.testing.assert_close(dw, 2 * (bfr(dtok).t() @ xb.float()), atol=4e-3, rtol=1e-3)
+
+
+def test_timestep_sinusoid_and_label_cond(dev):
+    from reed_amd import ops
+    gs = load("static")
+    t = torch.from_numpy(gs["sinus_t"]).to(dev)
+    out = torch.empty(len(t), 256, dtype=torch.bfloat16, device=dev)
+    ops.timestep_sinusoid(t, out, len(t))
+    ref = torch.from_numpy(gs["sinus"])
+    torch.testing.assert_close(out.float().cpu(), bfr(ref), atol=8e-3, rtol=0)   # one bf16 ulp at |x|<=1
+    # label embedding + conditioning (integer bookkeeping bit-exact)
+    B, D, NC = 6, 128, 10
+    g = torch.Generator().manual_seed(2)
+    table = torch.randn(NC + 1, D, generator=g).to(dev)
+    temb = torch.randn(B, D, generator=g).to(torch.bfloat16).to(dev)
+    labels = torch.tensor([0, 9, 3, 3, 7, 1], device=dev)
+    drop = torch.tensor([0, 1, 0, 0, 1, 0], dtype=torch.uint8, device=dev)
+    eff = torch.empty(B, dtype=torch.int64, device=dev)
+    c, sc = torch.empty(B, D, device=dev), torch.empty(B, D, dtype=torch.bfloat16, device=dev)
+    ops.label_cond(labels, drop, NC, table, temb, eff, c, sc, B, D)
+    assert eff.tolist() == [0, 10, 3, 3, 10, 1]
+    cref = temb.float() + table[eff]
+    assert torch.equal(c, cref)
+    torch.testing.assert_close(sc.float(), bfr(torch.nn.functional.silu(cref)), atol=1e-2, rtol=1e-2)
+    # backward: deterministic scatter-add with duplicate labels
+    ds = torch.randn(B, D, generator=g).to(dev)
+    dt = torch.empty(B, D, dtype=torch.bfloat16, device=dev)
+    dtab = torch.zeros(NC + 1, D, device=dev)
+    ops.label_cond_bwd(ds, c, eff, dt, dtab, B, D)
+    cr = cref.clone().requires_grad_(True)
+    torch.nn.functional.silu(cr).backward(bfr(ds))
+    torch.testing.assert_close(dt.float(), bfr(cr.grad), atol=1e-2, rtol=1e-2)
+    exp = torch.zeros_like(dtab).index_add_(0, eff, cr.grad)
+    torch.testing.assert_close(dtab, exp, atol=1e-5, rtol=1e-5)
+
+
+def test_loss_kernels(dev):
+    from reed_amd import ops
+    from reed_amd.loss import _Cosine, _MSE
+    g = torch.Generator().manual_seed(9)
+    B, per = 5, 4096
+    x, n = torch.randn(B, per, generator=g).to(dev), torch.randn(B, per, generator=g).to(dev)
+    t = torch.rand(B, generator=g).to(dev)
+    for pt in (0, 1):
+        xt, tg = torch.empty_like(x), torch.empty_like(x)
+        ops.interpolant(x, n, t, xt, tg, B, per, pt)
+        tt = t[:, None]
+        if pt == 0:
+            a, s, da, ds = 1 - tt, tt, -1.0, 1.0
+        else:
+            h = np.pi / 2
+            a, s, da, ds = torch.cos(tt * h), torch.sin(tt * h), -h * torch.sin(tt * h), h * torch.cos(tt * h)
+        torch.testing.assert_close(xt, a * x + s * n, atol=2e-6, rtol=1e-6)
+        torch.testing.assert_close(tg, da * x + ds * n, atol=2e-6, rtol=1e-6)
+    out = x.clone().requires_grad_(True)
+    l = _MSE.apply(out, n)
+    torch.testing.assert_close(l, ((x - n) ** 2).mean(1), atol=1e-5, rtol=1e-5)
+    w = torch.rand(B, generator=g).to(dev)
+    (l * w).sum().backward()
+    torch.testing.assert_close(out.grad, w[:, None] * 2 * (x - n) / per, atol=1e-7, rtol=1e-5)
+    # cosine alignment: 3-D (image tokens) and 2-D (pooled text)
+    for shape in ((B, 16, 256), (B, 512)):
+        zt = torch.randn(*shape, generator=g).to(torch.bfloat16).to(dev).requires_grad_(True)
+        z = torch.randn(*shape, generator=g).to(dev)
+        cur = _Cosine.apply(zt, z)
+        zr = zt.detach().float().requires_grad_(True)
+        a_, b_ = torch.nn.functional.normalize(zr, dim=-1), torch.nn.functional.normalize(z, dim=-1)
+        if len(shape) == 2:
+            a_, b_ = a_.unsqueeze(1), b_.unsqueeze(1)
+        ref = -(a_ * b_).sum(-1).mean(-1)
+        torch.testing.assert_close(cur, ref, atol=1e-5, rtol=1e-4)
+        (cur * w).sum().backward()
+        (ref * w).sum().backward()
+        torch.testing.assert_close(zt.grad.float(), bfr(zr.grad), atol=1e-4, rtol=2e-2)
+    # sample_posterior
+    mom = torch.randn(B, 8, 8, 8, generator=g).to(dev)
+    eps = torch.randn(B, 4, 8, 8, generator=g).to(dev)
+    o = torch.empty_like(eps)
+    ops.sample_posterior(mom, eps, o, B, 4 * 64, 0.18215, 0.0)
+    torch.testing.assert_close(o, (mom[:, :4] + mom[:, 4:] * eps) * 0.18215, atol=1e-6, rtol=1e-6)
+
+
+def test_fused_optimizer_vs_reference_toy(dev):
+    """clip_grad_norm_(1.0) + AdamW(wd=0.01) + EMA: golden from torch's own implementations (tools/gen_golden.py)."""
+    from reed_amd import ops
+    g = load("optim_toy")
+    shapes = [(5, 7), (11,), (3, 4, 2)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    offs = [0, 36, 48]          # 4-aligned segment offsets (35 -> 36, 11 -> 12)
+    n = 72
+    p = torch.zeros(n)
+    for i, s in enumerate(shapes):
+        p[offs[i]:offs[i] + sizes[i]] = detfill.normal(s, 70 + i).flatten()
+    p = p.to(dev)
+    ema, m, v = p.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    partial, nc = torch.empty(64, device=dev), torch.empty(2, device=dev)
+    for s in range(3):
+        gr = torch.zeros(n)
+        for i, sh in enumerate(shapes):
+            gr[offs[i]:offs[i] + sizes[i]] = (detfill.normal(sh, 80 + 10 * s + i) * (3.0 if s == 0 else 0.1)).flatten()
+        gr = gr.to(dev)
+        ops.grad_sqnorm(gr, n, partial, 64)
+        ops.clip_finalize(partial, 64, 1.0, nc)
+        np.testing.assert_allclose(float(nc[0]), g[f"gn{s}"], rtol=1e-6)
+        ops.adamw_ema(p, gr, m, v, ema, shadow, n, n, nc, 1e-2, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9 ** (s + 1),
+                      1 - 0.999 ** (s + 1), 0.99)
+        for i in range(3):
+            np.testing.assert_allclose(p[offs[i]:offs[i] + sizes[i]].cpu().numpy(), g[f"p{s}_{i}"].flatten(), rtol=2e-6, atol=5e-7)  # fp32 fma-contraction noise
+            np.testing.assert_allclose(ema[offs[i]:offs[i] + sizes[i]].cpu().numpy(), g[f"e{s}_{i}"].flatten(), rtol=2e-6, atol=5e-7)
+    assert torch.equal(shadow.float(), bfr(p))
+
+
+def test_sampler_kernels_bit_exact_fp64(dev):
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n = 3 * 4 * 8 * 8
+    x = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    mo = torch.randn(2 * n, generator=g).to(dev)
+    dprev = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    xin = torch.empty(2 * n, device=dev)
+    ops.sampler_input(x, xin, n, True)
+    assert torch.equal(xin[:n], x.float()) and torch.equal(xin[n:], x.float())
+    dt, s = -1.0 / 250, 1.7
+    dc, du = mo[:n].double(), mo[n:].double()
+    d = du + s * (dc - du)
+    out, dst = torch.empty_like(x), torch.empty_like(x)
+    ops.sampler_update(x, mo, None, dst, out, n, True, s, dt, 1.0, 0.0)
+    assert torch.equal(dst, d) and torch.equal(out, x + dt * d)
+    ops.sampler_update(x, mo, dprev, None, out, n, True, s, dt, 0.5, 0.5)
+    assert torch.equal(out, x + dt * (0.5 * dprev + 0.5 * d))
+    ops.sampler_update(x, mo, None, None, out, n, False, 1.0, dt, 1.0, 0.0)
+    assert torch.equal(out, x + dt * mo[:n].double())
+    # SDE step, linear path
+    eps = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
+    t = torch.tensor(0.6160, dtype=torch.float64)
+    dtt = torch.tensor(-0.0039, dtype=torch.float64)
+    ops.sde_update(x, mo, eps, out, n, True, s, float(t), float(dtt), 0, False)
+
+    def drift(v):
+        a, da, sg, dsg = 1 - t, -1.0, t, 1.0
+        r = a / da
+        var = sg ** 2 - r * dsg * sg
+        return v - 0.5 * (2 * t) * ((r * v - x.cpu()) / var)
+    dcc, duu = drift(mo[:n].double().cpu()), drift(mo[n:].double().cpu())
+    dd = duu + s * (dcc - duu)
+    ref = x.cpu() + dd * dtt + torch.sqrt(2 * t) * (eps.cpu() * torch.sqrt(torch.abs(dtt)))
+    torch.testing.assert_close(out.cpu(), ref, atol=1e-13, rtol=1e-13)
+
+
+def test_samplers_end_to_end_vs_reference(dev):
+    """Euler / Heun / Euler-Maruyama with (interval) CFG on a tiny SiT: HIP (bf16 model, fp64 state) vs the reference
+    (fp32 model, fp64 state). 6 steps; tolerance 3e-2 abs on latents of scale ~1 (bf16 model evaluations)."""
+    from reed_amd import samplers
+    from tests.test_model_gpu import build_hip_model
+    from tests.test_oracle_golden import tiny_cfg
+    g = load("samplers")
+    cfg = tiny_cfg(num_classes=1000)
+    m = build_hip_model(cfg, dev, 5).eval()
+    z = detfill.normal((3, 4, 8, 8), 41).to(dev)
+    y = torch.tensor([3, 500, 999], device=dev)
+    cfgs = {"euler": dict(heun=False, cfg_scale=1.0), "heun": dict(heun=True, cfg_scale=1.0),
+            "euler_cfg": dict(heun=False, cfg_scale=2.5), "heun_cfg": dict(heun=True, cfg_scale=1.5),
+            "heun_cfg_interval": dict(heun=True, cfg_scale=3.0, guidance_low=0.3, guidance_high=0.75)}
+    for name, c in cfgs.items():
+        out = samplers.euler_sampler(m, z, y, num_steps=6, prediction="v", **c)
+        assert out.dtype == torch.float64 and out.shape == z.shape
+        err = (out.cpu() - torch.from_numpy(g[name])).abs().max().item()
+        assert err < 3e-2, (name, err)
+    eps = [detfill.normal((3, 4, 8, 8), 600 + i).double() for i in range(8)]
+    for name, c in {"sde": dict(cfg_scale=1.0), "sde_cfg": dict(cfg_scale=2.0, guidance_high=0.9),
+                    "sde_cosine": dict(cfg_scale=1.0, path_type="cosine")}.items():
+        out = samplers.euler_maruyama_sampler(m, z, y, num_steps=6, noises=eps, **c)
+        err = (out.cpu() - torch.from_numpy(g[name])).abs().max().item()
+        assert err < 6e-2, (name, err)

@@ -150,8 +150,8 @@ def test_c1_s2_trajectory_vs_reference(dev):
 def test_c2_xl2_trajectory_vs_reference_bf16(dev):
     """C2: SiT-XL/2 + 1024-d (DINOv2-L-shaped) alignment, B=8, 5 optimiser steps on injected (x,t,eps,labels,zs).
     Golden = the reference under bf16 autocast (and fp32). Bar (BASELINE.json): per-step total loss within 1e-3 of
-    the same-precision reference where the reference's own bf16-vs-fp32 gap allows; we assert <= 2e-3 abs or the
-    reference's own bf16/fp32 gap x 1.5, whichever is larger, and report the deltas."""
+    the same-precision (bf16-autocast) reference; against the fp32 reference the bound is the reference's own
+    bf16-vs-fp32 gap (2.3e-3 at step 1)."""
     g = load("xl2_c2")
     kw = dict(z_dims=[1024], z_types=["i"], encoder_depth=8)
     m, ema, opt, lf = _hip_trainer("SiT-XL/2", kw, dev, ["dinov2"], [1.0])
@@ -163,7 +163,7 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
     print("REF bf16 :", [f"{v:.6f}" for v in g["bf16.loss"]])
     print("REF fp32 :", [f"{v:.6f}" for v in g["fp32.loss"]])
     print("|HIP-bf16|:", d_bf16, " |HIP-fp32|:", d_fp32, " ref bf16-fp32 gap:", ref_gap)
-    tol = np.maximum(2e-3, 1.5 * ref_gap)
-    assert (d_bf16 <= tol).all(), (d_bf16, tol)
+    assert (d_bf16 <= 1e-3).all(), d_bf16                       # BASELINE.json bar: within 1e-3 of the reference
+    assert (d_fp32 <= np.maximum(2e-3, 1.5 * ref_gap)).all(), (d_fp32, ref_gap)  # vs fp32: the reference's own bf16 gap
     np.testing.assert_allclose(rec["grad_norm"], g["bf16.grad_norm"], rtol=3e-2)
     np.testing.assert_allclose(rec["proj_loss"], g["bf16.proj_loss"], atol=2e-3)

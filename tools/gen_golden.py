@@ -411,7 +411,25 @@ def g_sched(ref_sit, ref_loss, ref_samplers):
     save("optim_toy", **out)
 
 
-ALL = {"static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
+def g_init(ref_sit, ref_loss, ref_samplers):
+    """Reference weight init (sit.py:217-254) for a fixed torch seed: probes of several tensors."""
+    out = {}
+    for tag, name, kw in (("s2", "SiT-S/2", dict(decoder_hidden_size=384, z_dims=[768], fused_attn=True, qk_norm=False)),
+                          ("tiny", "custom", tiny_kwargs(z_dims=[128, 256], z_types=["i", "t"]))):
+        torch.manual_seed(1234)
+        m = ref_sit.SiT_models[name](**kw) if name in ref_sit.SiT_models else ref_sit.SiT(**kw)
+        sd = m.state_dict()
+        out[f"{tag}.keys"] = np.array(sorted(sd.keys()))
+        out[f"{tag}.shapes"] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
+        for k in ("x_embedder.proj.weight", "t_embedder.mlp.0.weight", "t_embedder.mlp.2.weight",
+                  "y_embedder.embedding_table.weight", "blocks.0.attn.qkv.weight", "blocks.2.mlp.fc2.weight",
+                  "projectors.0.4.weight", "blocks.1.adaLN_modulation.1.weight", "final_layer.linear.weight"):
+            out[f"{tag}.{k}"] = sd[k].flatten()[:32].clone()
+            out[f"{tag}.sum.{k}"] = sd[k].double().sum()
+    save("init", **out)
+
+
+ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
        "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4}
 
 if __name__ == "__main__":
