@@ -42,6 +42,15 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
               int64_t ldr, const void* bias, const void* gate, int64_t ldgate, int rows_per_gate,
               float* dbias, int accumulate, int split_k, int64_t slab_stride, void* stream);
 
+/* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel */
+int reed_gemm_force_tile(int tile);
+
+/* bias gradient: out[n] (+)= sum_m x[m,n], x bf16 [M,N] (row stride ld); ws: caller scratch of
+ * reed_colsum_ws_floats(M, N) floats. Deterministic (fixed reduction order). */
+int64_t reed_colsum_ws_floats(int M, int N);
+int reed_colsum_bf16(const void* x, int64_t ld, float* ws, float* out, int M, int N, int accumulate,
+                     void* stream);
+
 /* sum split-K slabs: out[i] (+)= sum_z slabs[z*stride + i], i < n */
 int reed_reduce_slabs(const float* slabs, int64_t stride, int nslabs, float* out, int64_t n,
                       int accumulate, void* stream);

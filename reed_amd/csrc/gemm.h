@@ -34,6 +34,8 @@ struct GemmArgs {
   int accumulate;
   int ksplit_len;
   long slab_stride;
+  int xcd_gm, xcd_gn;  // >0: XCD-local split-K scheduling (gemm256.hip): co-resident blocks of one XCD = gm x gn tiles of one K slice
+  int xcd_splits;
 };
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);

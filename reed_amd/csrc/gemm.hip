@@ -18,22 +18,17 @@
 // v_mfma_f32_16x16x32_bf16.  The MFMA is issued "swapped" (Q fragment as A operand, P fragment
 // as B operand) so each lane ends up holding 4 consecutive n for one m: 8-B bf16 / 16-B fp32
 // epilogue accesses.  LDS is double buffered (64 KiB), one barrier per K step.
-#include "common.hpp"
-#include "gemm.h"
+#include "gemm_common.hpp"
+
+int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);
+bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits);
 
 namespace {
+using namespace gemm_detail;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 16384;          // one operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes) {
-  if (bytes < 0) bytes = 0;
-  if (bytes > 0xFFFFFFFFl) bytes = 0xFFFFFFFFl;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (unsigned)bytes, 0x00020000);
-}
-
-typedef void __attribute__((address_space(3))) * lds_ptr_t;
 
 // ---- staging ----------------------------------------------------------------
 // k-contiguous operand: tile rows [0,128) x k [k0,k0+64); rsrc is based at the tile's first row.
@@ -50,7 +45,6 @@ __device__ __forceinline__ void stage_row(__amdgpu_buffer_rsrc_t rs, char* tile,
   }
 }
 // k-strided operand: k rows [k0,k0+64) x cols [0,128); rsrc is based at column c0 of row 0.
-__device__ __forceinline__ int tr_sw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ void stage_tr(__amdgpu_buffer_rsrc_t rs, char* tile, long ld, int k0,
                                          int tid, int wave) {
 #pragma unroll
@@ -61,95 +55,6 @@ __device__ __forceinline__ void stage_tr(__amdgpu_buffer_rsrc_t rs, char* tile, 
     int voff = (int)(((long)(k0 + r) * ld + ch * 8) * 2);
     char* dst = tile + (i * 256 + wave * 64) * 16;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
-  }
-}
-
-// ---- fragment reads -----------------------------------------------------------
-// lane (i = lane&15, g = lane>>4) gets X[rowbase+i][ks*32 + 8g .. +7]
-__device__ __forceinline__ bf16x8 frag_row(const char* tile, int rowbase, int ks, int lane) {
-  int row = rowbase + (lane & 15);
-  int c = ks * 4 + (lane >> 4);
-  return *(const bf16x8*)(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-}
-// lane (i, g) gets X[k = ks*32 + 8g + j][colbase + i], j = 0..7 (two transposing reads)
-__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int colbase, int ks, int lane) {
-  int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
-  int row0 = ks * 32 + 8 * g + q, row1 = row0 + 4;
-  int ch = (colbase >> 3) + (p >> 1);
-  const char* a0 = tile + row0 * 256 + ((ch ^ tr_sw(row0)) << 4) + ((p & 1) << 3);
-  const char* a1 = tile + row1 * 256 + ((ch ^ tr_sw(row1)) << 4) + ((p & 1) << 3);
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// ---- epilogue -------------------------------------------------------------------
-template <int EPI>
-__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 acc, int m, int n, int z) {
-  if (m >= a.M) return;
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (a.bias) {
-    bf16x4 b = *(const bf16x4*)(a.bias + n);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] += bf2f(b[j]);
-  }
-  if constexpr (EPI == EPI_BF16) {
-    bf16x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-    *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
-  } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU) {
-    bf16x4 pre, act;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      pre[j] = f2bf(v[j]);
-      float x = bf2f(pre[j]);
-      act[j] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
-    }
-    if (a.C) *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = pre;
-    *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = act;
-  } else if constexpr (EPI == EPI_GATE_RES) {
-    // y = bf16(acc+bias); x_out = x_in + float(bf16(gate*y))   (sit.py:134-135 under bf16 autocast)
-    const bf16* gp = a.gate + (long)(m / a.rows_per_gate) * a.ldgate + n;
-    bf16x4 g = *(const bf16x4*)gp;
-    f32x4 xin = *(const f32x4*)((const float*)a.R + (long)m * a.ldr + n);
-    bf16x4 y;
-    f32x4 xo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      y[j] = f2bf(v[j]);
-      xo[j] = xin[j] + bfround(bf2f(g[j]) * bf2f(y[j]));
-    }
-    if (a.C2) *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = y;
-    *(f32x4*)((float*)a.C + (long)m * a.ldc + n) = xo;
-  } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DSILU) {
-    bf16x4 pre = *(const bf16x4*)((const bf16*)a.R + (long)m * a.ldr + n);
-    bf16x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float du = bfround(v[j]);
-      float x = bf2f(pre[j]);
-      o[j] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
-    }
-    *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
-  } else if constexpr (EPI == EPI_F32) {
-    float* cp = (float*)a.C + (long)z * a.slab_stride + (long)m * a.ldc + n;
-    f32x4 o = {v[0], v[1], v[2], v[3]};
-    if (a.accumulate) {
-      f32x4 old = *(const f32x4*)cp;
-      o += old;
-    }
-    *(f32x4*)cp = o;
-  } else if constexpr (EPI == EPI_ADDF32_RB) {
-    float* cp = (float*)a.C + (long)m * a.ldc + n;
-    f32x4 old = *(const f32x4*)cp;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) old[j] += bfround(v[j]);
-    *(f32x4*)cp = old;
-  } else if constexpr (EPI == EPI_ATOMIC_F32) {
-    float* cp = (float*)a.C + (long)m * a.ldc + n;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(cp + j, v[j]);
   }
 }
 
@@ -309,6 +214,9 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
+static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 = force (tests, A/B timing)
+extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
+
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
   REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   REED_CHECK_ARG(a.N % BN == 0, "reed_gemm: N=%d must be a multiple of %d", a.N, BN);
@@ -330,6 +238,9 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
     REED_CHECK_ARG(epi == EPI_ATOMIC_F32 || (epi == EPI_F32 && a.slab_stride > 0),
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
+  if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, a, splits)) &&
+      !(layout == LAY_TN && a.dbias))
+    return reed_gemm256_launch(layout, epi, a, splits, stream);
   switch (layout) {
     case LAY_NT: return dispatch_epi<LAY_NT>(epi, a, splits, stream);
     case LAY_NN: return dispatch_epi<LAY_NN>(epi, a, splits, stream);

@@ -1,0 +1,360 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950 — the large-problem kernel (same layouts, LDS tile formats and fused
+// epilogues as gemm.hip; see gemm_common.hpp).  8 waves (2 x 4), each 128x64 of the output = 8x4 MFMA tiles;
+// 128 KiB of LDS = 2 K-tile buffers x {A0, A1, B0, B1} half-tiles of 16 KiB (A_h feeds wave row h, B_h feeds wave
+// columns 2h, 2h+1).  Halving the global->LDS bytes per flop versus the 128^2 tile is half of the gain; the other
+// half is the pipeline: every half-tile is staged by LDS-DMA (buffer_load ... lds) 3-6 phases before its first
+// use and the loop never drains the vector-memory queue — one counted s_waitcnt vmcnt(4) per K-tile, raw
+// s_barrier — and the LDS fragment reads of the next phase are issued before this phase's 16 MFMAs.
+//
+// One K-tile = 4 phases; the wave's 128x64 output is cut into quadrants Q(mh, nh) of 64x32:
+//   phase   MFMA (regs)        LDS reads issued (for)          LDS-DMA issued (K-tile)
+//   p0      Q(0,0)  A0r,B0r    B-nh1(t)            (p1)        A1(t+1)
+//   p1      Q(0,1)  A0r,B1r    A-mh1(t)            (p2)        B0(t+2)
+//   p2      Q(1,1)  A1r,B1r    -                               B1(t+2)
+//   p3      Q(1,0)  A1r,B0r    A-mh0,B-nh0(t+1)    (next p0)   A0(t+2)      [vmcnt(4) + barrier first]
+// Each phase starts with s_waitcnt lgkmcnt(0) + s_barrier, which orders (WAR) the reads of a half-tile before the
+// DMA that overwrites it two K-tiles later, and (RAW, at p3) the landed K-tile t+1 before its first fragment read.
+#include "gemm_common.hpp"
+
+namespace {
+using namespace gemm_detail;
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int HT = 16384;        // half-tile bytes
+constexpr int LDS_BYTES = 8 * HT;
+// LDS map: slot(operand half, K-tile buffer) = [A0c0 A0c1 A1c0 A1c1 B0c0 B0c1 B1c0 B1c1]: the two K-tile buffers of a
+// half-tile are adjacent, so buffer select (cur*HT) and k-step (ks*8192) fit the 16-bit DS immediate offset.
+__device__ __forceinline__ constexpr int slotA(int h, int cur) { return (h * 2 + cur) * HT; }
+__device__ __forceinline__ constexpr int slotB(int h, int cur) { return (4 + h * 2 + cur) * HT; }
+
+__device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// stage one half-tile (16 KiB) with 512 threads: 2 x 16 B per thread.  The per-thread byte offsets (voff) are
+// loop invariant; everything that changes per K-tile / half goes through the scalar soffset.
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rs, char* ht, int voff0, int voff1, int soff,
+                                           int wave) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(ht + (wave * 64) * 16), 16, voff0, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(ht + (512 + wave * 64) * 16), 16, voff1, soff, 0, 0);
+}
+// per-thread offset of staging round i for a k-contiguous ("row") / k-strided ("tr") operand half-tile
+__device__ __forceinline__ int voff_row(int i, int tid, long ld) {
+  int L = i * 512 + tid, r = L >> 3, cp = L & 7;
+  return (int)(((long)r * ld + (cp ^ ((r >> 1) & 7)) * 8) * 2);
+}
+__device__ __forceinline__ int voff_tr(int i, int tid, long ld) {
+  int L = i * 512 + tid, r = L >> 4, chp = L & 15;
+  return (int)(((long)r * ld + (chp ^ tr_sw(r)) * 8) * 2);
+}
+
+#define BARRIER()                                          \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)
+
+template <int LAY, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
+  int tm, tn, z;
+  if (a.xcd_gm > 0) {
+    // XCD-local split-K scheduling (wgrad): workgroups are dealt round-robin to the 8 XCDs in launch order, so the
+    // blocks L, L+8, L+16, ... share one XCD and its L2.  A "unit" = (gm x gn rectangle of output tiles) x (one K
+    // slice); the U = gm*gn <= 32 blocks of a unit get consecutive slots on ONE XCD, i.e. they run together on its
+    // 32 CUs and every operand slab of the slice is fetched once per XCD and shared through its L2.  (Placement is
+    // a speed assumption only: any mapping is correct.)
+    const int U = a.xcd_gm * a.xcd_gn;
+    const int ngm = (ntm + a.xcd_gm - 1) / a.xcd_gm, ngn = (ntn + a.xcd_gn - 1) / a.xcd_gn;
+    const int nunits = ngm * ngn * a.xcd_splits;
+    const int L = blockIdx.x, xcd = L & 7, r = L >> 3;
+    const int u = (r / U) * 8 + xcd, within = r % U;
+    if (u >= nunits) return;
+    z = u / (ngm * ngn);
+    const int rem = u - z * (ngm * ngn);
+    tm = (rem / ngn) * a.xcd_gm + within / a.xcd_gn;
+    tn = (rem % ngn) * a.xcd_gn + within % a.xcd_gn;
+    if (tm >= ntm || tn >= ntn) return;
+  } else {
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+      int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * ntn;
+    const int group = bid / per_group, first_m = group * GM;
+    const int gs = min(ntm - first_m, GM);
+    tm = first_m + (bid % per_group) % gs;
+    tn = (bid % per_group) / gs;
+    z = blockIdx.y;
+  }
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int kbeg = z * a.ksplit_len;
+  const int kend = min(a.K, kbeg + a.ksplit_len);
+  const int nt = (kend - kbeg + BK2 - 1) / BK2;
+
+  __amdgpu_buffer_rsrc_t rsP, rsQ;
+  if constexpr (LAY == LAY_TN) rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
+  else rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
+  if constexpr (LAY == LAY_NT) rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
+  else rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
+
+  // loop-invariant per-thread staging offsets
+  const int vA0 = (LAY == LAY_TN) ? voff_tr(0, tid, a.ldp) : voff_row(0, tid, a.ldp);
+  const int vA1 = (LAY == LAY_TN) ? voff_tr(1, tid, a.ldp) : voff_row(1, tid, a.ldp);
+  const int vB0 = (LAY == LAY_NT) ? voff_row(0, tid, a.ldq) : voff_tr(0, tid, a.ldq);
+  const int vB1 = (LAY == LAY_NT) ? voff_row(1, tid, a.ldq) : voff_tr(1, tid, a.ldq);
+  // scalar byte offsets: per K-tile step and per half (128 rows of a row operand / 128 columns of a tr operand)
+  const int kstepA = (LAY == LAY_TN) ? (int)(BK2 * a.ldp * 2) : BK2 * 2;
+  const int kstepB = (LAY == LAY_NT) ? BK2 * 2 : (int)(BK2 * a.ldq * 2);
+  const int halfA = (LAY == LAY_TN) ? 128 * 2 : (int)(128 * a.ldp * 2);
+  const int halfB = (LAY == LAY_NT) ? (int)(128 * a.ldq * 2) : 128 * 2;
+  const int kbaseA = (LAY == LAY_TN) ? (int)((long)kbeg * a.ldp * 2) : kbeg * 2;
+  const int kbaseB = (LAY == LAY_NT) ? kbeg * 2 : (int)((long)kbeg * a.ldq * 2);
+  // half-tile h of operand A (P) / B (Q) of K-tile t into buffer CUR
+  auto issueA = [&](int t, int h, int cur) {
+    stage_half(rsP, smem + slotA(h, cur), vA0, vA1, kbaseA + t * kstepA + h * halfA, wave);
+  };
+  auto issueB = [&](int t, int h, int cur) {
+    stage_half(rsQ, smem + slotB(h, cur), vB0, vB1, kbaseB + t * kstepB + h * halfB, wave);
+  };
+  // ---- fragment addressing -------------------------------------------------------------------------------
+  // k-contiguous operand (frag_row): byte = row*128 + ((c ^ ((row>>1)&7))<<4), row = tile*16 + (lane&15), c = ks*4 + g:
+  //   lane base per ks (XOR of bit 2 of c), tile -> +2048 immediate.
+  // k-strided operand (transposing read, see gemm_common.hpp frag_tr): byte = row*256 + ((i' ^ xe)<<5) +
+  //   (((p>>1)^hh)<<4) + ((p&1)<<3), row = ks*32 + 8g + q + 4hh, xe = (q<<1)|(g&1), i' = 16-column tile index:
+  //   lane bases per hh (+ the tile-index high bit), a 4-entry lane table for the low two tile bits, ks -> +8192.
+  const int li = lane & 15, lg = lane >> 4, lq = li >> 2, lp = li & 3;
+  const int xe = (lq << 1) | (lg & 1);
+  const int xh = xe >> 2;
+  const int aoff = slotA(wr, 0), boff = slotB(wc >> 1, 0);
+  // Only ONE lane-dependent base per operand lives across the K loop; its siblings are derived inside the loop with
+  // XOR/add on bit fields that no other term of the address touches:
+  //   tr:  hh=1 base = (hh=0 base + 4 rows*256) ^ 16   (bit 4 = ((p>>1)^hh));  m-half 1 = base ^ 128 (bit 7 = mh^xh);
+  //        slot of tile-low-bits k = S0 ^ (k<<5)       (bits 5-6 = k ^ (xe&3))
+  //   row: ks=1 base = ks=0 base ^ 64                  (bit 6 = bit 2 of the chunk index ks*4+g, XOR-swizzled)
+  int S0 = (xe & 3) << 5;
+  int tA = aoff + (8 * lg + lq) * 256 + ((lp >> 1) << 4) + ((lp & 1) << 3) + (xh << 7);
+  int tB = boff + (8 * lg + lq) * 256 + ((lp >> 1) << 4) + ((lp & 1) << 3) + (((wc & 1) ^ xh) << 7);
+  const int rsw = (li >> 1) & 7;
+  int rA = aoff + li * 128 + ((lg ^ rsw) << 4);
+  int rB = boff + ((wc & 1) * 64 + li) * 128 + ((lg ^ rsw) << 4);
+
+  auto loadA = [&](int cur, int mh, bf16x8 (&f)[4][2]) {
+    if constexpr (LAY == LAY_TN) {
+      const int b0 = mh ? (tA ^ 128) : tA;
+      const int b1 = (b0 + 1024) ^ 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sl = S0 ^ (i << 5);
+        const char* p0 = smem + (b0 + sl);
+        const char* p1 = smem + (b1 + sl);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f[i][ks] = tr2(p0 + cur * HT + ks * 8192, p1 + cur * HT + ks * 8192);
+      }
+    } else {
+      const char* q0 = smem + rA;
+      const char* q1 = smem + (rA ^ 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f[i][0] = *(const bf16x8*)(q0 + cur * HT + (mh * 4 + i) * 2048);
+        f[i][1] = *(const bf16x8*)(q1 + cur * HT + (mh * 4 + i) * 2048);
+      }
+    }
+  };
+  auto loadB = [&](int cur, int nh, bf16x8 (&f)[2][2]) {
+    if constexpr (LAY == LAY_NT) {
+      const char* q0 = smem + rB;
+      const char* q1 = smem + (rB ^ 64);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f[j][0] = *(const bf16x8*)(q0 + cur * HT + (nh * 2 + j) * 2048);
+        f[j][1] = *(const bf16x8*)(q1 + cur * HT + (nh * 2 + j) * 2048);
+      }
+    } else {
+      const int b1 = (tB + 1024) ^ 16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int sl = S0 ^ ((nh * 2 + j) << 5);
+        const char* p0 = smem + (tB + sl);
+        const char* p1 = smem + (b1 + sl);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f[j][ks] = tr2(p0 + cur * HT + ks * 8192, p1 + cur * HT + ks * 8192);
+      }
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define MMA(MH, NH, AF, BF)                                                                       \
+  do {                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+      acc[(MH) * 4 + i][(NH) * 2 + j] =                                                           \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], AF[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                \
+  } while (0)
+
+  // One K-tile; BX holds B-nh0(t) on entry, BY receives B-nh1(t); on exit BY holds B-nh0(t+1) (roles swap).
+#define KTILE(T, CUR, BX, BY)                                                       \
+  do {                                                                          \
+    const int t_ = (T);                                                         \
+    asm volatile("" : "+v"(S0), "+v"(tA), "+v"(tB), "+v"(rA), "+v"(rB));        \
+    /* p0 */                                                                    \
+    BARRIER();                                                                  \
+    if (t_ + 1 < nt) issueA(t_ + 1, 1, 1 - (CUR));                                      \
+    loadB((CUR), 1, BY);                                                        \
+    MMA(0, 0, A0r, BX);                                                         \
+    /* p1 */                                                                    \
+    BARRIER();                                                                  \
+    if (t_ + 2 < nt) issueB(t_ + 2, 0, (CUR));                                      \
+    loadA((CUR), 1, A1r);                                                       \
+    MMA(0, 1, A0r, BY);                                                         \
+    /* p2 */                                                                    \
+    BARRIER();                                                                  \
+    if (t_ + 2 < nt) issueB(t_ + 2, 1, (CUR));                                      \
+    MMA(1, 1, A1r, BY);                                                         \
+    /* p3: K-tile t+1 must have landed before its first fragment read */        \
+    if (t_ + 1 < nt) {                                                          \
+      if (t_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+    }                                                                           \
+    BARRIER();                                                                  \
+    if (t_ + 2 < nt) issueA(t_ + 2, 0, (CUR));                                      \
+    if (t_ + 1 < nt) {                                                          \
+      loadA(1 - (CUR), 0, A0r); /* A0r is dead since p1 */                      \
+      loadB(1 - (CUR), 0, BY);  /* BY (B-nh1) dead since p2 */                 \
+    }                                                                           \
+    MMA(1, 0, A1r, BX);                                                         \
+  } while (0)
+
+  bf16x8 A0r[4][2], A1r[4][2], Bp[2][2], Bq[2][2];
+  if (nt > 0) {
+    // prologue: K-tile 0 complete, K-tile 1 minus its A1 half in flight
+    issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 0, 0); issueA(0, 1, 0);
+    if (nt > 1) {
+      issueB(1, 0, 1); issueB(1, 1, 1); issueA(1, 0, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BARRIER();
+    loadA(0, 0, A0r);
+    loadB(0, 0, Bp);
+  }
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    KTILE(t, 0, Bp, Bq);
+    KTILE(t + 1, 1, Bq, Bp);
+  }
+  if (t < nt) KTILE(t, 0, Bp, Bq);
+
+  // ---- epilogue: lane holds C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] of each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
+      epilogue<EPI>(a, acc[i][j], m, n, z);
+    }
+  }
+}
+
+template <int LAY, int EPI>
+int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<LAY, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) { reed_set_error("gemm256: cannot reserve 128 KiB LDS: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM2) * cdiv(a.N, BN2), splits, 1);
+  if (a.xcd_gm > 0) {
+    const int ngm = cdiv(cdiv(a.M, BM2), a.xcd_gm), ngn = cdiv(cdiv(a.N, BN2), a.xcd_gn);
+    const int nunits = ngm * ngn * a.xcd_splits;
+    grid = dim3(cdiv(nunits, 8) * 8 * a.xcd_gm * a.xcd_gn, 1, 1);
+  }
+  REED_KLAUNCH((gemm256_kernel<LAY, EPI>), grid, dim3(512), LDS_BYTES, stream, a);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+template <int LAY>
+int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
+  switch (epi) {
+    case EPI_BF16: return launch256<LAY, EPI_BF16>(a, splits, s);
+    case EPI_GELU: return launch256<LAY, EPI_GELU>(a, splits, s);
+    case EPI_SILU: return launch256<LAY, EPI_SILU>(a, splits, s);
+    case EPI_GATE_RES: return launch256<LAY, EPI_GATE_RES>(a, splits, s);
+    case EPI_DGELU: return launch256<LAY, EPI_DGELU>(a, splits, s);
+    case EPI_DSILU: return launch256<LAY, EPI_DSILU>(a, splits, s);
+    case EPI_F32: return launch256<LAY, EPI_F32>(a, splits, s);
+    case EPI_ADDF32_RB: return launch256<LAY, EPI_ADDF32_RB>(a, splits, s);
+    case EPI_ATOMIC_F32: return launch256<LAY, EPI_ATOMIC_F32>(a, splits, s);
+  }
+  reed_set_error("reed_gemm: unknown epilogue %d", epi);
+  return REED_ERR_ARG;
+}
+
+}  // namespace
+
+// Kernel selection, from A/B timing on MI355X at the SiT-XL/2 shapes (tools/bench_gemm.py):
+//   NT (forward):  256^2 wins 15-20 % once the grid fills the chip and N or K is large (qkv, fc1, fc2); the square
+//                  1152x1152 projection is ~6 % better on the 128^2 kernel (4.5 column tiles, short K).
+//   NN (dgrad):    a wash (+-4 %): stays on the 128^2 kernel (2 blocks/CU absorb the ragged tail better).
+//   TN (wgrad):    256^2 only together with XCD-local split-K (the planner passes splits > 1) and without the
+//                  fused bias gradient, which needs the 128^2 kernel's spare accumulators.
+bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
+  long tiles = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2);
+  if (layout == LAY_NT) return tiles >= 224 && a.K >= 256 && (a.N >= 2048 || a.K >= 2048);
+  if (layout == LAY_TN) return splits > 1 && !a.dbias && a.K >= 16384;
+  return false;
+}
+
+int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
+  a.xcd_gm = a.xcd_gn = 0;
+  a.xcd_splits = splits;
+  if (layout == LAY_TN && splits > 1) {
+    // pick the gm x gn rectangle (<= 32 tiles = one block per CU of an XCD) with the best operand reuse
+    const int ntm = cdiv(a.M, BM2), ntn = cdiv(a.N, BN2);
+    int best_gm = 1, best_gn = 1;
+    double best = 0;
+    for (int gm = 1; gm <= ntm && gm <= 32; ++gm) {
+      int gn = 32 / gm;
+      if (gn > ntn) gn = ntn;
+      if (gn < 1) continue;
+      // occupancy-weighted reuse: useful tiles per unit slot x flop per byte
+      const int ngm = cdiv(ntm, gm), ngn = cdiv(ntn, gn);
+      double fill = (double)(ntm * ntn) / ((double)ngm * ngn * gm * gn);
+      double score = fill * (double)(gm * gn) / (gm + gn) * ((gm * gn) / 32.0);
+      if (score > best) { best = score; best_gm = gm; best_gn = gn; }
+    }
+    a.xcd_gm = best_gm;
+    a.xcd_gn = best_gn;
+  }
+  switch (layout) {
+    case LAY_NT: return dispatch256<LAY_NT>(epi, a, splits, stream);
+    case LAY_NN: return dispatch256<LAY_NN>(epi, a, splits, stream);
+    case LAY_TN: return dispatch256<LAY_TN>(epi, a, splits, stream);
+  }
+  reed_set_error("reed_gemm: unknown layout %d", layout);
+  return REED_ERR_ARG;
+}

@@ -237,6 +237,46 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+// column sums of a bf16 [M,N] matrix (bias gradients): stage 1 = partial per 64-row slice (8 independent 8-byte loads
+// in flight per thread), stage 2 = ordered reduce of the slices (deterministic)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ x, long ld, float* __restrict__ part,
+                                                             int M, int N) {
+  const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * 64;
+  f32x4 s = {0, 0, 0, 0};
+  const bf16* base = x + (long)r0 * ld + col;
+  if (r0 + 64 <= M) {  // whole slice in range: unconditional loads, 8 in flight (a per-load bounds select would
+                       // make hipcc branch + vmcnt(0) around every load: cdna_hip_programming.md trap (c))
+#pragma unroll 1
+    for (int rr = 0; rr < 64; rr += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ld_bf4(base + (long)(rr + k) * ld);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+  } else {
+    for (int r = r0; r < M; ++r) s += ld_bf4(x + (long)r * ld + col);
+  }
+  *(f32x4*)(part + (long)blockIdx.y * N + col) = s;
+}
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nsl, float* __restrict__ out,
+                                                            int N, int accumulate) {
+  // one wave per 64 columns would under-fill; instead 4 lanes-groups over slices then a fixed-order tree
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < N)
+    for (int z = grp; z < nsl; z += 4) s += part[(long)z * N + col];
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && col < N) {
+    float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[col] = accumulate ? out[col] + t : t;
+  }
+}
+
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride, int ns,
                                                            float* __restrict__ out, long n, int accumulate) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -316,6 +356,19 @@ extern "C" int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stre
   int blocks = (int)(n4 / 256 + 1);
   if (blocks > 4096) blocks = 4096;
   REED_KLAUNCH(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n4, (long)n);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int64_t reed_colsum_ws_floats(int M, int N) { return (int64_t)cdiv(M, 64) * N; }
+
+extern "C" int reed_colsum_bf16(const void* x, int64_t ld, float* ws, float* out, int M, int N, int accumulate,
+                                void* stream) {
+  REED_CHECK_ARG(x && ws && out && M > 0 && N > 0 && N % 4 == 0, "colsum_bf16: bad args");
+  const int nsl = cdiv(M, 64);
+  REED_KLAUNCH(colsum_partial_kernel, dim3(cdiv(N, 1024), nsl), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+               (long)ld, ws, M, N);
+  REED_KLAUNCH(colsum_reduce_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, ws, nsl, out, N, accumulate);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -204,14 +204,21 @@ class Engine:
 
     # ---- backward ------------------------------------------------------------------
     def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev):
-        tiles = (N // 128) * (K // 128)
-        split = 1
-        if tiles < 160 and Mtok >= 2048:
-            split = max(1, min(8, 256 // tiles, Mtok // 512))
-        ws = self.ws(split * (N * K + N), dev) if split > 1 else None
+        """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena. Large problems take the 256^2 TN kernel
+        (split-K through slabs, deterministic) with the bias gradient as a separate column-sum; small ones the
+        128^2 kernel with the bias gradient fused as an extra ones-MFMA."""
         bname = wname.replace("weight", "bias")
-        ops.linear_wgrad(dy, x, self.G(wname), dbias=self.G(bname), accumulate=acc, split_k=split, Mtok=Mtok, N=N, K=K,
-                         ws=ws)
+        big, split = ops.plan_wgrad(Mtok, N, K)
+        if big:
+            cw = ops.colsum_ws_floats(Mtok, N)
+            ws = self.ws(cw + split * N * K, dev)
+            ops.colsum_bf16(dy, N, ws, self.G(bname), Mtok, N, acc)
+            ops.linear_wgrad(dy, x, self.G(wname), dbias=None, accumulate=acc, split_k=split, Mtok=Mtok, N=N, K=K,
+                             ws=ws.data_ptr() + 4 * cw if split > 1 else None)
+        else:
+            ws = self.ws(split * (N * K + N), dev) if split > 1 else None
+            ops.linear_wgrad(dy, x, self.G(wname), dbias=self.G(bname), accumulate=acc, split_k=split, Mtok=Mtok, N=N,
+                             K=K, ws=ws)
 
     def backward(self, tp, dout, dzs):
         m, L = self.m, self.L

@@ -82,16 +82,44 @@ def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, 
     slab = N * K
     if ws is None:
         ws = torch.empty(split_k * (slab + N), dtype=torch.float32, device=dw.device if torch.is_tensor(dw) else "cuda")
-    bslab = ws.data_ptr() + split_k * slab * 4
-    gemm(TN, EPI_F32, dy, x, N, K, Mtok, ws, N, K, K, dbias=bslab if dbias is not None else None,
+    wsp = ws if isinstance(ws, int) else ws.data_ptr()
+    bslab = wsp + split_k * slab * 4
+    gemm(TN, EPI_F32, dy, x, N, K, Mtok, wsp, N, K, K, dbias=bslab if dbias is not None else None,
          accumulate=False, split_k=split_k, slab_stride=slab)
     # the launcher may round the split count down; it reports nothing back, so recompute it the same way
     ksteps = (Mtok + 63) // 64
     per = (ksteps + split_k - 1) // split_k
     eff = (ksteps + per - 1) // per
-    reduce_slabs(ws, slab, eff, dw, slab, accumulate)
+    reduce_slabs(wsp, slab, eff, dw, slab, accumulate)
     if dbias is not None:
         reduce_slabs(bslab, N, eff, dbias, N, accumulate)
+
+
+def colsum_ws_floats(M, N):
+    return ((M + 63) // 64) * N
+
+
+def colsum_bf16(x, ld, ws, out, M, N, accumulate=False):
+    _call("reed_colsum_bf16", _p(x), ld, _p(ws), _p(out), M, N, int(accumulate), _stream())
+
+
+def gemm_force_tile(tile):
+    """0 = heuristic, 128 / 256 = force that GEMM kernel (tests and A/B timing)."""
+    _lib.load().reed_gemm_force_tile(int(tile))
+
+
+def plan_wgrad(Mtok, N, K):
+    """(use_256_tile, split_k) for dw[N,K] = dy[Mtok,N]^T x[Mtok,K]: fill the 256 CUs, keep >= 32 K-tiles per split."""
+    t256 = ((N + 255) // 256) * ((K + 255) // 256)
+    ktiles = (Mtok + 63) // 64
+    if ktiles >= 512 and N % 128 == 0 and K % 128 == 0:
+        # XCD-local split-K (gemm256.hip): one K slice per XCD round; 8 slices x (tile rectangles of <= 32 blocks)
+        return True, 8
+    t128 = (N // 128) * (K // 128)
+    split = 1
+    if t128 < 160 and Mtok >= 2048:
+        split = max(1, min(8, 256 // t128, Mtok // 512))
+    return False, split
 
 
 def reduce_slabs(slabs, stride, n, out, count, accumulate=False):

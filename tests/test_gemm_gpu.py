@@ -6,6 +6,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 128, 256], autouse=True)
+def force_tile(request):
+    """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined)."""
+    from reed_amd import ops
+    ops.gemm_force_tile(request.param)
+    yield request.param
+    ops.gemm_force_tile(0)
+
+
 def _bf(x):
     return x.to(torch.bfloat16)
 
@@ -14,7 +23,8 @@ def _gelu(x):
     return torch.nn.functional.gelu(x, approximate="tanh")
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 384, 1152), (200, 256, 128), (8, 128, 256), (1024, 1152, 4608)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (512, 384, 1152), (200, 256, 128), (8, 128, 256), (1024, 1152, 4608),
+                                   (700, 640, 192), (2048, 1152, 1152)])
 def test_nt_bias(dev, M, N, K):
     from reed_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
@@ -70,7 +80,7 @@ def test_epilogues(dev):
     torch.testing.assert_close(xout, ref, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 1152, 384), (8, 256, 1152)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (300, 1152, 384), (8, 256, 1152), (1000, 4608, 1152), (513, 640, 384)])
 def test_nn_dgrad(dev, M, N, K):
     """dx[M,K] = dy[M,N] @ w[N,K]"""
     from reed_amd import ops
@@ -101,10 +111,23 @@ def test_nn_asymmetric(dev):
     assert torch.equal(dx.float(), w.float())
 
 
-@pytest.mark.parametrize("Mtok,N,K,split", [(256, 128, 128, 1), (1000, 384, 256, 1), (8, 128, 128, 1), (2048, 256, 128, 4)])
-def test_tn_wgrad(dev, Mtok, N, K, split):
+@pytest.mark.parametrize("Mtok,N,K,split", [(256, 128, 128, 1), (1000, 384, 256, 1), (8, 128, 128, 1), (2048, 256, 128, 4),
+                                            (4100, 1152, 640, 1), (8192, 384, 1152, 3)])
+def test_tn_wgrad(dev, Mtok, N, K, split, force_tile):
     """dw[N,K] = dy[Mtok,N]^T @ x[Mtok,K]; dbias = colsum(dy)"""
     from reed_amd import ops
+    if force_tile == 256:   # the 256^2 TN kernel has no fused bias gradient: check dw there, dbias via colsum
+        g = torch.Generator().manual_seed(11)
+        dy = _bf(torch.randn(Mtok, N, generator=g)).to(dev)
+        x = _bf(torch.randn(Mtok, K, generator=g)).to(dev)
+        dw = torch.full((N, K), float("nan"), device=dev)
+        ops.linear_wgrad(dy, x, dw, split_k=split)
+        torch.testing.assert_close(dw, dy.float().t() @ x.float(), atol=1e-2, rtol=1e-3)
+        ws = torch.empty(ops.colsum_ws_floats(Mtok, N), device=dev)
+        db = torch.zeros(N, device=dev)
+        ops.colsum_bf16(dy, N, ws, db, Mtok, N)
+        torch.testing.assert_close(db, dy.float().sum(0), atol=1e-2, rtol=1e-3)
+        return
     g = torch.Generator().manual_seed(11)
     dy = _bf(torch.randn(Mtok, N, generator=g)).to(dev)
     x = _bf(torch.randn(Mtok, K, generator=g)).to(dev)
