@@ -164,7 +164,7 @@ def main():
     ema = copy.deepcopy(model).requires_grad_(False).eval()
     opt = FusedAdamWEMA(model, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
     reducer = None
-    if world > 1:
+    if world > 1 or os.environ.get("REED_FORCE_REDUCER", "0") == "1":
         reducer = GradReducer(model, rank, world)
         reducer.broadcast_params(0)
     loss_fn = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
@@ -230,9 +230,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    if reducer is not None:
+        reducer.close()
     if world > 1:
-        if reducer is not None:
-            reducer.close()
         dist.destroy_process_group()
 
 

@@ -44,6 +44,8 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
 
 /* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel */
 int reed_gemm_force_tile(int tile);
+/* L2 prefetch distance of the 256^2 kernel in K-tiles: -1 = default policy, 0 = off, n = n K-tiles ahead (A/B timing) */
+int reed_gemm_set_prefetch(int dist);
 
 /* bias gradient: out[n] (+)= sum_m x[m,n], x bf16 [M,N] (row stride ld); ws: caller scratch of
  * reed_colsum_ws_floats(M, N) floats. Deterministic (fixed reduction order). */
@@ -70,9 +72,12 @@ int reed_ln_modulate_bwd(const void* dh, const float* x, const float* mean, cons
                          const void* scale, int64_t ldmod, float* dx, float* part, int M, int D,
                          int T, void* stream);
 
-/* gate backward (sit.py:134-135): dg = bf16(dx); dy = bf16(dg*gate[b]); part[(m/16),:] = sum bf16(dg*y) */
+/* gate backward (sit.py:134-135): dg = bf16(dx); dy = bf16(dg*gate[b]); part[(m/16),:] = sum bf16(dg*y);
+ * optional part_dy[(m/16),:] = sum dy  (bias gradient of the linear that produced y, reduce with reed_rowsum_f32) */
 int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,
-                  float* part, int M, int D, int T, void* stream);
+                  float* part, float* part_dy, int M, int D, int T, void* stream);
+/* out[n] (+)= sum_r part[r, n], f32 [R, N], fixed order */
+int reed_rowsum_f32(const float* part, int R, float* out, int N, int accumulate, void* stream);
 
 /* reduce per-chunk partials to bf16 modulation grads:
  *   dmod[b, col0 + j*D + d] = bf16( sum_{c<T/16} part_j[(b*T/16 + c)*stride_j + d] ) for the listed parts */

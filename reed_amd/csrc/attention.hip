@@ -36,12 +36,31 @@ struct Cfg {
 template <int HD>
 __device__ __forceinline__ void load_tile(char* lds, const bf16* src, long row_stride, int rows_valid,
                                           int tid, int nthreads) {
+  // 256 rows x NCH 16-byte chunks. All loads are issued unconditionally on a clamped row (a per-load bounds branch
+  // would serialise them: cdna_hip_programming.md trap (c)); rows >= rows_valid are zeroed by a select afterwards.
   constexpr int NCH = Cfg<HD>::NCH;
-  for (int idx = tid; idx < 256 * NCH; idx += nthreads) {
+  constexpr int PER = (256 * NCH + 511) / 512;  // chunks per thread at 512 threads
+  uint4 v[PER];
+  const int last = rows_valid - 1;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int idx = tid + k * 512;
     int row = idx / NCH, c = idx - row * NCH;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < rows_valid) v = *(const uint4*)(src + (long)row * row_stride + c * 8);
-    *(uint4*)(lds + row * ROWB + c * 16) = v;
+    int rc = min(row, last);
+    if (rc < 0) rc = 0;
+    int cc = idx < 256 * NCH ? c : 0;
+    v[k] = *(const uint4*)(src + (long)rc * row_stride + cc * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int idx = tid + k * 512;
+    int row = idx / NCH, c = idx - row * NCH;
+    if (idx < 256 * NCH) {
+      const unsigned msk = row < rows_valid ? 0xFFFFFFFFu : 0u;  // component-wise mask (a select of two uint4
+      uint4 w = v[k];                                            // aggregates is lowered through scratch memory)
+      w.x &= msk; w.y &= msk; w.z &= msk; w.w &= msk;
+      *(uint4*)(lds + row * ROWB + c * 16) = w;
+    }
   }
 }
 
@@ -88,7 +107,7 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 // ------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, int B, int T, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT;
@@ -107,12 +126,6 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   const float sc2 = rsqrtf((float)HD) * LOG2E;
 
   bf16x8 qf[2][KS];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    int row = q0 + 16 * qt + i;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = load_frag_global<HD>(base + (long)row * tok, row < T, ks, lane);
-  }
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   f32x4 ot[2][DT];
 #pragma unroll
@@ -125,6 +138,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
     const int rows = min(256, T - kv0);
     load_tile<HD>(Kt, base + (long)kv0 * tok + D, tok, rows, tid, 512);
     load_tile<HD>(Vt, base + (long)kv0 * tok + 2 * D, tok, rows, tid, 512);
+    if (kv0 == 0) {  // Q fragments after the first tile loads: keeps the staging registers and Q from overlapping
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        int row = q0 + 16 * qt + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = load_frag_global<HD>(base + (long)row * tok, row < T, ks, lane);
+      }
+    }
     __syncthreads();
     if (!active) continue;
     const int nsub = (rows + 63) >> 6;

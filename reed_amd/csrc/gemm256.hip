@@ -21,7 +21,7 @@ using namespace gemm_detail;
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int HT = 16384;        // half-tile bytes
-constexpr int LDS_BYTES = 8 * HT;
+constexpr int LDS_BYTES = 8 * HT + 2048;  // + 2 KiB scratch: landing zone of the L2-prefetch DMA (never read)
 // LDS map: slot(operand half, K-tile buffer) = [A0c0 A0c1 A1c0 A1c1 B0c0 B0c1 B1c0 B1c1]: the two K-tile buffers of a
 // half-tile are adjacent, so buffer select (cur*HT) and k-step (ks*8192) fit the 16-bit DS immediate offset.
 __device__ __forceinline__ constexpr int slotA(int h, int cur) { return (h * 2 + cur) * HT; }
@@ -121,6 +121,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   const int halfB = (LAY == LAY_NT) ? (int)(128 * a.ldq * 2) : 128 * 2;
   const int kbaseA = (LAY == LAY_TN) ? (int)((long)kbeg * a.ldp * 2) : kbeg * 2;
   const int kbaseB = (LAY == LAY_NT) ? kbeg * 2 : (int)((long)kbeg * a.ldq * 2);
+  // L2 prefetch (streaming operands, wgrad): every thread touches ONE 128-byte line of K-tile t+pf_dist through a
+  // 4-byte LDS-DMA into a scratch area (no VGPR destination; it is just another in-order entry of the vmcnt queue).
+  // Waves 0-3 cover operand A's 256x64 K-tile, waves 4-7 operand B's: 256 lines each.
+  const int pf = a.pf_dist;
+  int vPF;
+  {
+    const int idx = tid & 255;
+    const bool opA = wr == 0;
+    const bool tr = opA ? (LAY == LAY_TN) : (LAY != LAY_NT);
+    const long ld = opA ? a.ldp : a.ldq;
+    vPF = tr ? (int)(((long)(idx >> 2) * ld + (idx & 3) * 64) * 2) : (int)((long)idx * ld * 2);
+  }
+  auto prefetch = [&](int t) {
+    char* dst = smem + 8 * HT + wave * 256;
+    if (wr == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)dst, 4, vPF, kbaseA + t * kstepA, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)dst, 4, vPF, kbaseB + t * kstepB, 0, 0);
+  };
   // half-tile h of operand A (P) / B (Q) of K-tile t into buffer CUR
   auto issueA = [&](int t, int h, int cur) {
     stage_half(rsP, smem + slotA(h, cur), vA0, vA1, kbaseA + t * kstepA + h * halfA, wave);
@@ -229,10 +246,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     /* p2 */                                                                    \
     BARRIER();                                                                  \
     if (t_ + 2 < nt) issueB(t_ + 2, 1, (CUR));                                      \
+    const bool pf_ = pf > 0 && t_ + pf < nt;                                    \
+    if (pf_) prefetch(t_ + pf);                                                 \
     MMA(1, 1, A1r, BY);                                                         \
     /* p3: K-tile t+1 must have landed before its first fragment read */        \
     if (t_ + 1 < nt) {                                                          \
-      if (t_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
+      if (pf_) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                 \
+      else if (t_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
     }                                                                           \
     BARRIER();                                                                  \
@@ -316,6 +336,9 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
+static int g_pf_override = -1;
+extern "C" int reed_gemm_set_prefetch(int dist) { g_pf_override = dist; return 0; }
+
 // Kernel selection, from A/B timing on MI355X at the SiT-XL/2 shapes (tools/bench_gemm.py):
 //   NT (forward):  256^2 wins 15-20 % once the grid fills the chip and N or K is large (qkv, fc1, fc2); the square
 //                  1152x1152 projection is ~6 % better on the 128^2 kernel (4.5 column tiles, short K).
@@ -332,6 +355,9 @@ bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
   a.xcd_gm = a.xcd_gn = 0;
   a.xcd_splits = splits;
+  a.pf_dist = 0;
+  if (g_pf_override >= 0) a.pf_dist = g_pf_override;
+  else if (layout == LAY_TN && splits > 1) a.pf_dist = 4;  // tools/pf_sweep.py: 3-5 K-tiles ahead = +5-10 %, <=2 too late, >=6 evicted
   if (layout == LAY_TN && splits > 1) {
     // pick the gm x gn rectangle (<= 32 tiles = one block per CU of an XCD) with the best operand reuse
     const int ntm = cdiv(a.M, BM2), ntn = cdiv(a.N, BN2);

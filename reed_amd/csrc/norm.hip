@@ -150,17 +150,18 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y,
                                                        const bf16* __restrict__ gate, long ldgate,
-                                                       bf16* __restrict__ dy, float* __restrict__ part, int M, int D,
-                                                       int T) {
+                                                       bf16* __restrict__ dy, float* __restrict__ part,
+                                                       float* __restrict__ part_dy, int M, int D, int T) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][D]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
   const int row0 = blockIdx.x * 16 + wave * 4;
   const bf16* gp = gate + (long)((blockIdx.x * 16) / T) * ldgate;
-  f32x4 gv[MAXV], pg[MAXV];
+  f32x4 gv[MAXV], pg[MAXV], pd[MAXV];
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     int idx = lane + 64 * k;
     pg[k] = f32x4{0, 0, 0, 0};
+    pd[k] = f32x4{0, 0, 0, 0};
     if (idx < nv) gv[k] = ld_bf4(gp + idx * 4);
   }
   for (int rr = 0; rr < 4; ++rr) {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
           float dg = bfround(d[j]);
           o[j] = dg * gv[k][j];
           pg[k][j] += bfround(dg * yv[j]);
+          pd[k][j] += bfround(o[j]);
         }
         st_bf4(dy + (long)row * D + idx * 4, o);
       }
@@ -190,6 +192,33 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   __syncthreads();
   float* out = part + (long)blockIdx.x * D;
   for (int i = threadIdx.x; i < D; i += 256) out[i] = red[i] + red[D + i] + red[2 * D + i] + red[3 * D + i];
+  if (part_dy) {  // column sums of dy over the chunk: the bias gradient of the linear that produced y
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) *(f32x4*)(red + wave * D + idx * 4) = pd[k];
+    }
+    __syncthreads();
+    float* o2 = part_dy + (long)blockIdx.x * D;
+    for (int i = threadIdx.x; i < D; i += 256) o2[i] = red[i] + red[D + i] + red[2 * D + i] + red[3 * D + i];
+  }
+}
+
+// out[n] (+)= sum over rows of an f32 [R, N] partial buffer (fixed order)
+__global__ __launch_bounds__(256) void rowsum_f32_kernel(const float* __restrict__ part, int R, float* __restrict__ out,
+                                                         int N, int accumulate) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < N)
+    for (int z = grp; z < R; z += 4) s += part[(long)z * N + col];
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && col < N) {
+    float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    out[col] = accumulate ? out[col] + t : t;
+  }
 }
 
 struct PartList {
@@ -237,19 +266,19 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-// column sums of a bf16 [M,N] matrix (bias gradients): stage 1 = partial per 64-row slice (8 independent 8-byte loads
+// column sums of a bf16 [M,N] matrix (bias gradients): stage 1 = partial per 256-row slice (8 independent 8-byte loads
 // in flight per thread), stage 2 = ordered reduce of the slices (deterministic)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ x, long ld, float* __restrict__ part,
                                                              int M, int N) {
   const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (col >= N) return;
-  const int r0 = blockIdx.y * 64;
+  const int r0 = blockIdx.y * 256;
   f32x4 s = {0, 0, 0, 0};
   const bf16* base = x + (long)r0 * ld + col;
-  if (r0 + 64 <= M) {  // whole slice in range: unconditional loads, 8 in flight (a per-load bounds select would
+  if (r0 + 256 <= M) {  // whole slice in range: unconditional loads, 8 in flight (a per-load bounds select would
                        // make hipcc branch + vmcnt(0) around every load: cdna_hip_programming.md trap (c))
 #pragma unroll 1
-    for (int rr = 0; rr < 64; rr += 8) {
+    for (int rr = 0; rr < 256; rr += 8) {
       f32x4 v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = ld_bf4(base + (long)(rr + k) * ld);
@@ -313,13 +342,20 @@ extern "C" int reed_ln_modulate_bwd(const void* dh, const float* x, const float*
   return REED_OK;
 }
 
+extern "C" int reed_rowsum_f32(const float* part, int R, float* out, int N, int accumulate, void* stream) {
+  REED_CHECK_ARG(part && out && R > 0 && N > 0, "rowsum_f32: bad args");
+  REED_KLAUNCH(rowsum_f32_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, part, R, out, N, accumulate);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
 extern "C" int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,
-                             float* part, int M, int D, int T, void* stream) {
+                             float* part, float* part_dy, int M, int D, int T, void* stream) {
   REED_CHECK_ARG(dx && y && gate && dy && part, "gate_bwd: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "gate_bwd: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "gate_bwd: T=%d, M=%d must be multiples of 16", T, M);
   REED_KLAUNCH(gate_bwd_kernel, dim3(M / 16), dim3(256), 4 * D * sizeof(float), (hipStream_t)stream, dx,
-                     (const bf16*)y, (const bf16*)gate, (long)ldgate, (bf16*)dy, part, M, D, T);
+                     (const bf16*)y, (const bf16*)gate, (long)ldgate, (bf16*)dy, part, part_dy, M, D, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -360,12 +396,12 @@ extern "C" int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stre
   return REED_OK;
 }
 
-extern "C" int64_t reed_colsum_ws_floats(int M, int N) { return (int64_t)cdiv(M, 64) * N; }
+extern "C" int64_t reed_colsum_ws_floats(int M, int N) { return (int64_t)cdiv(M, 256) * N; }
 
 extern "C" int reed_colsum_bf16(const void* x, int64_t ld, float* ws, float* out, int M, int N, int accumulate,
                                 void* stream) {
   REED_CHECK_ARG(x && ws && out && M > 0 && N > 0 && N % 4 == 0, "colsum_bf16: bad args");
-  const int nsl = cdiv(M, 64);
+  const int nsl = cdiv(M, 256);
   REED_KLAUNCH(colsum_partial_kernel, dim3(cdiv(N, 1024), nsl), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
                (long)ld, ws, M, N);
   REED_KLAUNCH(colsum_reduce_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, ws, nsl, out, N, accumulate);

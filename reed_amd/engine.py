@@ -203,16 +203,17 @@ class Engine:
         return zt.view(B, T, Z) if img else zt
 
     # ---- backward ------------------------------------------------------------------
-    def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev):
+    def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev, bias_done=False):
         """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena. Large problems take the 256^2 TN kernel
         (split-K through slabs, deterministic) with the bias gradient as a separate column-sum; small ones the
         128^2 kernel with the bias gradient fused as an extra ones-MFMA."""
         bname = wname.replace("weight", "bias")
         big, split = ops.plan_wgrad(Mtok, N, K)
-        if big:
-            cw = ops.colsum_ws_floats(Mtok, N)
-            ws = self.ws(cw + split * N * K, dev)
-            ops.colsum_bf16(dy, N, ws, self.G(bname), Mtok, N, acc)
+        if big or bias_done:
+            cw = 0 if bias_done else ops.colsum_ws_floats(Mtok, N)
+            ws = self.ws(cw + split * N * K, dev) if (cw or split > 1) else None
+            if not bias_done:
+                ops.colsum_bf16(dy, N, ws, self.G(bname), Mtok, N, acc)
             ops.linear_wgrad(dy, x, self.G(wname), dbias=None, accumulate=acc, split_k=split, Mtok=Mtok, N=N, K=K,
                              ws=ws.data_ptr() + 4 * cw if split > 1 else None)
         else:
@@ -271,9 +272,10 @@ class Engine:
             b = f"blocks.{i}."
             mb = mp + 2 * (i * 6 * D)
             # MLP branch
-            pg2, dy2 = f32(M // 16, D), bf(M, D)
-            ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T)
-            self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev)
+            pg2, dy2, pb = f32(M // 16, D), bf(M, D), f32(M // 16, D)
+            ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T, part_dy=pb)
+            ops.rowsum_f32(pb, M // 16, self.G(b + "mlp.fc2.bias"), D, acc)
+            self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, bias_done=True)
             da1 = bf(M, Hm)
             ops.gemm(NN, EPI_DGELU, dy2, self.W(b + "mlp.fc2.weight"), M, Hm, D, da1, D, Hm, Hm, R=bk.a1, ldr=Hm)
             self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev)
@@ -283,8 +285,9 @@ class Engine:
             ops.ln_modulate_bwd(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, M, D, T)
             # attention branch
             pg1, dy1 = f32(M // 16, D), bf(M, D)
-            ops.gate_bwd(dx, bk.y1, mb + 4 * D, Nall, dy1, pg1, M, D, T)
-            self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev)
+            ops.gate_bwd(dx, bk.y1, mb + 4 * D, Nall, dy1, pg1, M, D, T, part_dy=pb)
+            ops.rowsum_f32(pb, M // 16, self.G(b + "attn.proj.bias"), D, acc)
+            self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, bias_done=True)
             do = bf(M, D)
             ops.gemm(NN, EPI_BF16, dy1, self.W(b + "attn.proj.weight"), M, D, D, do, D, D, D)
             dqkv = bf(M, 3 * D)

@@ -96,7 +96,7 @@ def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, 
 
 
 def colsum_ws_floats(M, N):
-    return ((M + 63) // 64) * N
+    return ((M + 255) // 256) * N
 
 
 def colsum_bf16(x, ld, ws, out, M, N, accumulate=False):
@@ -135,8 +135,12 @@ def ln_modulate_bwd(dh, x, mean, rstd, scale, ldmod, dx, part, M, D, T):
     _call("reed_ln_modulate_bwd", _p(dh), _p(x), _p(mean), _p(rstd), _p(scale), ldmod, _p(dx), _p(part), M, D, T, _stream())
 
 
-def gate_bwd(dx, y, gate, ldgate, dy, part, M, D, T):
-    _call("reed_gate_bwd", _p(dx), _p(y), _p(gate), ldgate, _p(dy), _p(part), M, D, T, _stream())
+def gate_bwd(dx, y, gate, ldgate, dy, part, M, D, T, part_dy=None):
+    _call("reed_gate_bwd", _p(dx), _p(y), _p(gate), ldgate, _p(dy), _p(part), _p(part_dy), M, D, T, _stream())
+
+
+def rowsum_f32(part, R, out, N, accumulate=False):
+    _call("reed_rowsum_f32", _p(part), R, _p(out), N, int(accumulate), _stream())
 
 
 def reduce_mod_parts(parts, dmod, lddmod, B, D, chunks):

@@ -65,6 +65,7 @@ class GradReducer:
         self.model = model
         self.buckets = dict(check_buckets(model._layout))
         self.enabled = True
+        self.force = os.environ.get("REED_FORCE_REDUCER", "0") == "1"  # run the RCCL calls even at world == 1 (tests)
         L = _lib.load()
         idbuf = ctypes.create_string_buffer(128)
         if self.rank == 0:
@@ -88,7 +89,7 @@ class GradReducer:
         A.shadow_version = -1
 
     def ready(self, name):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or (self.world == 1 and not self.force):
             return
         b, e = self.buckets[name]
         g = self.model._arena.grad
@@ -96,7 +97,7 @@ class GradReducer:
                    "comm_allreduce_avg")
 
     def sync(self):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or (self.world == 1 and not self.force):
             return
         _lib.check(self._lib.reed_comm_sync(self.comm, self._stream()), "comm_sync")
 

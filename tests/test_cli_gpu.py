@@ -46,3 +46,40 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
     torch.set_grad_enabled(True)
     lat = np.load(folder + "_latents.npz")["arr_0"]
     assert lat.shape == (8, 4, 32, 32) and np.isfinite(lat).all()
+
+
+def test_rccl_reducer_world1(dev):
+    """Exercise every RCCL entry point (unique id, init, broadcast, bucketed all-reduce(avg) fired from backward on the
+    side stream, sync, destroy) with a 1-rank communicator: averaging over one rank must leave gradients unchanged."""
+    import copy
+    from oracle import detfill
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT
+    from reed_amd.parallel import GradReducer
+    os.environ["REED_FORCE_REDUCER"] = "1"
+    try:
+        def run(with_reducer):
+            m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10,
+                    z_dims=[128], projector_dim=128, encoder_depth=2)
+            detfill.fill_state_dict(m.state_dict(), base_seed=3)
+            m = m.to(dev).train()
+            m.force_drop_mask = torch.tensor([False, True, False, False])
+            red = GradReducer(m, rank=0, world=1) if with_reducer else None
+            if red:
+                red.broadcast_params(0)
+            lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+            x, n = detfill.normal((4, 4, 8, 8), 1).to(dev), detfill.normal((4, 4, 8, 8), 2)
+            out = lf(m, x, dict(y=torch.tensor([1, 2, 3, 4], device=dev)), zs=[detfill.normal((4, 16, 128), 4).to(dev)],
+                     time_input=detfill.uniform((4,), 3, 0.1, 0.9), noises=n)
+            (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+            if red:
+                red.sync()
+            torch.cuda.synchronize()
+            g = m._arena.grad.clone()
+            if red:
+                red.close()
+            return g
+        g0, g1 = run(False), run(True)
+        assert torch.equal(g0, g1)
+    finally:
+        os.environ.pop("REED_FORCE_REDUCER", None)

@@ -57,7 +57,11 @@ def test_gate_bwd(dev):
     gate = torch.randn(B, D, generator=g).to(torch.bfloat16).to(dev)
     dy = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
     part = torch.empty(M // 16, D, device=dev)
-    ops.gate_bwd(dx, y, gate, D, dy, part, M, D, T)
+    pdy = torch.empty(M // 16, D, device=dev)
+    ops.gate_bwd(dx, y, gate, D, dy, part, M, D, T, part_dy=pdy)
+    db = torch.zeros(D, device=dev)
+    ops.rowsum_f32(pdy, M // 16, db, D)
+    torch.testing.assert_close(db, dy.float().sum(0), atol=1e-3, rtol=1e-4)
     dg = bfr(dx)
     assert torch.equal(dy.float(), bfr(dg * gate.float().repeat_interleave(T, 0)))
     ref = bfr(dg * y.float()).view(B, T, D).sum(1)
