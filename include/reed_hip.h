@@ -76,6 +76,8 @@ int reed_ln_modulate_bwd(const void* dh, const float* x, const float* mean, cons
  * optional part_dy[(m/16),:] = sum dy  (bias gradient of the linear that produced y, reduce with reed_rowsum_f32) */
 int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,
                   float* part, float* part_dy, int M, int D, int T, void* stream);
+/* dst bf16 [C,R] = src bf16 [R,C]^T (transposed weight shadow: turns every block dgrad into the NT layout) */
+int reed_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
 /* out[n] (+)= sum_r part[r, n], f32 [R, N], fixed order */
 int reed_rowsum_f32(const float* part, int R, float* out, int N, int accumulate, void* stream);
 

@@ -205,6 +205,19 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   }
 }
 
+// dst[C,R] = src[R,C]^T, bf16, 64x64 tiles through LDS (both sides 128-byte coalesced)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R,
+                                                             int C) {
+  __shared__ bf16 t[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < R && c0 + tx < C) t[i][tx] = src[(long)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < C && r0 + tx < R) dst[(long)(c0 + i) * R + r0 + tx] = t[tx][i];
+}
+
 // out[n] (+)= sum over rows of an f32 [R, N] partial buffer (fixed order)
 __global__ __launch_bounds__(256) void rowsum_f32_kernel(const float* __restrict__ part, int R, float* __restrict__ out,
                                                          int N, int accumulate) {
@@ -338,6 +351,14 @@ extern "C" int reed_ln_modulate_bwd(const void* dh, const float* x, const float*
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd: T=%d, M=%d must be multiples of 16", T, M);
   REED_KLAUNCH(ln_mod_bwd_kernel, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
                      (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, M, D, T);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
+  REED_CHECK_ARG(src && dst && R > 0 && C > 0, "transpose_bf16: bad args");
+  REED_KLAUNCH(transpose_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
+               (const bf16*)src, (bf16*)dst, R, C);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

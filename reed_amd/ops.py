@@ -139,6 +139,10 @@ def gate_bwd(dx, y, gate, ldgate, dy, part, M, D, T, part_dy=None):
     _call("reed_gate_bwd", _p(dx), _p(y), _p(gate), ldgate, _p(dy), _p(part), _p(part_dy), M, D, T, _stream())
 
 
+def transpose_bf16(src, dst, R, C):
+    _call("reed_transpose_bf16", _p(src), _p(dst), R, C, _stream())
+
+
 def rowsum_f32(part, R, out, N, accumulate=False):
     _call("reed_rowsum_f32", _p(part), R, _p(out), N, int(accumulate), _stream())
 
