@@ -78,8 +78,9 @@ int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldga
                   float* part, float* part_dy, int M, int D, int T, void* stream);
 /* dst bf16 [C,R] = src bf16 [R,C]^T (transposed weight shadow: turns every block dgrad into the NT layout) */
 int reed_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
-/* out[n] (+)= sum_r part[r, n], f32 [R, N], fixed order */
-int reed_rowsum_f32(const float* part, int R, float* out, int N, int accumulate, void* stream);
+/* out[n] (+)= sum_r part[r, n], f32 [R, N], fixed order; ws (optional, cdiv(R,64)*N floats) enables the two-stage
+ * path for tall inputs */
+int reed_rowsum_f32(const float* part, int R, float* ws, float* out, int N, int accumulate, void* stream);
 
 /* reduce per-chunk partials to bf16 modulation grads:
  *   dmod[b, col0 + j*D + d] = bf16( sum_{c<T/16} part_j[(b*T/16 + c)*stride_j + d] ) for the listed parts */

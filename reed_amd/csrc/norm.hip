@@ -363,9 +363,34 @@ extern "C" int reed_transpose_bf16(const void* src, void* dst, int R, int C, voi
   return REED_OK;
 }
 
-extern "C" int reed_rowsum_f32(const float* part, int R, float* out, int N, int accumulate, void* stream) {
+// stage 1 of a tall reduce: part2[s, n] = sum of 64 consecutive rows (thread per column: coalesced, 8 loads in flight)
+__global__ __launch_bounds__(256) void rowsum_stage1_kernel(const float* __restrict__ part, int R, float* __restrict__ part2,
+                                                            int N) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int r0 = blockIdx.y * 64, r1 = min(R, r0 + 64);
+  float s = 0.f;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = part[(long)(r + k) * N + col];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; r < r1; ++r) s += part[(long)r * N + col];
+  part2[(long)blockIdx.y * N + col] = s;
+}
+
+extern "C" int reed_rowsum_f32(const float* part, int R, float* ws, float* out, int N, int accumulate, void* stream) {
   REED_CHECK_ARG(part && out && R > 0 && N > 0, "rowsum_f32: bad args");
-  REED_KLAUNCH(rowsum_f32_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, part, R, out, N, accumulate);
+  if (R > 256 && ws) {  // tall: two stages (ws: cdiv(R,64)*N floats), both in a fixed order
+    const int R2 = cdiv(R, 64);
+    REED_KLAUNCH(rowsum_stage1_kernel, dim3(cdiv(N, 256), R2), dim3(256), 0, (hipStream_t)stream, part, R, ws, N);
+    REED_KLAUNCH(rowsum_f32_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, ws, R2, out, N, accumulate);
+  } else {
+    REED_KLAUNCH(rowsum_f32_kernel, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, part, R, out, N, accumulate);
+  }
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

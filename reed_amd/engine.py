@@ -295,7 +295,8 @@ class Engine:
             # MLP branch
             pg2, dy2, pb = f32(M // 16, D), bf(M, D), f32(M // 16, D)
             ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T, part_dy=pb)
-            ops.rowsum_f32(pb, M // 16, self.G(b + "mlp.fc2.bias"), D, acc)
+            wsr = self.ws((M // 16 + 63) // 64 * D, dev)
+            ops.rowsum_f32(pb, M // 16, self.G(b + "mlp.fc2.bias"), D, acc, ws=wsr)
             self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, bias_done=True)
             da1 = bf(M, Hm)
             ops.gemm(NT, EPI_DGELU, dy2, self.WT(b + "mlp.fc2.weight"), M, Hm, D, da1, D, D, Hm, R=bk.a1, ldr=Hm)
@@ -307,7 +308,7 @@ class Engine:
             # attention branch
             pg1, dy1 = f32(M // 16, D), bf(M, D)
             ops.gate_bwd(dx, bk.y1, mb + 4 * D, Nall, dy1, pg1, M, D, T, part_dy=pb)
-            ops.rowsum_f32(pb, M // 16, self.G(b + "attn.proj.bias"), D, acc)
+            ops.rowsum_f32(pb, M // 16, self.G(b + "attn.proj.bias"), D, acc, ws=wsr)
             self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, bias_done=True)
             do = bf(M, D)
             ops.gemm(NT, EPI_BF16, dy1, self.WT(b + "attn.proj.weight"), M, D, D, do, D, D, D)

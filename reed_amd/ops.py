@@ -143,8 +143,8 @@ def transpose_bf16(src, dst, R, C):
     _call("reed_transpose_bf16", _p(src), _p(dst), R, C, _stream())
 
 
-def rowsum_f32(part, R, out, N, accumulate=False):
-    _call("reed_rowsum_f32", _p(part), R, _p(out), N, int(accumulate), _stream())
+def rowsum_f32(part, R, out, N, accumulate=False, ws=None):
+    _call("reed_rowsum_f32", _p(part), R, _p(ws), _p(out), N, int(accumulate), _stream())
 
 
 def reduce_mod_parts(parts, dmod, lddmod, B, D, chunks):

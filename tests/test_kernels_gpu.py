@@ -62,6 +62,10 @@ def test_gate_bwd(dev):
     db = torch.zeros(D, device=dev)
     ops.rowsum_f32(pdy, M // 16, db, D)
     torch.testing.assert_close(db, dy.float().sum(0), atol=1e-3, rtol=1e-4)
+    tall = torch.randn(1000, 384, generator=g).to(dev)
+    o2, wsr = torch.zeros(384, device=dev), torch.empty(16 * 384, device=dev)
+    ops.rowsum_f32(tall, 1000, o2, 384, ws=wsr)
+    torch.testing.assert_close(o2, tall.sum(0), atol=1e-3, rtol=1e-4)
     dg = bfr(dx)
     assert torch.equal(dy.float(), bfr(dg * gate.float().repeat_interleave(T, 0)))
     ref = bfr(dg * y.float()).view(B, T, D).sum(1)
