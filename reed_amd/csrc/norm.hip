@@ -31,13 +31,16 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
   const float* xr = x + (long)row * D;
   f32x4 v[MAXV];
   float s = 0.f;
+  // unconditional loads on a clamped index (a bounds branch per load would serialise them: guide trap (c));
+  // out-of-range lanes are masked arithmetically
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     int idx = lane + 64 * k;
-    if (idx < nv) {
-      v[k] = *(const f32x4*)(xr + idx * 4);
-      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
-    }
+    const bool ok = idx < nv;
+    v[k] = *(const f32x4*)(xr + (ok ? idx : 0) * 4);
+    const float m = ok ? 1.f : 0.f;
+    v[k] *= m;
+    s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
   }
   bf16* hr = h + (long)row * D;
   if (scale == nullptr) {  // plain cast
@@ -62,13 +65,21 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
   if (lane == 0 && mean) { mean[row] = mu; rstd[row] = r; }
   const bf16* sc = scale + (long)(row / T) * ldmod;
   const bf16* sh = shift + (long)(row / T) * ldmod;
+  f32x4 av[MAXV], bv[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    int idx = lane + 64 * k;
+    int ic = idx < nv ? idx : 0;
+    av[k] = ld_bf4(sc + ic * 4);
+    bv[k] = ld_bf4(sh + ic * 4);
+  }
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     int idx = lane + 64 * k;
     if (idx < nv) {
-      f32x4 a = ld_bf4(sc + idx * 4), b = ld_bf4(sh + idx * 4), o;
+      f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mu) * r * bfround(1.f + a[j]) + b[j];
+      for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mu) * r * bfround(1.f + av[k][j]) + bv[k][j];
       st_bf4(hr + idx * 4, o);
     }
   }
@@ -100,14 +111,21 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
     const int row = row0 + rr;
     if (row >= M) break;
     const float mu = mean[row], r = rstd[row];
-    f32x4 xh[MAXV], gy[MAXV];
+    f32x4 xh[MAXV], gy[MAXV], xin[MAXV], gin[MAXV];
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       int idx = lane + 64 * k;
+      int ic = idx < nv ? idx : 0;
+      xin[k] = *(const f32x4*)(x + (long)row * D + ic * 4);
+      gin[k] = ld_bf4(dh + (long)row * D + ic * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
       if (idx < nv) {
-        f32x4 xv = *(const f32x4*)(x + (long)row * D + idx * 4);
-        f32x4 g = ld_bf4(dh + (long)row * D + idx * 4);
+        f32x4 xv = xin[k];
+        f32x4 g = gin[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           xh[k][j] = (xv[j] - mu) * r;
@@ -119,6 +137,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
         }
       }
     }
+    f32x4 dold[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      dold[k] = *(const f32x4*)(dx + (long)row * D + (idx < nv ? idx : 0) * 4);
+    }
     a1 = wave_sum(a1) / D;
     a2 = wave_sum(a2) / D;
 #pragma unroll
@@ -126,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
       int idx = lane + 64 * k;
       if (idx < nv) {
         float* dp = dx + (long)row * D + idx * 4;
-        f32x4 o = *(const f32x4*)dp;
+        f32x4 o = dold[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += r * (gy[k][j] - a1 - xh[k][j] * a2);
         *(f32x4*)dp = o;
@@ -167,12 +191,20 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   for (int rr = 0; rr < 4; ++rr) {
     const int row = row0 + rr;
     if (row >= M) break;
+    f32x4 din[MAXV], yin[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      int ic = idx < nv ? idx : 0;
+      din[k] = *(const f32x4*)(dx + (long)row * D + ic * 4);
+      yin[k] = ld_bf4(y + (long)row * D + ic * 4);
+    }
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       int idx = lane + 64 * k;
       if (idx < nv) {
-        f32x4 d = *(const f32x4*)(dx + (long)row * D + idx * 4);
-        f32x4 yv = ld_bf4(y + (long)row * D + idx * 4), o;
+        f32x4 d = din[k];
+        f32x4 yv = yin[k], o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float dg = bfround(d[j]);
