@@ -97,6 +97,16 @@ int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H
 int reed_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
                        void* dqkv, int B, int T, int H, int hd, void* stream);
 
+/* qk_norm (timm Attention(qk_norm=True); reference flag --qk-norm, sit.py:114-116): LayerNorm over head_dim (eps, affine
+ * f32 [hd]) on the q and k thirds of qkv bf16 [M,3,H,hd]; v copied through; stats f32 [M,2,H,2] = (mean, rstd).
+ * backward: dpre = LNbwd(dn*w) (v copied); part f32 [nblocks,2(q,k),2(dw,db),hd] per-block partial parameter grads
+ * (reed_qk_norm_bwd_part_floats floats), reduce with reed_rowsum_f32. */
+int reed_qk_norm_fwd(const void* qkv, const float* qw, const float* qb, const float* kw, const float* kb,
+                     void* out, float* stats, int M, int H, int hd, float eps, void* stream);
+int64_t reed_qk_norm_bwd_part_floats(int M, int H, int hd);
+int reed_qk_norm_bwd(const void* dn, const void* qkv, const float* stats, const float* qw, const float* kw,
+                     void* dpre, float* part, int M, int H, int hd, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Embedders and the final layer
  * ------------------------------------------------------------------------------------------- */

@@ -158,7 +158,13 @@ class Engine:
             ops.ln_modulate_fwd(xcur, mb, mb + 2 * D, Nall, h, mean1, rstd1, M, D, T)
             ops.gemm(NT, EPI_BF16, h, self.W(b + "attn.qkv.weight"), M, 3 * D, D, qkv, D, D, 3 * D,
                      bias=self.W(b + "attn.qkv.bias"))
-            ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+            qkv_a, qstats = qkv, None
+            if m.qk_norm:
+                qkv_a = bf(M, 3 * D)
+                qstats = f32(M, 2, H, 2) if need_grad else None
+                ops.qk_norm_fwd(qkv, self.Wf(b + "attn.q_norm.weight"), self.Wf(b + "attn.q_norm.bias"),
+                                self.Wf(b + "attn.k_norm.weight"), self.Wf(b + "attn.k_norm.bias"), qkv_a, qstats, M, H, hd)
+            ops.attention_fwd(qkv_a, o, lse, B, T, H, hd)
             ops.gemm(NT, EPI_GATE_RES, o, self.W(b + "attn.proj.weight"), M, D, D, xmid, D, D, D, C2=y1, ldc2=D,
                      R=xcur, ldr=D, bias=self.W(b + "attn.proj.bias"), gate=mb + 4 * D, ldgate=Nall, rows_per_gate=T)
             ops.ln_modulate_fwd(xmid, mb + 6 * D, mb + 8 * D, Nall, h2, mean2, rstd2, M, D, T)
@@ -167,7 +173,8 @@ class Engine:
             ops.gemm(NT, EPI_GATE_RES, u, self.W(b + "mlp.fc2.weight"), M, D, Hm, xout, Hm, Hm, D, C2=y2, ldc2=D,
                      R=xmid, ldr=D, bias=self.W(b + "mlp.fc2.bias"), gate=mb + 10 * D, ldgate=Nall, rows_per_gate=T)
             if need_grad:
-                tp.blocks.append(types.SimpleNamespace(x=xcur, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, o=o, lse=lse,
+                tp.blocks.append(types.SimpleNamespace(x=xcur, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, qkv_a=qkv_a,
+                                                       qstats=qstats, o=o, lse=lse,
                                                        y1=y1, xmid=xmid, mean2=mean2, rstd2=rstd2, h2=h2, a1=a1, u=u,
                                                        y2=y2))
             xcur = xout
@@ -313,7 +320,16 @@ class Engine:
             do = bf(M, D)
             ops.gemm(NT, EPI_BF16, dy1, self.WT(b + "attn.proj.weight"), M, D, D, do, D, D, D)
             dqkv = bf(M, 3 * D)
-            ops.attention_bwd(bk.qkv, bk.o, do, bk.lse, dqkv, B, T, H, hd)
+            ops.attention_bwd(bk.qkv_a, bk.o, do, bk.lse, dqkv, B, T, H, hd)
+            if m.qk_norm:  # back through the per-head LayerNorm of q and k; parameter grads via per-block partials
+                nb = (M * 3 * H + 255) // 256
+                part = f32(nb, 4 * hd)
+                dpre = bf(M, 3 * D)
+                ops.qk_norm_bwd(dqkv, bk.qkv, bk.qstats, self.Wf(b + "attn.q_norm.weight"),
+                                self.Wf(b + "attn.k_norm.weight"), dpre, part, M, H, hd)
+                ops.rowsum_f32(part, nb, self.G(b + "attn.q_norm.weight"), 4 * hd, acc,
+                               ws=self.ws((nb + 63) // 64 * 4 * hd, dev))
+                dqkv = dpre
             self._wgrad(dqkv, bk.h, b + "attn.qkv.weight", M, 3 * D, D, acc, dev)
             dh1 = do  # reuse
             ops.gemm(NT, EPI_BF16, dqkv, self.WT(b + "attn.qkv.weight"), M, D, 3 * D, dh1, 3 * D, 3 * D, D)

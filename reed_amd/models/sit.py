@@ -83,8 +83,6 @@ class SiT(nn.Module):
                              "projector (the reference keeps only the last of each, sit.py:291-304)")
         if hidden_size % num_heads or hidden_size // num_heads not in (64, 72):
             raise ValueError(f"head_dim {hidden_size / num_heads} unsupported: the HIP attention kernels cover 64 and 72")
-        if self.qk_norm:
-            raise NotImplementedError("qk_norm=True is not implemented in the HIP attention path yet")
         self.num_patches = (input_size // patch_size) ** 2
 
         shapes = self._param_shapes()
@@ -113,6 +111,11 @@ class SiT(nn.Module):
             b = f"blocks.{i}."
             sh[b + "attn.qkv.weight"] = (3 * D, D)
             sh[b + "attn.qkv.bias"] = (3 * D,)
+            if self.qk_norm:  # timm Attention: q_norm / k_norm = LayerNorm(head_dim) between qkv and proj
+                hd = D // self.num_heads
+                for n in ("q_norm", "k_norm"):
+                    sh[b + f"attn.{n}.weight"] = (hd,)
+                    sh[b + f"attn.{n}.bias"] = (hd,)
             sh[b + "attn.proj.weight"] = (D, D)
             sh[b + "attn.proj.bias"] = (D,)
             sh[b + "mlp.fc1.weight"] = (Hm, D)
@@ -240,6 +243,10 @@ class SiT(nn.Module):
         for i in range(self.depth):
             sd[f"blocks.{i}.adaLN_modulation.1.weight"].zero_()
             sd[f"blocks.{i}.adaLN_modulation.1.bias"].zero_()
+            if self.qk_norm:  # nn.LayerNorm default init (no RNG): weight 1, bias 0
+                for n in ("q_norm", "k_norm"):
+                    sd[f"blocks.{i}.attn.{n}.weight"].fill_(1.0)
+                    sd[f"blocks.{i}.attn.{n}.bias"].zero_()
         for n in ("final_layer.adaLN_modulation.1.weight", "final_layer.adaLN_modulation.1.bias",
                   "final_layer.linear.weight", "final_layer.linear.bias"):
             sd[n].zero_()

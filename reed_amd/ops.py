@@ -177,6 +177,18 @@ def attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd):
     _call("reed_attention_bwd", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream())
 
 
+def qk_norm_fwd(qkv, qw, qb, kw, kb, out, stats, M, H, hd, eps=1e-5):
+    _call("reed_qk_norm_fwd", _p(qkv), _p(qw), _p(qb), _p(kw), _p(kb), _p(out), _p(stats), M, H, hd, eps, _stream())
+
+
+def qk_norm_part_floats(M, H, hd):
+    return int(_lib.load().reed_qk_norm_bwd_part_floats(M, H, hd))
+
+
+def qk_norm_bwd(dn, qkv, stats, qw, kw, dpre, part, M, H, hd):
+    _call("reed_qk_norm_bwd", _p(dn), _p(qkv), _p(stats), _p(qw), _p(kw), _p(dpre), _p(part), M, H, hd, _stream())
+
+
 # ---------------- embedders / final layer ----------------
 def patch_embed_fwd(x, w, bias, pos, tokens, B, C, HW, P, D):
     _call("reed_patch_embed_fwd", _p(x), _p(w), _p(bias), _p(pos), _p(tokens), B, C, HW, P, D, _stream())

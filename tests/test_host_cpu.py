@@ -53,6 +53,15 @@ def test_state_dict_surface_matches_reference():
     assert list(osit.param_shapes(kw).keys()) == [k for k in osit.param_shapes(kw)]  # oracle uses the same names
     assert set(osit.param_shapes(kw)) == set(t.state_dict().keys())
     assert len(SiT_models) == 12 and "SiT-XL/2" in SiT_models
+    # qk_norm=True adds timm's q_norm / k_norm LayerNorm(head_dim) parameters, initialised to (1, 0), adjacent in the arena
+    q = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=2, num_heads=2, num_classes=10, z_dims=[],
+            qk_norm=True)
+    kq = tiny_cfg(qk_norm=True, depth=2, z_dims=[], z_types=[])
+    assert set(osit.param_shapes(kq)) == set(q.state_dict().keys())
+    assert float(q.blocks[1].attn.q_norm.weight.sum()) == 64.0 and float(q.blocks[1].attn.k_norm.bias.abs().sum()) == 0.0
+    L = q._layout
+    assert L.off("blocks.0.attn.q_norm.bias") == L.off("blocks.0.attn.q_norm.weight") + 64
+    assert L.off("blocks.0.attn.k_norm.bias") == L.off("blocks.0.attn.q_norm.weight") + 192
 
 
 def test_init_matches_reference_rng_stream():

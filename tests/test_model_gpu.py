@@ -74,8 +74,8 @@ def test_tiny_vs_reference_and_oracle(dev, name):
             continue
         gh, go = p.grad.detach().cpu().float(), P[k].grad
         nh, no = gh.norm().item(), go.norm().item()
-        if no < 1e-10:
-            assert nh < 1e-6, k
+        if no < 5e-5:   # analytically zero gradients (e.g. k_norm.bias: softmax is invariant to a common key shift)
+            assert nh < 5e-4, (k, nh, no)
             continue
         cs = cos(gh, go)
         if cs < 0.98 or abs(nh / no - 1) > 0.08:

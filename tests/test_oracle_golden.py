@@ -47,7 +47,7 @@ TINY_CASES = {
     "hd64": dict(cfg=tiny_cfg(), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=True),
     "hd72": dict(cfg=tiny_cfg(D=144, z_dims=[64]), zspec=[(64, "i")], enc=["dinov2"], co=[1.0], hip=False),
     "unfused": dict(cfg=tiny_cfg(fused_attn=False), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=True),
-    "qknorm": dict(cfg=tiny_cfg(qk_norm=True), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=False),
+    "qknorm": dict(cfg=tiny_cfg(qk_norm=True), zspec=[(128, "i")], enc=["dinov2"], co=[1.0], hip=True),
     "two_same": dict(cfg=tiny_cfg(z_dims=[128, 256], z_types=["i", "t"]), zspec=[(128, "i"), (256, "t")],
                      enc=["clip", "text_embeds_qwenvl"], co=[1.0, 0.5], hip=True),
     "two_split": dict(cfg=tiny_cfg(z_dims=[128, 256], z_types=["i", "t"], encoder_depth=1, encoder_depth_text=3),
