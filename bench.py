@@ -63,16 +63,19 @@ def random_fill(model, seed):
     A.shadow_version = -1
 
 
+TRAFFIC_B256 = None
+TRAFFIC_NOTE = "traffic: PMC pass pending for the r1 kernel set"
+
+
 def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
     """Per-shape timing of the block GEMMs through the SAME entry points and kernel-selection logic the engine uses
-    (events on the launch stream): forward NT with fused epilogues, dgrad as NT on the transposed weight shadow,
-    wgrad through ops.plan_wgrad (XCD-local split-K slabs + column-sum bias gradient on the 256^2 path)."""
+    (events on the launch stream): forward NT with fused epilogues, dgrad NN on the weight shadow, wgrad TN through
+    ops.plan_wgrad (wave-quantised split-K slabs + deterministic reduce, bias gradient fused as a ones-MFMA)."""
     from reed_amd import ops
     dev = torch.device("cuda")
     M = b * T
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.05).to(torch.bfloat16)  # noqa: E731
     x, w_qkv, w_proj, w1, w2 = bf(M, D), bf(3 * D, D), bf(D, D), bf(Hm, D), bf(D, Hm)
-    w_qkv_t, w1_t, w2_t = bf(D, 3 * D), bf(D, Hm), bf(Hm, D)
     big, big2 = bf(M, Hm), bf(M, Hm)
     o3 = bf(M, 3 * D)
     ybuf = bf(M, D)
@@ -82,28 +85,28 @@ def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
     gw = torch.empty(Hm * D, device=dev)
     gb = torch.empty(Hm, device=dev)
     bias = bf(Hm)
-    ws = torch.empty(8 * Hm * D + ops.colsum_ws_floats(M, Hm), device=dev)
+    ws = torch.empty(8 * (Hm * D + Hm), device=dev)
 
-    def wgrad(dy, xx, N, K):
-        use256, split = ops.plan_wgrad(M, N, K)
-        if use256:
-            cw = ops.colsum_ws_floats(M, N)
-            ops.colsum_bf16(dy, N, ws, gb, M, N)
-            ops.linear_wgrad(dy, xx, gw, split_k=split, Mtok=M, N=N, K=K, ws=ws.data_ptr() + 4 * cw)
-        else:
-            ops.linear_wgrad(dy, xx, gw, dbias=gb, split_k=split, Mtok=M, N=N, K=K, ws=ws)
+    def wgrad(dy, xx, N, K, with_bias=True):
+        _, split = ops.plan_wgrad(M, N, K)
+        ops.linear_wgrad(dy, xx, gw, dbias=gb if with_bias else None, split_k=split, Mtok=M, N=N, K=K, ws=ws)
+
+    def dgrad(epi, dy, w, N, K, out, **kw):
+        ops.gemm(ops.NN, epi, dy, w, M, K, N, out, N, K, K, **kw)
 
     cases = [
         ("fwd qkv  NT bias", 2.0 * M * 3 * D * D, lambda: ops.linear_fwd(x, w_qkv, bias[:3 * D], o3)),
         ("fwd proj NT gate+res", 2.0 * M * D * D, lambda: ops.linear_fwd(x, w_proj, bias[:D], xo, epi=ops.EPI_GATE_RES, R=xi, gate=gate, ldgate=6 * D, rows_per_gate=T, y_out=ybuf)),
         ("fwd fc1  NT gelu", 2.0 * M * Hm * D, lambda: ops.linear_fwd(x, w1, bias, big, epi=ops.EPI_GELU, act_out=big2)),
         ("fwd fc2  NT gate+res", 2.0 * M * Hm * D, lambda: ops.linear_fwd(big, w2, bias[:D], xo, epi=ops.EPI_GATE_RES, R=xi, gate=gate, ldgate=6 * D, rows_per_gate=T, y_out=ybuf)),
-        ("dgrad fc2 NT(W^T) dgelu", 2.0 * M * Hm * D, lambda: ops.gemm(ops.NT, ops.EPI_DGELU, x, w2_t, M, Hm, D, big, D, D, Hm, R=big2, ldr=Hm)),
-        ("dgrad fc1 NT(W^T)", 2.0 * M * Hm * D, lambda: ops.gemm(ops.NT, ops.EPI_BF16, big, w1_t, M, D, Hm, ybuf, Hm, Hm, D)),
-        ("dgrad qkv NT(W^T)", 2.0 * M * 3 * D * D, lambda: ops.gemm(ops.NT, ops.EPI_BF16, o3, w_qkv_t, M, D, 3 * D, ybuf, 3 * D, 3 * D, D)),
-        ("wgrad fc1 TN (+bias grad)", 2.0 * M * Hm * D, lambda: wgrad(big, x, Hm, D)),
-        ("wgrad fc2 TN (+bias grad)", 2.0 * M * Hm * D, lambda: wgrad(x, big, D, Hm)),
-        ("wgrad qkv TN (+bias grad)", 2.0 * M * 3 * D * D, lambda: wgrad(o3, x, 3 * D, D)),
+        ("dgrad fc2 NN dgelu", 2.0 * M * Hm * D, lambda: dgrad(ops.EPI_DGELU, x, w2, D, Hm, big, R=big2, ldr=Hm)),
+        ("dgrad fc1 NN", 2.0 * M * Hm * D, lambda: dgrad(ops.EPI_BF16, big, w1, Hm, D, ybuf)),
+        ("dgrad proj NN", 2.0 * M * D * D, lambda: dgrad(ops.EPI_BF16, x, w_proj, D, D, ybuf)),
+        ("dgrad qkv NN", 2.0 * M * 3 * D * D, lambda: dgrad(ops.EPI_BF16, o3, w_qkv, 3 * D, D, ybuf)),
+        ("wgrad fc1 TN +dbias", 2.0 * M * Hm * D, lambda: wgrad(big, x, Hm, D)),
+        ("wgrad fc2 TN", 2.0 * M * Hm * D, lambda: wgrad(x, big, D, Hm, False)),
+        ("wgrad proj TN", 2.0 * M * D * D, lambda: wgrad(x, ybuf, D, D, False)),
+        ("wgrad qkv TN +dbias", 2.0 * M * 3 * D * D, lambda: wgrad(o3, x, 3 * D, D)),
     ]
     rows = []
     for name, flop, fn in cases:
@@ -232,15 +235,14 @@ def main():
             tot_ms = sum(r["ms"] for r in rows)
             agg = sum(r["tflops"] * r["ms"] for r in rows) / tot_ms
             dom = max(rows, key=lambda r: r["ms"])
-            # HBM-side traffic of the dominant kernel (gemm256 TN = fc1 wgrad, 29 % of the step), per launch, from
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r1_pmc_gemm.txt; FETCH_SIZE doubled per the
-            # gfx950 correction). Valid for the b=256 workload only.
-            traffic = 1.47e9 if (b == 256 and args.model == "SiT-XL/2") else None
+            # HBM-side traffic of the slowest GEMM launch, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            # (profiles/; FETCH_SIZE doubled per the gfx950 correction). Valid for the b=256 workload only.
+            traffic = TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None
             out["roofline"] = {"bound": "mfma", "achieved": round(agg, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(agg * 1e12 / PEAK_BF16, 4), "traffic": traffic,
-                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|TN> / gemm_kernel (time-weighted over the "
-                                         "block's 10 GEMM launches; flop per launch / event-timed duration)",
-                               "dominant": "gemm256_kernel<TN> fc1 wgrad: algorithmic 0.78 GB/launch, measured 1.47 GB",
+                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm_kernel<TN> (time-weighted over "
+                                         "the block's 12 GEMM launches; flop per launch / event-timed duration)",
+                               "dominant": TRAFFIC_NOTE,
                                "slowest_shape": dom}
             out["gemm_table"] = rows
         if world == 1 and not args.no_cpu_baseline:

@@ -92,8 +92,6 @@ class ParamArena:
         self.grad = None
         self.shadow = None
         self.shadow_version = -1
-        self.shadow_t = None        # bf16 W^T of the block linears (same offsets), see Engine.refresh_wt
-        self.wt_fresh = False
 
     def view(self, buf, name):
         off, shp = self.layout.seg[name]
@@ -114,9 +112,7 @@ class ParamArena:
         if self.shadow_version != self.master._version:
             ops.cast_bf16(self.master, self.shadow, self.layout.n_total)
             self.shadow_version = self.master._version
-            self.wt_fresh = False
         return self.shadow
 
     def mark_shadow_fresh(self):
         self.shadow_version = self.master._version
-        self.wt_fresh = False

@@ -129,26 +129,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
     const char* tp = smem + buf * STAGE_BYTES;
     const char* tq = tp + TILE_BYTES;
+    bf16x8 pf[2][4], qf[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 pf[4], qf[4];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if constexpr (LAY == LAY_TN) pf[i] = frag_tr(tp, wm * 64 + i * 16, ks, lane);
-        else pf[i] = frag_row(tp, wm * 64 + i * 16, ks, lane);
-        if constexpr (LAY == LAY_NT) qf[i] = frag_row(tq, wn * 64 + i * 16, ks, lane);
-        else qf[i] = frag_tr(tq, wn * 64 + i * 16, ks, lane);
+        if constexpr (LAY == LAY_TN) pf[ks][i] = frag_tr(tp, wm * 64 + i * 16, ks, lane);
+        else pf[ks][i] = frag_row(tp, wm * 64 + i * 16, ks, lane);
+        if constexpr (LAY == LAY_NT) qf[ks][i] = frag_row(tq, wn * 64 + i * 16, ks, lane);
+        else qf[ks][i] = frag_tr(tq, wn * 64 + i * 16, ks, lane);
       }
+    if constexpr (LAY != LAY_NT) REED_LDS_WAIT();  // asm transposing reads: the compiler does not count them
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks][j], pf[ks][i], acc[i][j], 0, 0, 0);
       if constexpr (LAY == LAY_TN) {
         if (do_dbias) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], accb[i], 0, 0, 0);
+            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[ks][i], accb[i], 0, 0, 0);
         }
       }
     }

@@ -27,9 +27,10 @@ constexpr int LDS_BYTES = 8 * HT + 2048;  // + 2 KiB scratch: landing zone of th
 __device__ __forceinline__ constexpr int slotA(int h, int cur) { return (h * 2 + cur) * HT; }
 __device__ __forceinline__ constexpr int slotB(int h, int cur) { return (4 + h * 2 + cur) * HT; }
 
+template <int OFF>
 __device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
+  bf16x4 lo = ds_read_tr16_off<OFF>(a0);   // inline asm: see gemm_common.hpp (no compiler vmcnt(0) before it)
+  bf16x4 hi = ds_read_tr16_off<OFF>(a1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -53,6 +54,7 @@ __device__ __forceinline__ int voff_tr(int i, int tid, long ld) {
 #define BARRIER()                                          \
   do {                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
     __builtin_amdgcn_s_barrier();                          \
     asm volatile("" ::: "memory");                         \
   } while (0)
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
         const int sl = S0 ^ (i << 5);
         const char* p0 = smem + (b0 + sl);
         const char* p1 = smem + (b1 + sl);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) f[i][ks] = tr2(p0 + cur * HT + ks * 8192, p1 + cur * HT + ks * 8192);
+        if (cur == 0) { f[i][0] = tr2<0>(p0, p1); f[i][1] = tr2<8192>(p0, p1); }
+        else { f[i][0] = tr2<HT>(p0, p1); f[i][1] = tr2<HT + 8192>(p0, p1); }
       }
     } else {
       const char* q0 = smem + rA;
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
         const int sl = S0 ^ ((nh * 2 + j) << 5);
         const char* p0 = smem + (tB + sl);
         const char* p1 = smem + (b1 + sl);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) f[j][ks] = tr2(p0 + cur * HT + ks * 8192, p1 + cur * HT + ks * 8192);
+        if (cur == 0) { f[j][0] = tr2<0>(p0, p1); f[j][1] = tr2<8192>(p0, p1); }
+        else { f[j][0] = tr2<HT>(p0, p1); f[j][1] = tr2<HT + 8192>(p0, p1); }
       }
     }
   };
@@ -348,8 +350,8 @@ extern "C" int reed_gemm_set_prefetch(int dist) { g_pf_override = dist; return 0
 bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
   long tiles = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2);
   if (layout == LAY_NT) return tiles >= 224 && a.K >= 256 && (a.N >= 2048 || a.K >= 2048);
-  if (layout == LAY_TN) return splits > 1 && !a.dbias && a.K >= 16384;
-  return false;
+  if (layout == LAY_NN) return tiles >= 224 && a.K >= 256;
+  return false;  // TN (weight gradients): the 128x128 kernel with wave-quantised split-K wins (tools/wgrad_sweep.py)
 }
 
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {

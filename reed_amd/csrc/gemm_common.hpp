@@ -24,6 +24,29 @@ __device__ __forceinline__ bf16x8 frag_row(const char* tile, int rowbase, int ks
   int c = ks * 4 + (lane >> 4);
   return *(const bf16x8*)(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
 }
+// ds_read_b64_tr_b16 through inline asm.  With the builtin, hipcc (ROCm 7.2) puts an `s_waitcnt vmcnt(0)` between any
+// pending LDS-DMA (buffer_load ... lds) and the transposing read, which drains the whole staging pipeline every
+// K step (the plain ds_read_b128 path is not affected).  The asm form is invisible to that logic; the CALLER owns
+// the ordering: an `s_waitcnt lgkmcnt(0)` + `__builtin_amdgcn_sched_barrier(0)` (REED_LDS_WAIT) before the first
+// consumer, and the usual DMA-landed wait + barrier before the read.
+#define REED_LDS_WAIT()                                    \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+__device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
+  bf16x4 r;
+  const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x4 ds_read_tr16_off(const char* p) {
+  bf16x4 r;
+  const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF));
+  return r;
+}
 // lane (i, g) gets X[k = ks*32 + 8g + j][colbase + i], j = 0..7 (two transposing reads)
 __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int colbase, int ks, int lane) {
   int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
@@ -31,8 +54,8 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int colbase, int ks,
   int ch = (colbase >> 3) + (p >> 1);
   const char* a0 = tile + row0 * 256 + ((ch ^ tr_sw(row0)) << 4) + ((p & 1) << 3);
   const char* a1 = tile + row1 * 256 + ((ch ^ tr_sw(row1)) << 4) + ((p & 1) << 3);
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
+  bf16x4 lo = ds_read_tr16(a0);
+  bf16x4 hi = ds_read_tr16(a1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 

@@ -59,26 +59,6 @@ class Engine:
     def G(self, name):
         return self.A.grad.data_ptr() + 4 * self.L.off(name)
 
-    def WT(self, name):
-        return self.A.shadow_t.data_ptr() + 2 * self.L.off(name)
-
-    def refresh_wt(self):
-        """bf16 W^T copies of the four block linears (same arena offsets). With them every block dgrad
-        dx = dy W becomes the NT layout (dy [M,N] x W^T [K,N]) and runs on the faster 256^2 pipelined kernel; the
-        transposes cost one pass over 1.4 GB per optimiser step (~0.5 ms)."""
-        A = self.A
-        if A.wt_fresh:
-            return
-        if A.shadow_t is None:
-            A.shadow_t = torch.empty(self.L.n_total, dtype=torch.bfloat16, device=A.master.device)
-        D, Hm = self.D, self.Hm
-        for i in range(self.depth):
-            b = f"blocks.{i}."
-            for n, (R, C) in (("attn.qkv.weight", (3 * D, D)), ("attn.proj.weight", (D, D)),
-                              ("mlp.fc1.weight", (Hm, D)), ("mlp.fc2.weight", (D, Hm))):
-                ops.transpose_bf16(self.W(b + n), self.WT(b + n), R, C)
-        A.wt_fresh = True
-
     def ws(self, nfloats, dev):
         if self._ws is None or self._ws.numel() < nfloats:
             self._ws = torch.empty(int(nfloats), dtype=torch.float32, device=dev)
@@ -231,22 +211,19 @@ class Engine:
 
     # ---- backward ------------------------------------------------------------------
     def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev, bias_done=False):
-        """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena. Large problems take the 256^2 TN kernel
-        (split-K through slabs, deterministic) with the bias gradient as a separate column-sum; small ones the
-        128^2 kernel with the bias gradient fused as an extra ones-MFMA."""
+        """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena: the 128^2 TN kernel with wave-quantised
+        split-K through slabs (deterministic reduce, ops.plan_wgrad); the bias gradient rides along as an extra
+        ones-MFMA in the blocks of the first column tile unless the caller already has it (bias_done)."""
         bname = wname.replace("weight", "bias")
-        big, split = ops.plan_wgrad(Mtok, N, K)
-        if big or bias_done:
-            cw = 0 if bias_done else ops.colsum_ws_floats(Mtok, N)
-            ws = self.ws(cw + split * N * K, dev) if (cw or split > 1) else None
-            if not bias_done:
-                ops.colsum_bf16(dy, N, ws, self.G(bname), Mtok, N, acc)
-            ops.linear_wgrad(dy, x, self.G(wname), dbias=None, accumulate=acc, split_k=split, Mtok=Mtok, N=N, K=K,
-                             ws=ws.data_ptr() + 4 * cw if split > 1 else None)
-        else:
-            ws = self.ws(split * (N * K + N), dev) if split > 1 else None
-            ops.linear_wgrad(dy, x, self.G(wname), dbias=self.G(bname), accumulate=acc, split_k=split, Mtok=Mtok, N=N,
-                             K=K, ws=ws)
+        _, split = ops.plan_wgrad(Mtok, N, K)
+        ws = self.ws(split * (N * K + N), dev) if split > 1 else None
+        ops.linear_wgrad(dy, x, self.G(wname), dbias=None if bias_done else self.G(bname), accumulate=acc,
+                         split_k=split, Mtok=Mtok, N=N, K=K, ws=ws)
+
+    def _dgrad(self, epi, dy, wname, Mtok, N, K, out, **kw):
+        """dx[Mtok,K] = dy[Mtok,N] W[N,K]: NN layout straight on the bf16 weight shadow (W is the k-strided operand,
+        read with transposing LDS reads) — no W^T copies to keep fresh."""
+        ops.gemm(NN, epi, dy, self.W(wname), Mtok, K, N, out, N, K, K, **kw)
 
     def backward(self, tp, dout, dzs):
         m, L = self.m, self.L
@@ -256,7 +233,6 @@ class Engine:
         dev = dout.device
         Nall = L.ada_rows
         self.A.ensure_grad()
-        self.refresh_wt()
         acc = self.grad_live
         mp = tp.mod.data_ptr()
         ch = T // 16  # 16-row chunks per sample
@@ -306,10 +282,10 @@ class Engine:
             ops.rowsum_f32(pb, M // 16, self.G(b + "mlp.fc2.bias"), D, acc, ws=wsr)
             self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, bias_done=True)
             da1 = bf(M, Hm)
-            ops.gemm(NT, EPI_DGELU, dy2, self.WT(b + "mlp.fc2.weight"), M, Hm, D, da1, D, D, Hm, R=bk.a1, ldr=Hm)
+            self._dgrad(EPI_DGELU, dy2, b + "mlp.fc2.weight", M, D, Hm, da1, R=bk.a1, ldr=Hm)
             self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev)
             dh2 = dy2  # reuse
-            ops.gemm(NT, EPI_BF16, da1, self.WT(b + "mlp.fc1.weight"), M, D, Hm, dh2, Hm, Hm, D)
+            self._dgrad(EPI_BF16, da1, b + "mlp.fc1.weight", M, Hm, D, dh2)
             pl2 = f32(M // 16, 2, D)
             ops.ln_modulate_bwd(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, M, D, T)
             # attention branch
@@ -318,7 +294,7 @@ class Engine:
             ops.rowsum_f32(pb, M // 16, self.G(b + "attn.proj.bias"), D, acc, ws=wsr)
             self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, bias_done=True)
             do = bf(M, D)
-            ops.gemm(NT, EPI_BF16, dy1, self.WT(b + "attn.proj.weight"), M, D, D, do, D, D, D)
+            self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
             dqkv = bf(M, 3 * D)
             ops.attention_bwd(bk.qkv_a, bk.o, do, bk.lse, dqkv, B, T, H, hd)
             if m.qk_norm:  # back through the per-head LayerNorm of q and k; parameter grads via per-block partials
@@ -332,7 +308,7 @@ class Engine:
                 dqkv = dpre
             self._wgrad(dqkv, bk.h, b + "attn.qkv.weight", M, 3 * D, D, acc, dev)
             dh1 = do  # reuse
-            ops.gemm(NT, EPI_BF16, dqkv, self.WT(b + "attn.qkv.weight"), M, D, 3 * D, dh1, 3 * D, 3 * D, D)
+            self._dgrad(EPI_BF16, dqkv, b + "attn.qkv.weight", M, 3 * D, D, dh1)
             pl1 = f32(M // 16, 2, D)
             ops.ln_modulate_bwd(dh1, bk.x, bk.mean1, bk.rstd1, mb + 2 * D, Nall, dx, pl1, M, D, T)
             o6 = i * 6 * D

@@ -6,6 +6,8 @@ Pointer arguments may be torch tensors or raw integer device addresses (for sub-
 """
 import ctypes
 
+import math
+
 import torch
 
 from . import _lib
@@ -108,18 +110,28 @@ def gemm_force_tile(tile):
     _lib.load().reed_gemm_force_tile(int(tile))
 
 
+WGRAD_SLOTS = 512  # resident 128x128 blocks: 256 CUs x 2 (64 KiB LDS, <=128 VGPRs... see gemm.hip launch bounds)
+
+
 def plan_wgrad(Mtok, N, K):
-    """(use_256_tile, split_k) for dw[N,K] = dy[Mtok,N]^T x[Mtok,K]: fill the 256 CUs, keep >= 32 K-tiles per split."""
-    t256 = ((N + 255) // 256) * ((K + 255) // 256)
+    """(use_256_tile, split_k) for dw[N,K] = dy[Mtok,N]^T x[Mtok,K] on the 128x128 TN kernel.
+    Split-K is chosen for WAVE QUANTISATION: tiles*split should fill a whole number of rounds of the 512 resident
+    blocks (SiT-XL qkv: 243 tiles x 4 = 972 of 1024 slots; fc1/fc2: 324 x 3; proj: 81 x 6), and among equally full
+    choices the one whose K slice is closest to 256 K-tiles (16384 tokens) wins: long enough to amortise the
+    prologue/epilogue + slab traffic, short enough that two rounds overlap their tails (tools/wgrad_sweep.py)."""
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
     ktiles = (Mtok + 63) // 64
-    if ktiles >= 512 and N % 128 == 0 and K % 128 == 0:
-        # XCD-local split-K (gemm256.hip): one K slice per XCD round; 8 slices x (tile rectangles of <= 32 blocks)
-        return True, 8
-    t128 = (N // 128) * (K // 128)
-    split = 1
-    if t128 < 160 and Mtok >= 2048:
-        split = max(1, min(8, 256 // t128, Mtok // 512))
-    return False, split
+    best, best_key = 1, None
+    for s in range(1, 9):
+        if s > 1 and ktiles // s < 32:
+            break
+        blocks = tiles * s
+        eff = blocks / (((blocks + WGRAD_SLOTS - 1) // WGRAD_SLOTS) * WGRAD_SLOTS)
+        dist = abs(math.log((ktiles / s) / 256.0))
+        key = (-round(eff / 0.03), dist)   # 3 % efficiency buckets, then slice length
+        if best_key is None or key < best_key:
+            best, best_key = s, key
+    return False, best
 
 
 def reduce_slabs(slabs, stride, n, out, count, accumulate=False):
