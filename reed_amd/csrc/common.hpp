@@ -47,25 +47,32 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float bfround(float x) { return (float)(bf16)x; }
 
+// Hardware transcendentals: v_rcp_f32 / v_exp_f32 are 1-ulp, quarter-rate single instructions.  (`__frcp_rn` and `1/x`
+// expand to the 10-instruction IEEE division sequence, `__expf` to a range-checked scale: in the GEMM epilogues that
+// VALU work, not HBM, was what the MFMA pipe waited on.)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// sigmoid(y) = 1 / (1 + 2^(-y log2 e)); exp2 -> inf gives rcp -> 0, the correct limit.
+__device__ __forceinline__ float sigmoid_f(float y) { return fast_rcp(1.f + fast_exp2(-1.4426950408889634f * y)); }
+
 // GELU(tanh approx) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi)(x + 0.044715 x^3).  Since 0.5(1 + tanh(u)) = sigmoid(2u),
-// gelu(x) = x * s with s = 1/(1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of a libm tanhf in the GEMM
-// epilogues (300 M elements per fc1 call at b=256).  Error << bf16 resolution of the stored result.
+// gelu(x) = x * s with s = 1/(1 + 2^t), t = -2u log2(e) = x (c0 + c1 x^2): three full-rate ops + one v_exp_f32 + one
+// v_rcp_f32 instead of a libm tanhf (300 M elements per fc1 call at b=256).  Error << bf16 resolution of the result.
 __device__ __forceinline__ float gelu_sig(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u2 = 2.f * k0 * (x + k1 * x * x * x);
-  return __frcp_rn(1.f + __expf(-u2));
+  const float c0 = -2.f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+  return fast_rcp(1.f + fast_exp2(x * fmaf(c1, x * x, c0)));
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) { return x * gelu_sig(x); }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-  // d/dx [x s(2u)] = s + x s (1 - s) 2 u',  u' = sqrt(2/pi)(1 + 3*0.044715 x^2)
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  // d/dx [x s(2u)] = s + x s (1 - s) 2 u',  2u' = 2 sqrt(2/pi)(1 + 3*0.044715 x^2)
+  const float d0 = 2.f * 0.7978845608028654f, d1 = d0 * 3.f * 0.044715f;
   float s = gelu_sig(x);
-  float du2 = 2.f * k0 * (1.f + 3.f * k1 * x * x);
-  return s + x * s * (1.f - s) * du2;
+  float xs = x * s;
+  return fmaf(xs - xs * s, fmaf(d1, x * x, d0), s);
 }
-__device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
-  float s = __frcp_rn(1.f + __expf(-x));
+  float s = sigmoid_f(x);
   return s * (1.f + x * (1.f - s));
 }
 

@@ -34,9 +34,8 @@ struct GemmArgs {
   int accumulate;
   int ksplit_len;
   long slab_stride;
-  int xcd_gm, xcd_gn;  // >0: XCD-local split-K scheduling (gemm256.hip): co-resident blocks of one XCD = gm x gn tiles of one K slice
-  int xcd_splits;
-  int pf_dist;  // gemm256: L2 prefetch distance in K-tiles (0 = off)
+  int persist;  // gemm256: >0 = persistent launch with this many blocks (one per CU)
+  int stagger;  // gemm256: first-round start stagger, 10 ns ticks per phase step (0 = off)
 };
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);

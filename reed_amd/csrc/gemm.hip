@@ -158,16 +158,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] ----
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-      epilogue<EPI>(a, acc[i][j], m, n, z);
-    }
-  }
+  // (the K loop ended on a __syncthreads: the tile buffers are free, each wave stages through its own 4 KiB)
+  tile_epilogue<EPI, 4>(a, acc, m0, wm * 64, n0 + wn * 64, lane, z, smem + wave * EPI_STAGE_BYTES);
   if constexpr (LAY == LAY_TN) {
     if (do_dbias && (lane >> 4) == 0) {
 #pragma unroll
@@ -224,6 +216,9 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
   REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   REED_CHECK_ARG(a.N % BN == 0, "reed_gemm: N=%d must be a multiple of %d", a.N, BN);
   REED_CHECK_ARG(a.ldp % 8 == 0 && a.ldq % 8 == 0, "reed_gemm: leading dims must be multiples of 8 elements");
+  REED_CHECK_ARG(a.ldc >= 0 && a.ldc < (1 << 20) && a.ldc2 >= 0 && a.ldc2 < (1 << 20) && a.ldr >= 0 && a.ldr < (1 << 20) &&
+                     a.ldc % 8 == 0 && a.ldc2 % 8 == 0 && a.ldr % 8 == 0,
+                 "reed_gemm: output/residual leading dims must be multiples of 8 below 2^20 (32-bit tile offsets)");
   REED_CHECK_ARG(((uintptr_t)a.P % 16) == 0 && ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
                  "reed_gemm: operands must be 16-byte aligned");
   if (layout == LAY_TN) {

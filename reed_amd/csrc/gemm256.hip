@@ -21,7 +21,7 @@ using namespace gemm_detail;
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int HT = 16384;        // half-tile bytes
-constexpr int LDS_BYTES = 8 * HT + 2048;  // + 2 KiB scratch: landing zone of the L2-prefetch DMA (never read)
+constexpr int LDS_BYTES = 8 * HT + 8 * EPI_STAGE_BYTES;  // K-tile buffers + the waves' epilogue staging patches = 160 KiB
 // LDS map: slot(operand half, K-tile buffer) = [A0c0 A0c1 A1c0 A1c1 B0c0 B0c1 B1c0 B1c1]: the two K-tile buffers of a
 // half-tile are adjacent, so buffer select (cur*HT) and k-step (ks*8192) fit the 16-bit DS immediate offset.
 __device__ __forceinline__ constexpr int slotA(int h, int cur) { return (h * 2 + cur) * HT; }
@@ -36,10 +36,10 @@ __device__ __forceinline__ bf16x8 tr2(const char* a0, const char* a1) {
 
 // stage one half-tile (16 KiB) with 512 threads: 2 x 16 B per thread.  The per-thread byte offsets (voff) are
 // loop invariant; everything that changes per K-tile / half goes through the scalar soffset.
-__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rs, char* ht, int voff0, int voff1, int soff,
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rs, char* ht, int voff, int round2, int soff,
                                            int wave) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(ht + (wave * 64) * 16), 16, voff0, soff, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(ht + (512 + wave * 64) * 16), 16, voff1, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(ht + (wave * 64) * 16), 16, voff, soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(ht + (512 + wave * 64) * 16), 16, voff, soff + round2, 0, 0);
 }
 // per-thread offset of staging round i for a k-contiguous ("row") / k-strided ("tr") operand half-tile
 __device__ __forceinline__ int voff_row(int i, int tid, long ld) {
@@ -67,27 +67,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   const int wr = wave >> 2, wc = wave & 3;
 
   const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
-  int tm, tn, z;
-  if (a.xcd_gm > 0) {
-    // XCD-local split-K scheduling (wgrad): workgroups are dealt round-robin to the 8 XCDs in launch order, so the
-    // blocks L, L+8, L+16, ... share one XCD and its L2.  A "unit" = (gm x gn rectangle of output tiles) x (one K
-    // slice); the U = gm*gn <= 32 blocks of a unit get consecutive slots on ONE XCD, i.e. they run together on its
-    // 32 CUs and every operand slab of the slice is fetched once per XCD and shared through its L2.  (Placement is
-    // a speed assumption only: any mapping is correct.)
-    const int U = a.xcd_gm * a.xcd_gn;
-    const int ngm = (ntm + a.xcd_gm - 1) / a.xcd_gm, ngn = (ntn + a.xcd_gn - 1) / a.xcd_gn;
-    const int nunits = ngm * ngn * a.xcd_splits;
-    const int L = blockIdx.x, xcd = L & 7, r = L >> 3;
-    const int u = (r / U) * 8 + xcd, within = r % U;
-    if (u >= nunits) return;
-    z = u / (ngm * ngn);
-    const int rem = u - z * (ngm * ngn);
-    tm = (rem / ngn) * a.xcd_gm + within / a.xcd_gn;
-    tn = (rem % ngn) * a.xcd_gn + within % a.xcd_gn;
-    if (tm >= ntm || tn >= ntn) return;
-  } else {
+  int tm = 0, tn = 0, z = 0;
+  // virtual block id -> output tile (and K slice).  Persistent launches (a.persist: grid = one block per CU) walk
+  // vb = blockIdx.x, +gridDim.x, ...: the same order the hardware would dispatch a full grid in.
+  auto map_tile = [&](int vb) -> bool {
     const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
+    if (vb >= nwg) return false;
+    int bid = vb;
     {
       int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
       bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -99,23 +85,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     tm = first_m + (bid % per_group) % gs;
     tn = (bid % per_group) / gs;
     z = blockIdx.y;
+    return true;
+  };
+  int vb = blockIdx.x;
+  if (!map_tile(vb)) return;
+  if (a.stagger > 0 && blockIdx.x < 256) {
+    const long t0 = wall_clock64();
+    const long d = (long)((blockIdx.x >> 3) & 7) * a.stagger;
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(16);
   }
-  const int m0 = tm * BM2, n0 = tn * BN2;
+  int m0 = tm * BM2, n0 = tn * BN2;
   const int kbeg = z * a.ksplit_len;
   const int kend = min(a.K, kbeg + a.ksplit_len);
   const int nt = (kend - kbeg + BK2 - 1) / BK2;
 
   __amdgpu_buffer_rsrc_t rsP, rsQ;
-  if constexpr (LAY == LAY_TN) rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
-  else rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
-  if constexpr (LAY == LAY_NT) rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
-  else rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
+  auto set_rsrc = [&]() {
+    if constexpr (LAY == LAY_TN) rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
+    else rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
+    if constexpr (LAY == LAY_NT) rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
+    else rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
+  };
+  set_rsrc();
 
   // loop-invariant per-thread staging offsets
+  // (the second staging round of a half-tile is 64 rows (row operand) / 32 rows (tr operand) further down; both
+  // swizzle keys are periodic in that, so it is the same per-thread offset plus a scalar)
   const int vA0 = (LAY == LAY_TN) ? voff_tr(0, tid, a.ldp) : voff_row(0, tid, a.ldp);
-  const int vA1 = (LAY == LAY_TN) ? voff_tr(1, tid, a.ldp) : voff_row(1, tid, a.ldp);
   const int vB0 = (LAY == LAY_NT) ? voff_row(0, tid, a.ldq) : voff_tr(0, tid, a.ldq);
-  const int vB1 = (LAY == LAY_NT) ? voff_row(1, tid, a.ldq) : voff_tr(1, tid, a.ldq);
+  const int r2A = (LAY == LAY_TN) ? (int)(32 * a.ldp * 2) : (int)(64 * a.ldp * 2);
+  const int r2B = (LAY == LAY_NT) ? (int)(64 * a.ldq * 2) : (int)(32 * a.ldq * 2);
   // scalar byte offsets: per K-tile step and per half (128 rows of a row operand / 128 columns of a tr operand)
   const int kstepA = (LAY == LAY_TN) ? (int)(BK2 * a.ldp * 2) : BK2 * 2;
   const int kstepB = (LAY == LAY_NT) ? BK2 * 2 : (int)(BK2 * a.ldq * 2);
@@ -123,29 +122,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   const int halfB = (LAY == LAY_NT) ? (int)(128 * a.ldq * 2) : 128 * 2;
   const int kbaseA = (LAY == LAY_TN) ? (int)((long)kbeg * a.ldp * 2) : kbeg * 2;
   const int kbaseB = (LAY == LAY_NT) ? kbeg * 2 : (int)((long)kbeg * a.ldq * 2);
-  // L2 prefetch (streaming operands, wgrad): every thread touches ONE 128-byte line of K-tile t+pf_dist through a
-  // 4-byte LDS-DMA into a scratch area (no VGPR destination; it is just another in-order entry of the vmcnt queue).
-  // Waves 0-3 cover operand A's 256x64 K-tile, waves 4-7 operand B's: 256 lines each.
-  const int pf = a.pf_dist;
-  int vPF;
-  {
-    const int idx = tid & 255;
-    const bool opA = wr == 0;
-    const bool tr = opA ? (LAY == LAY_TN) : (LAY != LAY_NT);
-    const long ld = opA ? a.ldp : a.ldq;
-    vPF = tr ? (int)(((long)(idx >> 2) * ld + (idx & 3) * 64) * 2) : (int)((long)idx * ld * 2);
-  }
-  auto prefetch = [&](int t) {
-    char* dst = smem + 8 * HT + wave * 256;
-    if (wr == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)dst, 4, vPF, kbaseA + t * kstepA, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)dst, 4, vPF, kbaseB + t * kstepB, 0, 0);
-  };
   // half-tile h of operand A (P) / B (Q) of K-tile t into buffer CUR
   auto issueA = [&](int t, int h, int cur) {
-    stage_half(rsP, smem + slotA(h, cur), vA0, vA1, kbaseA + t * kstepA + h * halfA, wave);
+    stage_half(rsP, smem + slotA(h, cur), vA0, r2A, kbaseA + t * kstepA + h * halfA, wave);
   };
   auto issueB = [&](int t, int h, int cur) {
-    stage_half(rsQ, smem + slotB(h, cur), vB0, vB1, kbaseB + t * kstepB + h * halfB, wave);
+    stage_half(rsQ, smem + slotB(h, cur), vB0, r2B, kbaseB + t * kstepB + h * halfB, wave);
   };
   // ---- fragment addressing -------------------------------------------------------------------------------
   // k-contiguous operand (frag_row): byte = row*128 + ((c ^ ((row>>1)&7))<<4), row = tile*16 + (lane&15), c = ks*4 + g:
@@ -231,34 +213,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   } while (0)
 
   // One K-tile; BX holds B-nh0(t) on entry, BY receives B-nh1(t); on exit BY holds B-nh0(t+1) (roles swap).
-#define KTILE(T, CUR, BX, BY)                                                       \
+  // FIRST = 1 for K-tile 0 of an output tile: its successor K-tile 1 was staged completely by the tile prologue, and
+  // the p3 wait may leave `relax_ops` younger vector-memory instructions (the previous tile's epilogue) in flight.
+#define VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define KTILE(T, CUR, BX, BY, FIRST)                                                \
   do {                                                                          \
     const int t_ = (T);                                                         \
     asm volatile("" : "+v"(S0), "+v"(tA), "+v"(tB), "+v"(rA), "+v"(rB));        \
     /* p0 */                                                                    \
     BARRIER();                                                                  \
-    if (t_ + 1 < nt) issueA(t_ + 1, 1, 1 - (CUR));                                      \
+    if (!(FIRST) && t_ + 1 < nt) issueA(t_ + 1, 1, 1 - (CUR));                  \
     loadB((CUR), 1, BY);                                                        \
     MMA(0, 0, A0r, BX);                                                         \
     /* p1 */                                                                    \
     BARRIER();                                                                  \
-    if (t_ + 2 < nt) issueB(t_ + 2, 0, (CUR));                                      \
+    if (t_ + 2 < nt) issueB(t_ + 2, 0, (CUR));                                  \
     loadA((CUR), 1, A1r);                                                       \
     MMA(0, 1, A0r, BY);                                                         \
     /* p2 */                                                                    \
     BARRIER();                                                                  \
-    if (t_ + 2 < nt) issueB(t_ + 2, 1, (CUR));                                      \
-    const bool pf_ = pf > 0 && t_ + pf < nt;                                    \
-    if (pf_) prefetch(t_ + pf);                                                 \
+    if (t_ + 2 < nt) issueB(t_ + 2, 1, (CUR));                                  \
     MMA(1, 1, A1r, BY);                                                         \
     /* p3: K-tile t+1 must have landed before its first fragment read */        \
     if (t_ + 1 < nt) {                                                          \
-      if (pf_) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                 \
-      else if (t_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+      if ((FIRST) && relax) {                                                   \
+        if (t_ + 2 < nt) VMCNT(RELAX4); else VMCNT(RELAX0);                     \
+      } else {                                                                  \
+        if (t_ + 2 < nt) VMCNT(4); else VMCNT(0);                               \
+      }                                                                         \
     }                                                                           \
     BARRIER();                                                                  \
-    if (t_ + 2 < nt) issueA(t_ + 2, 0, (CUR));                                      \
+    if (t_ + 2 < nt) issueA(t_ + 2, 0, (CUR));                                  \
     if (t_ + 1 < nt) {                                                          \
       loadA(1 - (CUR), 0, A0r); /* A0r is dead since p1 */                      \
       loadB(1 - (CUR), 0, BY);  /* BY (B-nh1) dead since p2 */                 \
@@ -266,36 +251,66 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     MMA(1, 0, A1r, BX);                                                         \
   } while (0)
 
-  bf16x8 A0r[4][2], A1r[4][2], Bp[2][2], Bq[2][2];
-  if (nt > 0) {
-    // prologue: K-tile 0 complete, K-tile 1 minus its A1 half in flight
-    issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 0, 0); issueA(0, 1, 0);
-    if (nt > 1) {
-      issueB(1, 0, 1); issueB(1, 1, 1); issueA(1, 0, 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    BARRIER();
-    loadA(0, 0, A0r);
-    loadB(0, 0, Bp);
-  }
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    KTILE(t, 0, Bp, Bq);
-    KTILE(t + 1, 1, Bq, Bp);
-  }
-  if (t < nt) KTILE(t, 0, Bp, Bq);
+  // Vector-memory instructions return in order, so "K-tile k has landed" is a count of the YOUNGER instructions.
+  // After the first output tile of a persistent block those include the previous tile's epilogue, whose instruction
+  // count is exact (gemm_common.hpp, EpiOps): waiting with that many more outstanding lets its stores drain under
+  // the first K-tiles' MFMAs.  s_waitcnt vmcnt holds 6 bits; capping only makes the wait stricter.
+  constexpr int EOPS = EpiOps<EPI, 8>::value;
+  constexpr int RELAX8 = EOPS < 0 ? 8 : (EOPS + 8 > 63 ? 63 : EOPS + 8);
+  constexpr int RELAX4 = EOPS < 0 ? 4 : (EOPS + 4 > 63 ? 63 : EOPS + 4);
+  constexpr int RELAX0 = EOPS < 0 ? 0 : (EOPS > 63 ? 63 : EOPS);
+  bool relax = false;   // true from the block's second output tile on
 
-  // ---- epilogue: lane holds C[m = ..+(lane&15)][n = ..+4*(lane>>4) .. +3] of each 16x16 tile
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
-      epilogue<EPI>(a, acc[i][j], m, n, z);
+  bf16x8 A0r[4][2], A1r[4][2], Bp[2][2], Bq[2][2];
+  // prologue DMA of an output tile: K-tiles 0 and 1 complete (8 + 8 instructions per wave)
+  auto issue_prologue = [&]() {
+    if (nt > 0) {
+      issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 0, 0); issueA(0, 1, 0);
+      if (nt > 1) { issueB(1, 0, 1); issueB(1, 1, 1); issueA(1, 0, 1); issueA(1, 1, 1); }
     }
+  };
+  issue_prologue();
+  for (;;) {
+    int t = 0;
+    if (nt > 0) {
+      // K-tile 0 landed: younger = K-tile 1's 8 loads (+ the previous tile's epilogue)
+      if (relax) { if (nt > 1) VMCNT(RELAX8); else VMCNT(RELAX0); }
+      else { if (nt > 1) VMCNT(8); else VMCNT(0); }
+      BARRIER();
+      loadA(0, 0, A0r);
+      loadB(0, 0, Bp);
+      KTILE(0, 0, Bp, Bq, 1);
+      if (nt > 1) KTILE(1, 1, Bq, Bp, 0);
+      t = 2;
+    }
+    for (; t + 1 < nt; t += 2) {
+      KTILE(t, 0, Bp, Bq, 0);
+      KTILE(t + 1, 1, Bq, Bp, 0);
+    }
+    if (t < nt) KTILE(t, 0, Bp, Bq, 0);
+
+    // Persistent blocks: every wave is past the last K-tile's p3 barrier, so all LDS fragment reads of this tile are
+    // done and both K-tile buffers are free: put the NEXT tile's prologue DMA in flight first, then run this tile's
+    // epilogue (HBM-heavy for the fused ones) under it.  Hides workgroup launch + the prologue's load latency.
+    const int em0 = m0, en0 = n0;
+    bool more = false;
+    if (a.persist) {
+      vb += gridDim.x;
+      more = map_tile(vb);
+      if (more) {
+        m0 = tm * BM2;
+        n0 = tn * BN2;
+        set_rsrc();
+        issue_prologue();
+      }
+    }
+    tile_epilogue<EPI, 8>(a, acc, em0, wr * 128, en0 + wc * 64, lane, z, smem + 8 * HT + wave * EPI_STAGE_BYTES);
+    if (!more) break;
+    relax = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
@@ -309,11 +324,7 @@ int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM2) * cdiv(a.N, BN2), splits, 1);
-  if (a.xcd_gm > 0) {
-    const int ngm = cdiv(cdiv(a.M, BM2), a.xcd_gm), ngn = cdiv(cdiv(a.N, BN2), a.xcd_gn);
-    const int nunits = ngm * ngn * a.xcd_splits;
-    grid = dim3(cdiv(nunits, 8) * 8 * a.xcd_gm * a.xcd_gn, 1, 1);
-  }
+  if (a.persist) grid = dim3(a.persist, 1, 1);
   REED_KLAUNCH((gemm256_kernel<LAY, EPI>), grid, dim3(512), LDS_BYTES, stream, a);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -338,15 +349,27 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int g_pf_override = -1;
-extern "C" int reed_gemm_set_prefetch(int dist) { g_pf_override = dist; return 0; }
+static int g_persist = 1;
+extern "C" int reed_gemm_set_persistent(int on) { g_persist = on; return 0; }
+static int reed_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+static int g_stagger = -1;
+extern "C" int reed_gemm_set_stagger(int ticks) { g_stagger = ticks; return 0; }
 
-// Kernel selection, from A/B timing on MI355X at the SiT-XL/2 shapes (tools/bench_gemm.py):
-//   NT (forward):  256^2 wins 15-20 % once the grid fills the chip and N or K is large (qkv, fc1, fc2); the square
-//                  1152x1152 projection is ~6 % better on the 128^2 kernel (4.5 column tiles, short K).
-//   NN (dgrad):    a wash (+-4 %): stays on the 128^2 kernel (2 blocks/CU absorb the ragged tail better).
-//   TN (wgrad):    256^2 only together with XCD-local split-K (the planner passes splits > 1) and without the
-//                  fused bias gradient, which needs the 128^2 kernel's spare accumulators.
+// Kernel selection, from A/B timing on MI355X at the SiT-XL/2 shapes (tools/bench_gemm.py, tools/wgrad_sweep.py):
+//   NT (forward):  256^2 once the grid fills the chip and N or K is large (qkv, fc1, fc2); the square 1152x1152
+//                  projection stays on the 128^2 kernel (4.5 column tiles, short K).
+//   NN (dgrad):    256^2 whenever the grid fills the chip (with the asm transposing reads it runs at NT speed).
+//   TN (wgrad):    128^2 with wave-quantised split-K (ops.plan_wgrad); the 256^2 TN variant is kept for large
+//                  square problems (forced tile) only.
 bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
   long tiles = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2);
   if (layout == LAY_NT) return tiles >= 224 && a.K >= 256 && (a.N >= 2048 || a.K >= 2048);
@@ -355,28 +378,12 @@ bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
 }
 
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
-  a.xcd_gm = a.xcd_gn = 0;
-  a.xcd_splits = splits;
-  a.pf_dist = 0;
-  if (g_pf_override >= 0) a.pf_dist = g_pf_override;
-  else if (layout == LAY_TN && splits > 1) a.pf_dist = 4;  // tools/pf_sweep.py: 3-5 K-tiles ahead = +5-10 %, <=2 too late, >=6 evicted
-  if (layout == LAY_TN && splits > 1) {
-    // pick the gm x gn rectangle (<= 32 tiles = one block per CU of an XCD) with the best operand reuse
-    const int ntm = cdiv(a.M, BM2), ntn = cdiv(a.N, BN2);
-    int best_gm = 1, best_gn = 1;
-    double best = 0;
-    for (int gm = 1; gm <= ntm && gm <= 32; ++gm) {
-      int gn = 32 / gm;
-      if (gn > ntn) gn = ntn;
-      if (gn < 1) continue;
-      // occupancy-weighted reuse: useful tiles per unit slot x flop per byte
-      const int ngm = cdiv(ntm, gm), ngn = cdiv(ntn, gn);
-      double fill = (double)(ntm * ntn) / ((double)ngm * ngn * gm * gn);
-      double score = fill * (double)(gm * gn) / (gm + gn) * ((gm * gn) / 32.0);
-      if (score > best) { best = score; best_gm = gm; best_gn = gn; }
-    }
-    a.xcd_gm = best_gm;
-    a.xcd_gn = best_gn;
+  a.stagger = g_stagger > 0 ? g_stagger : 0;
+  {
+    // persistent launch (one block per CU walking the tile list) whenever there is more than one round of tiles
+    const long nwg = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2);
+    const int ncu = reed_num_cus();
+    a.persist = (g_persist && splits == 1 && nwg > ncu) ? ncu : 0;
   }
   switch (layout) {
     case LAY_NT: return dispatch256<LAY_NT>(epi, a, splits, stream);

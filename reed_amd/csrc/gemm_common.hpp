@@ -60,72 +60,254 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int colbase, int ks,
 }
 
 // ---- epilogue -------------------------------------------------------------------
-template <int EPI>
-__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 acc, int m, int n, int z) {
-  if (m >= a.M || n >= a.N) return;
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (a.bias) {
-    bf16x4 b = *(const bf16x4*)(a.bias + n);
+// One wave's NI x 4 grid of 16x16 accumulator tiles covers rows m0+mw .. +16 NI, columns nbase .. +64.  In the MFMA
+// layout a lane owns 4 consecutive columns of one row, i.e. a wave-level store would write sixteen 32-byte pieces:
+// partial cache lines that HBM takes badly (measured: the output stream cost as much as if nothing overlapped it).
+// So every 16-row group goes through a wave-private 4 KiB LDS patch (XOR-swizzled, conflict-free both ways) and
+// comes back row-contiguous: lane L owns 8 consecutive columns (L&7) of rows (L>>3) and (L>>3)+8, every global
+// access is 16 bytes per lane and a wave-level access covers 8 full 128-byte (bf16) / 256-byte (fp32) row segments.
+//
+// The bf16-output epilogues (forward / dgrad paths) are also BRANCH-FREE: raw buffer loads/stores through
+// descriptors based at the tile's first row; rows >= M fall outside num_records (dropped / read as 0 by the
+// hardware range check), a wave whose 64 columns lie beyond N (N % 128 == 0) gets an out-of-range offset, and absent
+// optional operands (bias, pre-activation, y) get an empty descriptor.  A wave therefore issues EXACTLY
+// EpiOps<EPI, NI>::value vector-memory instructions, which the persistent 256^2 kernel relies on to keep this
+// tile's stores in flight under the next tile's first K-tiles (counted s_waitcnt vmcnt).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, int NI>
+struct EpiOps {
+  static constexpr int value = EPI == EPI_BF16 ? 1 + NI * 2
+                               : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU) ? 1 + NI * 4
+                               : EPI == EPI_GATE_RES ? 1 + NI * 12
+                                                     : -1;  // fp32-accumulate epilogues: pointer path, not counted
+};
+
+constexpr int EPI_STAGE_BYTES = 4096;  // per wave: 16 rows x 64 columns x fp32
+constexpr int EPI_OOB = 0x7FFFFFF0;    // >= every num_records we build (epi_rsrc clamps to 0x7FFF0000)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, long bytes) {
+  if (!p || bytes < 0) bytes = 0;
+  if (bytes > 0x7FFF0000l) bytes = 0x7FFF0000l;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 ld_bf16x8(__amdgpu_buffer_rsrc_t rs, int off, int soff = 0) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0));
+}
+__device__ __forceinline__ void st_bf16x8(bf16x8 v, __amdgpu_buffer_rsrc_t rs, int off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0);
+}
+__device__ __forceinline__ f32x4 ld_f32x4(__amdgpu_buffer_rsrc_t rs, int off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ __forceinline__ void st_f32x4(f32x4 v, __amdgpu_buffer_rsrc_t rs, int off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0);
+}
+
+template <int EPI, int NI>
+__device__ __forceinline__ void tile_epilogue_ptr(const GemmArgs& a, const f32x4 (&acc)[NI][4], int mbase, int nbase,
+                                                  int lane, int z);
+
+// stage: this wave's EPI_STAGE_BYTES of LDS (no other wave touches it; the caller made sure the K loop is done with it)
+template <int EPI, int NI>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[NI][4], int m0, int mw, int nbase,
+                                              int lane, int z, char* stage) {
+  if constexpr (EpiOps<EPI, NI>::value < 0) {
+    tile_epilogue_ptr<EPI, NI>(a, acc, m0 + mw, nbase, lane, z);
+  } else {
+    // MFMA-side coordinates (LDS write) and row-contiguous coordinates (LDS read, global access)
+    const int wr_row = lane & 15, wr_g = lane >> 4;
+    const int rd_row = lane >> 3, rd_c = lane & 7;       // rows rd_row, rd_row + 8; columns 8 rd_c .. +7
+    char* wr_base = stage + wr_row * 256;
+    const char* rd_base0 = stage + rd_row * 256;
+    const char* rd_base1 = stage + (rd_row + 8) * 256;
+    const int rd_sw0 = ((2 * rd_c) ^ rd_row) << 4, rd_sw1 = ((2 * rd_c) ^ (rd_row + 8)) << 4;  // chunk c0; c0+1 = ^16
+
+    const bool cv = nbase < a.N;            // wave-uniform: N % 128 == 0 and a wave spans 64 columns
+    const long rows = a.M - m0;             // rows of C from the tile's first row on (> 0)
+    const int col = nbase + 8 * rd_c;       // lane's first column
+    const int rt = mw + rd_row;             // lane's first row inside the tile (i = 0, h = 0)
+    float bs[8];
+    {
+      const __amdgpu_buffer_rsrc_t rsB = epi_rsrc(a.bias, (long)a.N * 2);   // empty if absent -> zeros
+      bf16x8 b = ld_bf16x8(rsB, cv ? col * 2 : EPI_OOB);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] += bf2f(b[j]);
+      for (int e = 0; e < 8; ++e) bs[e] = bf2f(b[e]);
+    }
+    auto tile_rsrc = [&](const void* p, long ld, int es) {
+      return epi_rsrc(p ? (const char*)p + (long)m0 * ld * es : nullptr, ((rows - 1) * ld + a.N) * es);
+    };
+    auto lane_off = [&](long ld, int es) { return cv ? (int)((rt * ld + col) * es) : EPI_OOB; };
+    // acc group i -> LDS -> v[h][0..7] = (acc + bias) of row 16 i + rd_row + 8 h, columns col .. col + 7
+    auto transpose = [&](int i, float (&v)[2][8]) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(wr_base + (((4 * j + wr_g) ^ wr_row) << 4)) = acc[i][j];
+      asm volatile("" ::: "memory");   // same wave, LDS executes in order: no barrier, just no compiler reordering
+      f32x4 q[2][2];
+      q[0][0] = *(const f32x4*)(rd_base0 + rd_sw0);
+      q[0][1] = *(const f32x4*)(rd_base0 + (rd_sw0 ^ 16));
+      q[1][0] = *(const f32x4*)(rd_base1 + rd_sw1);
+      q[1][1] = *(const f32x4*)(rd_base1 + (rd_sw1 ^ 16));
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[h][e] = q[h][e >> 2][e & 3] + bs[e];
+    };
+
+    if constexpr (EPI == EPI_BF16) {
+      const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2);
+      int oc = lane_off(a.ldc, 2);
+      const int s8 = (int)(8 * a.ldc * 2);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8) {
+        float v[2][8];
+        transpose(i, v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(v[h][e]);
+          st_bf16x8(o, rsC, oc + h * s8);
+        }
+      }
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU) {
+      const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsC2 = tile_rsrc(a.C2, a.ldc2, 2);
+      int oc = lane_off(a.ldc, 2), oc2 = lane_off(a.ldc2, 2);
+      const int s8 = (int)(8 * a.ldc * 2), t8 = (int)(8 * a.ldc2 * 2);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8, oc2 += 2 * t8) {
+        float v[2][8];
+        transpose(i, v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 pre, act;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pre[e] = f2bf(v[h][e]);
+            float x = bf2f(pre[e]);
+            act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
+          }
+          st_bf16x8(pre, rsC, oc + h * s8);    // empty descriptor when the pre-activation is not wanted
+          st_bf16x8(act, rsC2, oc2 + h * t8);
+        }
+      }
+    } else if constexpr (EPI == EPI_GATE_RES) {
+      // y = bf16(acc+bias); x_out = x_in + float(bf16(gate*y))   (sit.py:134-135 under bf16 autocast)
+      const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 4), rsR = tile_rsrc(a.R, a.ldr, 4),
+                                   rsY = tile_rsrc(a.C2, a.ldc2, 2);
+      const long grows = (a.M + a.rows_per_gate - 1) / a.rows_per_gate;
+      const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(a.gate, ((grows - 1) * a.ldgate + a.N) * 2);
+      int oc = lane_off(a.ldc, 4), orr = lane_off(a.ldr, 4), oy = lane_off(a.ldc2, 2);
+      const int s8 = (int)(8 * a.ldc * 4), r8 = (int)(8 * a.ldr * 4), y8 = (int)(8 * a.ldc2 * 2);
+      // gate row of a 16-row group: scalar walk when groups cannot straddle gate rows, per-lane division otherwise
+      const bool gfast = (a.rows_per_gate & 15) == 0;
+      int grow = (m0 + mw) / a.rows_per_gate;
+      int grem = (m0 + mw) - grow * a.rows_per_gate;
+      const int og = cv ? col * 2 : EPI_OOB;
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8, orr += 2 * r8, oy += 2 * y8) {
+        int gso = 0;
+        if (gfast) {
+          gso = grow * (int)a.ldgate * 2;
+          grem += 16;
+          if (grem >= a.rows_per_gate) { grem -= a.rows_per_gate; ++grow; }
+        }
+        // operand loads first (they do not depend on the accumulators), then the LDS round trip
+        bf16x8 g[2];
+        f32x4 xin[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int gvo = og;
+          if (!gfast) gvo = cv ? (int)(((long)((m0 + rt + 16 * i + 8 * h) / a.rows_per_gate) * a.ldgate + col) * 2) : EPI_OOB;
+          g[h] = ld_bf16x8(rsG, gvo, gso);
+          xin[h][0] = ld_f32x4(rsR, orr + h * r8);
+          xin[h][1] = ld_f32x4(rsR, orr + h * r8 + 16);
+        }
+        float v[2][8];
+        transpose(i, v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 y;
+          f32x4 xo[2];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            y[e] = f2bf(v[h][e]);
+            xo[e >> 2][e & 3] = xin[h][e >> 2][e & 3] + bfround(bf2f(g[h][e]) * bf2f(y[e]));
+          }
+          st_bf16x8(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
+          st_f32x4(xo[0], rsC, oc + h * s8);
+          st_f32x4(xo[1], rsC, oc + h * s8 + 16);
+        }
+      }
+    } else {  // EPI_DGELU / EPI_DSILU
+      const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsR = tile_rsrc(a.R, a.ldr, 2);
+      int oc = lane_off(a.ldc, 2), orr = lane_off(a.ldr, 2);
+      const int s8 = (int)(8 * a.ldc * 2), r8 = (int)(8 * a.ldr * 2);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8, orr += 2 * r8) {
+        bf16x8 pre[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pre[h] = ld_bf16x8(rsR, orr + h * r8);
+        float v[2][8];
+        transpose(i, v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float du = bfround(v[h][e]);
+            float x = bf2f(pre[h][e]);
+            o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
+          }
+          st_bf16x8(o, rsC, oc + h * s8);
+        }
+      }
+    }
   }
-  if constexpr (EPI == EPI_BF16) {
-    bf16x4 o;
+}
+
+// fp32-output epilogues (weight gradients, accumulating variants): plain pointers, guarded per row / column group.
+template <int EPI, int NI>
+__device__ __forceinline__ void tile_epilogue_ptr(const GemmArgs& a, const f32x4 (&acc)[NI][4], int mbase, int nbase,
+                                                  int lane, int z) {
+  const int lr = lane & 15, lc = 4 * (lane >> 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-    *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
-  } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU) {
-    bf16x4 pre, act;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      pre[j] = f2bf(v[j]);
-      float x = bf2f(pre[j]);
-      act[j] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
-    }
-    if (a.C) *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = pre;
-    *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = act;
-  } else if constexpr (EPI == EPI_GATE_RES) {
-    // y = bf16(acc+bias); x_out = x_in + float(bf16(gate*y))   (sit.py:134-135 under bf16 autocast)
-    const bf16* gp = a.gate + (long)(m / a.rows_per_gate) * a.ldgate + n;
-    bf16x4 g = *(const bf16x4*)gp;
-    f32x4 xin = *(const f32x4*)((const float*)a.R + (long)m * a.ldr + n);
-    bf16x4 y;
-    f32x4 xo;
+  for (int i = 0; i < NI; ++i) {
+    const int m = mbase + 16 * i + lr;
+    if (m >= a.M) continue;
+    const long rc = (long)m * a.ldc;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      y[j] = f2bf(v[j]);
-      xo[j] = xin[j] + bfround(bf2f(g[j]) * bf2f(y[j]));
-    }
-    if (a.C2) *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = y;
-    *(f32x4*)((float*)a.C + (long)m * a.ldc + n) = xo;
-  } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DSILU) {
-    bf16x4 pre = *(const bf16x4*)((const bf16*)a.R + (long)m * a.ldr + n);
-    bf16x4 o;
+      const int n = nbase + 16 * j + lc;
+      if (n >= a.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (a.bias) {
+        bf16x4 b = *(const bf16x4*)(a.bias + n);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float du = bfround(v[j]);
-      float x = bf2f(pre[j]);
-      o[j] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
-    }
-    *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
-  } else if constexpr (EPI == EPI_F32) {
-    float* cp = (float*)a.C + (long)z * a.slab_stride + (long)m * a.ldc + n;
-    f32x4 o = {v[0], v[1], v[2], v[3]};
-    if (a.accumulate) {
-      f32x4 old = *(const f32x4*)cp;
-      o += old;
-    }
-    *(f32x4*)cp = o;
-  } else if constexpr (EPI == EPI_ADDF32_RB) {
-    float* cp = (float*)a.C + (long)m * a.ldc + n;
-    f32x4 old = *(const f32x4*)cp;
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(b[e]);
+      }
+      if constexpr (EPI == EPI_F32) {
+        float* cp = (float*)a.C + (long)z * a.slab_stride + rc + n;
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (a.accumulate) {
+          f32x4 old = *(const f32x4*)cp;
+          o += old;
+        }
+        *(f32x4*)cp = o;
+      } else if constexpr (EPI == EPI_ADDF32_RB) {
+        float* cp = (float*)a.C + rc + n;
+        f32x4 old = *(const f32x4*)cp;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) old[j] += bfround(v[j]);
-    *(f32x4*)cp = old;
-  } else if constexpr (EPI == EPI_ATOMIC_F32) {
-    float* cp = (float*)a.C + (long)m * a.ldc + n;
+        for (int e = 0; e < 4; ++e) old[e] += bfround(v[e]);
+        *(f32x4*)cp = old;
+      } else {  // EPI_ATOMIC_F32
+        float* cp = (float*)a.C + rc + n;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(cp + j, v[j]);
+        for (int e = 0; e < 4; ++e) atomicAdd(cp + e, v[e]);
+      }
+    }
   }
 }
 

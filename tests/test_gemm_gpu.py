@@ -165,3 +165,71 @@ def test_gemm_arg_errors(dev):
     out = torch.zeros(128, 100, dtype=torch.bfloat16, device=dev)
     with pytest.raises(RuntimeError, match="multiple of 128"):
         ops.linear_fwd(x, w, None, out)
+
+
+@pytest.mark.parametrize("lay", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(8192, 4608, 128), (9000, 2432, 320), (65536, 1152, 64)])
+def test_many_tiles_persistent(dev, lay, M, N, K):
+    """More 256x256 tiles than CUs: the 256^2 kernel runs persistently (one workgroup per CU walks the tile list, the
+    next tile's loads are issued under the current epilogue). Ragged M/N edges, every tile visited exactly once,
+    and the same numbers as the one-workgroup-per-tile launch (bit-exact)."""
+    from reed_amd import _lib, ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    wq = w if lay == "NT" else w.t().contiguous()   # NN reads the k-strided operand [K, N]
+
+    def run():
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        if lay == "NT":
+            ops.gemm(ops.NT, ops.EPI_BF16, x, wq, M, N, K, out, K, K, N, bias=b)
+        else:
+            ops.gemm(ops.NN, ops.EPI_BF16, x, wq, M, N, K, out, K, N, N, bias=b)
+        return out
+
+    out = run()
+    ref = x.float() @ w.float().t() + b.float()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= ref.abs().max().item() * 2 ** -7, err
+    L = _lib.load()
+    L.reed_gemm_set_persistent(0)
+    try:
+        out1 = run()
+    finally:
+        L.reed_gemm_set_persistent(1)
+    assert torch.equal(out, out1)
+
+
+def test_persistent_fused_epilogues(dev):
+    """gate+residual and gelu epilogues across many persistent tiles (gate rows change inside and across tiles)."""
+    from reed_amd import ops
+    M, N, K, T = 16384, 2304, 128, 64
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    pre_ref = _bf(x.float() @ w.float().t() + b.float())
+    pre = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    act = torch.zeros_like(pre)
+    ops.linear_fwd(x, w, b, pre, epi=ops.EPI_GELU, act_out=act)
+    torch.testing.assert_close(pre.float(), pre_ref.float(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(act.float(), _bf(_gelu(pre.float())).float(), atol=1e-2, rtol=1e-2)
+    gate = _bf(torch.randn(M // T, N, generator=g)).to(dev)
+    xin = torch.randn(M, N, generator=g).to(dev)
+    xout = torch.zeros(M, N, device=dev)
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ops.linear_fwd(x, w, b, xout, epi=ops.EPI_GATE_RES, R=xin, gate=gate, ldgate=gate.stride(0), rows_per_gate=T,
+                   y_out=y)
+    ref = xin + _bf(gate.float().repeat_interleave(T, 0) * y.float()).float()
+    torch.testing.assert_close(y.float(), pre_ref.float(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(xout, ref, atol=1e-5, rtol=1e-5)
+    # rows_per_gate not a multiple of 16: per-lane gate row (slow path)
+    T2 = 40
+    Mr = (M // T2) * T2
+    gate2 = _bf(torch.randn(Mr // T2, N, generator=g)).to(dev)
+    xout2 = torch.zeros(Mr, N, device=dev)
+    ops.linear_fwd(x[:Mr], w, b, xout2, epi=ops.EPI_GATE_RES, R=xin[:Mr], gate=gate2, ldgate=gate2.stride(0),
+                   rows_per_gate=T2, M=Mr, N=N, K=K, ldx=K, ldw=K, ldo=N)
+    ref2 = xin[:Mr] + _bf(gate2.float().repeat_interleave(T2, 0) * pre_ref[:Mr].float()).float()
+    torch.testing.assert_close(xout2, ref2, atol=2e-2, rtol=2e-2)

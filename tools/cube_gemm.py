@@ -16,10 +16,10 @@ def timeit(fn, it=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
 for tile in (128, 256):
-    L.reed_gemm_force_tile(tile); L.reed_gemm_set_prefetch(0)
+    L.reed_gemm_force_tile(tile)
     for name, fn in (("NT", lambda: ops.gemm(ops.NT, ops.EPI_BF16, a, b, n, n, n, ob, n, n, n)),
                      ("NN", lambda: ops.gemm(ops.NN, ops.EPI_BF16, a, b, n, n, n, ob, n, n, n)),
                      ("TN", lambda: ops.gemm(ops.TN, ops.EPI_F32, a, b, n, n, n, of, n, n, n))):
         ms = timeit(fn)
         print(f"tile {tile} {name}: {ms:.4f} ms {2.0*n**3/ms/1e9:7.1f} TF/s", flush=True)
-L.reed_gemm_force_tile(0); L.reed_gemm_set_prefetch(-1)
+L.reed_gemm_force_tile(0)

@@ -23,8 +23,8 @@ for name, (N, K) in shapes.items():
     res = []
     for tile in (128, 256):
         for split in (1, 2, 3, 4, 6, 8):
-            for pf in ((0,) if tile == 128 else (0, 4)):
-                L.reed_gemm_force_tile(tile); L.reed_gemm_set_prefetch(pf)
+            for pf in (0,):
+                L.reed_gemm_force_tile(tile)
                 f = lambda: ops.linear_wgrad(dy, x, out, split_k=split, ws=ws, Mtok=M, N=N, K=K)
                 ms = timeit(f)
                 if ref is None: ref = out.clone()
@@ -33,4 +33,4 @@ for name, (N, K) in shapes.items():
     res.sort()
     print(f"{name} N={N} K={K} M={M}: best " + " | ".join(f"t{t} s{s} pf{p} {ms:.3f}ms {fl/ms/1e9:.0f}TF e={e:.1e}" for ms, t, s, p, e in res[:6]), flush=True)
     print("    worst " + " | ".join(f"t{t} s{s} pf{p} {ms:.3f}ms" for ms, t, s, p, e in res[-3:]), flush=True)
-L.reed_gemm_force_tile(0); L.reed_gemm_set_prefetch(-1)
+L.reed_gemm_force_tile(0)
