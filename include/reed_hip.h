@@ -44,12 +44,6 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
 
 /* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel */
 int reed_gemm_force_tile(int tile);
-/* start-phase stagger of the 256^2 kernel's first round of workgroups, in 10 ns ticks per phase step (8 phases):
- * -1 = default policy, 0 = off (A/B timing) */
-int reed_gemm_set_stagger(int ticks);
-/* persistent scheduling of the 256^2 kernel (one workgroup per CU walks the tile list; next tile's loads are issued
- * under the current tile's epilogue): 1 = on (default), 0 = one workgroup per tile (A/B timing) */
-int reed_gemm_set_persistent(int on);
 
 /* bias gradient: out[n] (+)= sum_m x[m,n], x bf16 [M,N] (row stride ld); ws: caller scratch of
  * reed_colsum_ws_floats(M, N) floats. Deterministic (fixed reduction order). */

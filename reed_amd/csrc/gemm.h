@@ -34,8 +34,6 @@ struct GemmArgs {
   int accumulate;
   int ksplit_len;
   long slab_stride;
-  int persist;  // gemm256: >0 = persistent launch with this many blocks (one per CU)
-  int stagger;  // gemm256: first-round start stagger, 10 ns ticks per phase step (0 = off)
 };
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);

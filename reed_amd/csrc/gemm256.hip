@@ -67,13 +67,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   const int wr = wave >> 2, wc = wave & 3;
 
   const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
-  int tm = 0, tn = 0, z = 0;
-  // virtual block id -> output tile (and K slice).  Persistent launches (a.persist: grid = one block per CU) walk
-  // vb = blockIdx.x, +gridDim.x, ...: the same order the hardware would dispatch a full grid in.
-  auto map_tile = [&](int vb) -> bool {
+  int tm, tn;
+  {
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, so blocks L, L+8, ... share an L2; give
+    // each XCD a contiguous run of tiles, walked in groups of GM tile rows x all tile columns.
     const int nwg = ntm * ntn;
-    if (vb >= nwg) return false;
-    int bid = vb;
+    int bid = blockIdx.x;
     {
       int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
       bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -84,29 +83,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     const int gs = min(ntm - first_m, GM);
     tm = first_m + (bid % per_group) % gs;
     tn = (bid % per_group) / gs;
-    z = blockIdx.y;
-    return true;
-  };
-  int vb = blockIdx.x;
-  if (!map_tile(vb)) return;
-  if (a.stagger > 0 && blockIdx.x < 256) {
-    const long t0 = wall_clock64();
-    const long d = (long)((blockIdx.x >> 3) & 7) * a.stagger;
-    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(16);
   }
-  int m0 = tm * BM2, n0 = tn * BN2;
+  const int z = blockIdx.y;
+  const int m0 = tm * BM2, n0 = tn * BN2;
   const int kbeg = z * a.ksplit_len;
   const int kend = min(a.K, kbeg + a.ksplit_len);
   const int nt = (kend - kbeg + BK2 - 1) / BK2;
 
   __amdgpu_buffer_rsrc_t rsP, rsQ;
-  auto set_rsrc = [&]() {
-    if constexpr (LAY == LAY_TN) rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
-    else rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
-    if constexpr (LAY == LAY_NT) rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
-    else rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
-  };
-  set_rsrc();
+  if constexpr (LAY == LAY_TN) rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
+  else rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
+  if constexpr (LAY == LAY_NT) rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
+  else rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
 
   // loop-invariant per-thread staging offsets
   // (the second staging round of a half-tile is 64 rows (row operand) / 32 rows (tr operand) further down; both
@@ -213,16 +201,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   } while (0)
 
   // One K-tile; BX holds B-nh0(t) on entry, BY receives B-nh1(t); on exit BY holds B-nh0(t+1) (roles swap).
-  // FIRST = 1 for K-tile 0 of an output tile: its successor K-tile 1 was staged completely by the tile prologue, and
-  // the p3 wait may leave `relax_ops` younger vector-memory instructions (the previous tile's epilogue) in flight.
-#define VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-#define KTILE(T, CUR, BX, BY, FIRST)                                                \
+#define KTILE(T, CUR, BX, BY)                                                   \
   do {                                                                          \
     const int t_ = (T);                                                         \
     asm volatile("" : "+v"(S0), "+v"(tA), "+v"(tB), "+v"(rA), "+v"(rB));        \
     /* p0 */                                                                    \
     BARRIER();                                                                  \
-    if (!(FIRST) && t_ + 1 < nt) issueA(t_ + 1, 1, 1 - (CUR));                  \
+    if (t_ + 1 < nt) issueA(t_ + 1, 1, 1 - (CUR));                              \
     loadB((CUR), 1, BY);                                                        \
     MMA(0, 0, A0r, BX);                                                         \
     /* p1 */                                                                    \
@@ -236,11 +221,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     MMA(1, 1, A1r, BY);                                                         \
     /* p3: K-tile t+1 must have landed before its first fragment read */        \
     if (t_ + 1 < nt) {                                                          \
-      if ((FIRST) && relax) {                                                   \
-        if (t_ + 2 < nt) VMCNT(RELAX4); else VMCNT(RELAX0);                     \
-      } else {                                                                  \
-        if (t_ + 2 < nt) VMCNT(4); else VMCNT(0);                               \
-      }                                                                         \
+      if (t_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
     }                                                                           \
     BARRIER();                                                                  \
     if (t_ + 2 < nt) issueA(t_ + 2, 0, (CUR));                                  \
@@ -251,67 +233,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     MMA(1, 0, A1r, BX);                                                         \
   } while (0)
 
-  // Vector-memory instructions return in order, so "K-tile k has landed" is a count of the YOUNGER instructions.
-  // After the first output tile of a persistent block those include the previous tile's epilogue, whose instruction
-  // count is exact (gemm_common.hpp, EpiOps): waiting with that many more outstanding lets its stores drain under
-  // the first K-tiles' MFMAs.  s_waitcnt vmcnt holds 6 bits; capping only makes the wait stricter.
-  constexpr int EOPS = EpiOps<EPI, 8>::value;
-  constexpr int RELAX8 = EOPS < 0 ? 8 : (EOPS + 8 > 63 ? 63 : EOPS + 8);
-  constexpr int RELAX4 = EOPS < 0 ? 4 : (EOPS + 4 > 63 ? 63 : EOPS + 4);
-  constexpr int RELAX0 = EOPS < 0 ? 0 : (EOPS > 63 ? 63 : EOPS);
-  bool relax = false;   // true from the block's second output tile on
-
   bf16x8 A0r[4][2], A1r[4][2], Bp[2][2], Bq[2][2];
-  // prologue DMA of an output tile: K-tiles 0 and 1 complete (8 + 8 instructions per wave)
-  auto issue_prologue = [&]() {
-    if (nt > 0) {
-      issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 0, 0); issueA(0, 1, 0);
-      if (nt > 1) { issueB(1, 0, 1); issueB(1, 1, 1); issueA(1, 0, 1); issueA(1, 1, 1); }
+  if (nt > 0) {
+    // prologue: K-tile 0 complete, K-tile 1 minus its A1 half in flight
+    issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 0, 0); issueA(0, 1, 0);
+    if (nt > 1) {
+      issueB(1, 0, 1); issueB(1, 1, 1); issueA(1, 0, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  };
-  issue_prologue();
-  for (;;) {
-    int t = 0;
-    if (nt > 0) {
-      // K-tile 0 landed: younger = K-tile 1's 8 loads (+ the previous tile's epilogue)
-      if (relax) { if (nt > 1) VMCNT(RELAX8); else VMCNT(RELAX0); }
-      else { if (nt > 1) VMCNT(8); else VMCNT(0); }
-      BARRIER();
-      loadA(0, 0, A0r);
-      loadB(0, 0, Bp);
-      KTILE(0, 0, Bp, Bq, 1);
-      if (nt > 1) KTILE(1, 1, Bq, Bp, 0);
-      t = 2;
-    }
-    for (; t + 1 < nt; t += 2) {
-      KTILE(t, 0, Bp, Bq, 0);
-      KTILE(t + 1, 1, Bq, Bp, 0);
-    }
-    if (t < nt) KTILE(t, 0, Bp, Bq, 0);
-
-    // Persistent blocks: every wave is past the last K-tile's p3 barrier, so all LDS fragment reads of this tile are
-    // done and both K-tile buffers are free: put the NEXT tile's prologue DMA in flight first, then run this tile's
-    // epilogue (HBM-heavy for the fused ones) under it.  Hides workgroup launch + the prologue's load latency.
-    const int em0 = m0, en0 = n0;
-    bool more = false;
-    if (a.persist) {
-      vb += gridDim.x;
-      more = map_tile(vb);
-      if (more) {
-        m0 = tm * BM2;
-        n0 = tn * BN2;
-        set_rsrc();
-        issue_prologue();
-      }
-    }
-    tile_epilogue<EPI, 8>(a, acc, em0, wr * 128, en0 + wc * 64, lane, z, smem + 8 * HT + wave * EPI_STAGE_BYTES);
-    if (!more) break;
-    relax = true;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    BARRIER();
+    loadA(0, 0, A0r);
+    loadB(0, 0, Bp);
   }
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    KTILE(t, 0, Bp, Bq);
+    KTILE(t + 1, 1, Bq, Bp);
+  }
+  if (t < nt) KTILE(t, 0, Bp, Bq);
+
+  // One workgroup per output tile.  (A persistent variant — one workgroup per CU walking the tile list, the next
+  // tile's prologue DMA issued under this epilogue, counted s_waitcnt across tiles — measured equal or slower at every
+  // SiT-XL/2 shape: the hardware's workgroup hand-over already overlaps the store drain with the next launch.)
+  // The epilogue stages through its own 32 KiB of LDS, so it needs no barrier against waves still in their last MFMAs.
+  tile_epilogue<EPI, 8>(a, acc, m0, wr * 128, n0 + wc * 64, lane, z, smem + 8 * HT + wave * EPI_STAGE_BYTES);
 }
 
 template <int LAY, int EPI>
@@ -324,7 +271,6 @@ int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM2) * cdiv(a.N, BN2), splits, 1);
-  if (a.persist) grid = dim3(a.persist, 1, 1);
   REED_KLAUNCH((gemm256_kernel<LAY, EPI>), grid, dim3(512), LDS_BYTES, stream, a);
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -349,8 +295,6 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int g_persist = 1;
-extern "C" int reed_gemm_set_persistent(int on) { g_persist = on; return 0; }
 static int reed_num_cus() {
   static int n = 0;
   if (!n) {
@@ -361,30 +305,24 @@ static int reed_num_cus() {
   }
   return n;
 }
-static int g_stagger = -1;
-extern "C" int reed_gemm_set_stagger(int ticks) { g_stagger = ticks; return 0; }
 
-// Kernel selection, from A/B timing on MI355X at the SiT-XL/2 shapes (tools/bench_gemm.py, tools/wgrad_sweep.py):
-//   NT (forward):  256^2 once the grid fills the chip and N or K is large (qkv, fc1, fc2); the square 1152x1152
-//                  projection stays on the 128^2 kernel (4.5 column tiles, short K).
-//   NN (dgrad):    256^2 whenever the grid fills the chip (with the asm transposing reads it runs at NT speed).
-//   TN (wgrad):    128^2 with wave-quantised split-K (ops.plan_wgrad); the 256^2 TN variant is kept for large
-//                  square problems (forced tile) only.
+// Kernel selection (NT forward / NN dgrad), a round-count model fitted to A/B timing at the SiT-XL/2 shapes for b = 64
+// and 256 per GPU (tools/stagger_sweep.py): the 256^2 kernel does one tile per CU at a time and is ~1.18x faster per
+// flop (half the global->LDS bytes, deeper pipeline); the 128^2 kernel keeps two tiles per CU in flight, which
+// quantises better when the 256^2 grid is only one or two rounds.  Time in units of "one CU, one 128^2 tile":
+//   t256 = ceil(tiles256 / CUs) * 4 / 1.18        t128 = ceil(tiles128 / (2 CUs)) * 2
+// TN (wgrad) stays on the 128^2 kernel with wave-quantised split-K (ops.plan_wgrad); its 256^2 variant is reachable
+// through reed_gemm_force_tile only.
 bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
-  long tiles = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2);
-  if (layout == LAY_NT) return tiles >= 224 && a.K >= 256 && (a.N >= 2048 || a.K >= 2048);
-  if (layout == LAY_NN) return tiles >= 224 && a.K >= 256;
-  return false;  // TN (weight gradients): the 128x128 kernel with wave-quantised split-K wins (tools/wgrad_sweep.py)
+  if (layout == LAY_TN || splits > 1 || a.K < 256) return false;
+  const int ncu = reed_num_cus();
+  const long t256 = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2), t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+  const double c256 = (double)((t256 + ncu - 1) / ncu) * 4.0 / 1.18;
+  const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
+  return c256 < c128;
 }
 
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
-  a.stagger = g_stagger > 0 ? g_stagger : 0;
-  {
-    // persistent launch (one block per CU walking the tile list) whenever there is more than one round of tiles
-    const long nwg = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2);
-    const int ncu = reed_num_cus();
-    a.persist = (g_persist && splits == 1 && nwg > ncu) ? ncu : 0;
-  }
   switch (layout) {
     case LAY_NT: return dispatch256<LAY_NT>(epi, a, splits, stream);
     case LAY_NN: return dispatch256<LAY_NN>(epi, a, splits, stream);

@@ -70,9 +70,8 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int colbase, int ks,
 // The bf16-output epilogues (forward / dgrad paths) are also BRANCH-FREE: raw buffer loads/stores through
 // descriptors based at the tile's first row; rows >= M fall outside num_records (dropped / read as 0 by the
 // hardware range check), a wave whose 64 columns lie beyond N (N % 128 == 0) gets an out-of-range offset, and absent
-// optional operands (bias, pre-activation, y) get an empty descriptor.  A wave therefore issues EXACTLY
-// EpiOps<EPI, NI>::value vector-memory instructions, which the persistent 256^2 kernel relies on to keep this
-// tile's stores in flight under the next tile's first K-tiles (counted s_waitcnt vmcnt).
+// optional operands (bias, pre-activation, y) get an empty descriptor.  A wave issues exactly EpiOps<EPI, NI>::value
+// vector-memory instructions whatever the tile's position (tools/isa_loops.py checks the count in the ISA).
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -140,6 +139,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
     auto lane_off = [&](long ld, int es) { return cv ? (int)((rt * ld + col) * es) : EPI_OOB; };
     // acc group i -> LDS -> v[h][0..7] = (acc + bias) of row 16 i + rd_row + 8 h, columns col .. col + 7
     auto transpose = [&](int i, float (&v)[2][8]) {
+      // one row group at a time: without the scheduling fence the compiler interleaves several groups' LDS round
+      // trips, runs out of registers and spills a K-loop value, whose reload costs an s_waitcnt vmcnt(0) per tile
+      __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int j = 0; j < 4; ++j) *(f32x4*)(wr_base + (((4 * j + wr_g) ^ wr_row) << 4)) = acc[i][j];

@@ -169,40 +169,36 @@ def test_gemm_arg_errors(dev):
 
 @pytest.mark.parametrize("lay", ["NT", "NN"])
 @pytest.mark.parametrize("M,N,K", [(8192, 4608, 128), (9000, 2432, 320), (65536, 1152, 64)])
-def test_many_tiles_persistent(dev, lay, M, N, K):
-    """More 256x256 tiles than CUs: the 256^2 kernel runs persistently (one workgroup per CU walks the tile list, the
-    next tile's loads are issued under the current epilogue). Ragged M/N edges, every tile visited exactly once,
-    and the same numbers as the one-workgroup-per-tile launch (bit-exact)."""
-    from reed_amd import _lib, ops
+def test_many_tiles(dev, lay, M, N, K):
+    """Several rounds of tiles per CU, ragged M edge and a half-empty last 256-column tile: every tile written exactly
+    once through the LDS-staged epilogue, and the 128^2 and 256^2 kernels agree bit for bit."""
+    from reed_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
     w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
     b = _bf(torch.randn(N, generator=g)).to(dev)
     wq = w if lay == "NT" else w.t().contiguous()   # NN reads the k-strided operand [K, N]
 
-    def run():
-        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    def run(tile):
+        ops.gemm_force_tile(tile)
+        out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)   # +1 guard row
         if lay == "NT":
             ops.gemm(ops.NT, ops.EPI_BF16, x, wq, M, N, K, out, K, K, N, bias=b)
         else:
             ops.gemm(ops.NN, ops.EPI_BF16, x, wq, M, N, K, out, K, N, N, bias=b)
         return out
 
-    out = run()
+    o128, o256 = run(128), run(256)
+    ops.gemm_force_tile(0)
+    assert torch.isnan(o128[M]).all() and torch.isnan(o256[M]).all()       # nothing written past row M-1
     ref = x.float() @ w.float().t() + b.float()
-    err = (out.float() - ref).abs().max().item()
+    err = (o256[:M].float() - ref).abs().max().item()
     assert err <= ref.abs().max().item() * 2 ** -7, err
-    L = _lib.load()
-    L.reed_gemm_set_persistent(0)
-    try:
-        out1 = run()
-    finally:
-        L.reed_gemm_set_persistent(1)
-    assert torch.equal(out, out1)
+    assert torch.equal(o128[:M], o256[:M])
 
 
-def test_persistent_fused_epilogues(dev):
-    """gate+residual and gelu epilogues across many persistent tiles (gate rows change inside and across tiles)."""
+def test_fused_epilogues_many_tiles(dev):
+    """gate+residual and gelu epilogues over many tiles (gate rows change inside and across tiles)."""
     from reed_amd import ops
     M, N, K, T = 16384, 2304, 128, 64
     g = torch.Generator().manual_seed(5)
