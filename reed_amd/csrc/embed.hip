@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int MAXV = 5;
-constexpr int NSL = 64;  // token slices of the two-stage small-K wgrad
+constexpr int NSL = 256;  // token slices of the two-stage small-K wgrad (one wave each x Dw/128 column blocks)
 
 __device__ __forceinline__ f32x4 ld_bf4(const bf16* p) {
   bf16x4 v = *(const bf16x4*)p;
@@ -68,51 +68,91 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
   }
 }
 
-// ---- small-K weight gradient, stage 1: ws[slice] holds partial out[.] (layout 0: d*KS+k, 1: k*Dw+d),
-//      then partial colsum(wide)[Dw], then partial colsum(small)[KS] ----
-template <bool WIDE_F32>
-__global__ __launch_bounds__(256) void smallk_wgrad_kernel(const void* __restrict__ wide, const bf16* __restrict__ small,
-                                                           float* __restrict__ ws, int M, int Dw, int KS,
-                                                           int layout) {
-  extern __shared__ float sm[];  // [64][KS]
-  const int d = blockIdx.x * 256 + threadIdx.x;
+// ---- small-K weight gradient (final layer: KS = 2*C*p*p = 32, patch embed: KS = C*p*p = 16 at patch 2), stage 1 ----
+// out[d][k] = sum_m wide[m][d] * small[m][k] over a token slice; ws[slice] holds the partial out (layout 0: d*KS+k,
+// 1: k*Dw+d), then the partial colsum(wide)[Dw], then the partial colsum(small)[KS].
+// One wave per block: a lane owns 2 adjacent columns d of `wide` (4- or 8-byte loads: a wave reads a contiguous
+// 256/512-byte row segment) and KSP accumulators for each; small[m][k0 .. k0+KSP) is the same for every lane and comes
+// in as 16-byte broadcast loads.  No LDS, no barriers.  blockIdx.z walks KS in chunks of KSP (KS % 8 == 0).
+template <bool WIDE_F32, int KSP>
+__global__ __launch_bounds__(64) void smallk_wgrad_kernel(const void* __restrict__ wide, const bf16* __restrict__ small,
+                                                          float* __restrict__ ws, int M, int Dw, int KS, int layout) {
+  const int lane = threadIdx.x;
+  const int d = blockIdx.x * 128 + 2 * lane;
   const int slice = blockIdx.y;
+  const int k0 = blockIdx.z * KSP;
   const int per = (M + NSL - 1) / NSL;
   const int mbeg = slice * per, mend = min(M, mbeg + per);
   float* wout = ws + (long)slice * ((long)KS * Dw + Dw + KS);
-  const bool dok = d < Dw;
-  for (int k0 = 0; k0 < KS; k0 += 16) {
-    float acc[16];
+  const bool dok = d < Dw;   // Dw is even
+  float acc0[KSP], acc1[KSP];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    float wsum = 0.f, ssum = 0.f;
-    for (int mc = mbeg; mc < mend; mc += 64) {
-      const int nr = min(64, mend - mc);
-      __syncthreads();
-      for (int i = threadIdx.x; i < nr * KS; i += 256) sm[i] = bf2f(small[(long)mc * KS + i]);
-      __syncthreads();
-      if (blockIdx.x == 0 && threadIdx.x < 16 && k0 + threadIdx.x < KS)
-        for (int r = 0; r < nr; ++r) ssum += sm[r * KS + k0 + threadIdx.x];
-      if (dok) {
-        for (int r = 0; r < nr; ++r) {
-          float wv;
-          if (WIDE_F32) wv = bfround(((const float*)wide)[(long)(mc + r) * Dw + d]);
-          else wv = bf2f(((const bf16*)wide)[(long)(mc + r) * Dw + d]);
-          wsum += wv;
+  for (int k = 0; k < KSP; ++k) acc0[k] = acc1[k] = 0.f;
+  float ws0 = 0.f, ws1 = 0.f;
+  const int dc = dok ? d : 0;
+  const int nch = min(KSP, KS - k0) >> 3;   // valid 8-element chunks of this block's k range (block-uniform)
+  // rows in groups of RG: all loads of a group are issued before its FMAs (a one-wave block has nothing else to hide
+  // the load latency behind)
+  constexpr int RG = KSP == 16 ? 8 : 4;
+  // (the row of `small` is wave-uniform; an opaque zero keeps its address in a VGPR so that the 16-byte broadcast
+  // loads land in VGPRs: as scalar loads RG rows would need 64-128 SGPRs and spill)
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  for (int m = mbeg; m < mend; m += RG) {
+    float w0[RG], w1[RG];
+    bf16x8 sv[RG][KSP / 8];
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (k0 + j < KS) acc[j] += wv * sm[r * KS + k0 + j];
-        }
+    for (int r = 0; r < RG; ++r) {
+      const int mr = min(m + r, mend - 1);          // clamped: the tail rows are masked to zero below
+      if (WIDE_F32) {
+        const float2 v = *(const float2*)((const float*)wide + (long)mr * Dw + dc);
+        w0[r] = bfround(v.x); w1[r] = bfround(v.y);
+      } else {
+        const bf16x2 v = *(const bf16x2*)((const bf16*)wide + (long)mr * Dw + dc);
+        w0[r] = bf2f(v[0]); w1[r] = bf2f(v[1]);
+      }
+      if (m + r >= mend) w0[r] = w1[r] = 0.f;
+      const bf16* srow = small + (long)mr * KS + k0 + vz;
+#pragma unroll
+      for (int c = 0; c < KSP / 8; ++c) {
+        if (c < nch) sv[r][c] = *(const bf16x8*)(srow + 8 * c);
+        else
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sv[r][c][j] = (bf16)0.f;
       }
     }
-    if (dok) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (k0 + j < KS) wout[layout == 0 ? (long)d * KS + k0 + j : (long)(k0 + j) * Dw + d] = acc[j];
-      if (k0 == 0) wout[(long)KS * Dw + d] = wsum;
+    for (int r = 0; r < RG; ++r) {
+      ws0 += w0[r]; ws1 += w1[r];
+#pragma unroll
+      for (int c = 0; c < KSP / 8; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f(sv[r][c][j]);
+          acc0[8 * c + j] = fmaf(w0[r], f, acc0[8 * c + j]);
+          acc1[8 * c + j] = fmaf(w1[r], f, acc1[8 * c + j]);
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < 16 && k0 + threadIdx.x < KS)
-      wout[(long)KS * Dw + Dw + k0 + threadIdx.x] = ssum;
+  }
+  if (dok) {
+#pragma unroll
+    for (int k = 0; k < KSP; ++k)
+      if (k0 + k < KS) {
+        const int kk = k0 + k;
+        if (layout == 0) { wout[(long)d * KS + kk] = acc0[k]; wout[(long)(d + 1) * KS + kk] = acc1[k]; }
+        else { wout[(long)kk * Dw + d] = acc0[k]; wout[(long)kk * Dw + d + 1] = acc1[k]; }
+      }
+    if (blockIdx.z == 0) {
+      wout[(long)KS * Dw + d] = ws0;
+      wout[(long)KS * Dw + d + 1] = ws1;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.z == 0) {
+    for (int k = lane; k < KS; k += 64) {
+      float ssum = 0.f;
+      for (int m = mbeg; m < mend; ++m) ssum += bf2f(small[(long)m * KS + k]);
+      wout[(long)KS * Dw + Dw + k] = ssum;
+    }
   }
 }
 __global__ __launch_bounds__(256) void smallk_reduce_kernel(const float* __restrict__ ws, long stride,
@@ -308,13 +348,17 @@ extern "C" int reed_smallk_wgrad(const void* wide, int wide_is_f32, const void* 
                                  float* colsum_wide, float* colsum_small, int M, int Dw, int KS, int layout,
                                  int accumulate, void* stream) {
   REED_CHECK_ARG(wide && small && ws, "smallk_wgrad: null pointer");
-  REED_CHECK_ARG(KS >= 1 && KS <= 256, "smallk_wgrad: KS=%d out of range", KS);
-  dim3 grid(cdiv(Dw, 256), NSL);
-  size_t lds = 64 * KS * sizeof(float);
-  if (wide_is_f32)
-    REED_KLAUNCH(smallk_wgrad_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
-  else
-    REED_KLAUNCH(smallk_wgrad_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+  REED_CHECK_ARG(KS >= 8 && KS <= 512 && KS % 8 == 0, "smallk_wgrad: KS=%d must be a multiple of 8 in 8..512", KS);
+  REED_CHECK_ARG(Dw > 0 && Dw % 2 == 0, "smallk_wgrad: Dw=%d must be even", Dw);
+  if (KS <= 16) {
+    dim3 grid(cdiv(Dw, 128), NSL, 1);
+    if (wide_is_f32) REED_KLAUNCH((smallk_wgrad_kernel<true, 16>), grid, dim3(64), 0, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+    else REED_KLAUNCH((smallk_wgrad_kernel<false, 16>), grid, dim3(64), 0, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+  } else {
+    dim3 grid(cdiv(Dw, 128), NSL, cdiv(KS, 32));
+    if (wide_is_f32) REED_KLAUNCH((smallk_wgrad_kernel<true, 32>), grid, dim3(64), 0, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+    else REED_KLAUNCH((smallk_wgrad_kernel<false, 32>), grid, dim3(64), 0, (hipStream_t)stream, wide, (const bf16*)small, ws, M, Dw, KS, layout);
+  }
   REED_LAUNCH_CHECK();
   long n0 = (long)KS * Dw, n1 = Dw, n2 = KS;
   REED_KLAUNCH(smallk_reduce_kernel, dim3(cdiv(n0 + n1 + n2, 256)), dim3(256), 0, (hipStream_t)stream, ws,
