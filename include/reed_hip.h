@@ -70,6 +70,13 @@ int reed_ln_modulate_bwd(const void* dh, const float* x, const float* mean, cons
                          const void* scale, int64_t ldmod, float* dx, float* part, int M, int D,
                          int T, void* stream);
 
+/* the same followed, in the same pass, by the gate backward of the next branch in backward order (the one that
+ * consumes the dx just finished): see reed_gate_bwd for dy / part_g / part_dy. Saves one read of the fp32 dx. */
+int reed_ln_modulate_bwd_gate(const void* dh, const float* x, const float* mean, const float* rstd,
+                              const void* scale, int64_t ldmod, float* dx, float* part, const void* y,
+                              const void* gate, int64_t ldgate, void* dy, float* part_g, float* part_dy,
+                              int M, int D, int T, void* stream);
+
 /* gate backward (sit.py:134-135): dg = bf16(dx); dy = bf16(dg*gate[b]); part[(m/16),:] = sum bf16(dg*y);
  * optional part_dy[(m/16),:] = sum dy  (bias gradient of the linear that produced y, reduce with reed_rowsum_f32) */
 int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,

@@ -86,25 +86,35 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
 }
 
 // 16 rows per block (4 per wave); all 16 rows belong to one sample (T % 16 == 0).
+// GATE: the gate backward of the NEXT branch in backward order (the one that reads the dx this kernel just finished)
+// rides along — dg = bf16(dx_new); dy = bf16(dg*gate); partial sums of bf16(dg*y) and of dy — which saves re-reading
+// the fp32 dx (b*T*D*4 bytes) in a separate pass.
+template <bool GATE>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict__ dh, const float* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const bf16* __restrict__ scale, long ldmod,
-                                                         float* __restrict__ dx, float* __restrict__ part, int M,
-                                                         int D, int T) {
+                                                         float* __restrict__ dx, float* __restrict__ part,
+                                                         const bf16* __restrict__ y, const bf16* __restrict__ gate,
+                                                         long ldgate, bf16* __restrict__ dy, float* __restrict__ part_g,
+                                                         float* __restrict__ part_dy, int M, int D, int T) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][D]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
   const int row0 = blockIdx.x * 16 + wave * 4;
-  const bf16* sc = scale + (long)((blockIdx.x * 16) / T) * ldmod;
+  const long smp = (blockIdx.x * 16) / T;
+  const bf16* sc = scale + smp * ldmod;
   f32x4 s1[MAXV], ps[MAXV], pq[MAXV];
+  f32x4 gv[GATE ? MAXV : 1], pg[GATE ? MAXV : 1], pd[GATE ? MAXV : 1];
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     int idx = lane + 64 * k;
     ps[k] = f32x4{0, 0, 0, 0};
     pq[k] = f32x4{0, 0, 0, 0};
+    if (GATE) { pg[k] = f32x4{0, 0, 0, 0}; pd[k] = f32x4{0, 0, 0, 0}; }
     if (idx < nv) {
       f32x4 a = ld_bf4(sc + idx * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) s1[k][j] = bfround(1.f + a[j]);
+      if (GATE) gv[k] = ld_bf4(gate + smp * ldgate + idx * 4);
     }
   }
   for (int rr = 0; rr < 4; ++rr) {
@@ -137,11 +147,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
         }
       }
     }
-    f32x4 dold[MAXV];
+    f32x4 dold[MAXV], yin[GATE ? MAXV : 1];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
       int idx = lane + 64 * k;
       dold[k] = *(const f32x4*)(dx + (long)row * D + (idx < nv ? idx : 0) * 4);
+      if (GATE) yin[k] = ld_bf4(y + (long)row * D + (idx < nv ? idx : 0) * 4);
     }
     a1 = wave_sum(a1) / D;
     a2 = wave_sum(a2) / D;
@@ -154,6 +165,17 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += r * (gy[k][j] - a1 - xh[k][j] * a2);
         *(f32x4*)dp = o;
+        if (GATE) {
+          f32x4 oy;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dg = bfround(o[j]);
+            oy[j] = dg * gv[k][j];
+            pg[k][j] += bfround(dg * yin[k][j]);
+            pd[k][j] += bfround(oy[j]);
+          }
+          st_bf4(dy + (long)row * D + idx * 4, oy);
+        }
       }
     }
   }
@@ -169,6 +191,24 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
   float* out = part + (long)blockIdx.x * 2 * D;
   for (int i = threadIdx.x; i < 2 * D; i += 256) {
     out[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+  }
+  if (GATE) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) {
+        *(f32x4*)(red + (wave * 2 + 0) * D + idx * 4) = pg[k];
+        *(f32x4*)(red + (wave * 2 + 1) * D + idx * 4) = pd[k];
+      }
+    }
+    __syncthreads();
+    float* og = part_g + (long)blockIdx.x * D;
+    float* od = part_dy + (long)blockIdx.x * D;
+    for (int i = threadIdx.x; i < D; i += 256) {
+      og[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+      od[i] = red[D + i] + red[3 * D + i] + red[5 * D + i] + red[7 * D + i];
+    }
   }
 }
 
@@ -381,8 +421,24 @@ extern "C" int reed_ln_modulate_bwd(const void* dh, const float* x, const float*
   REED_CHECK_ARG(dh && x && mean && rstd && scale && dx && part, "ln_modulate_bwd: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd: T=%d, M=%d must be multiples of 16", T, M);
-  REED_KLAUNCH(ln_mod_bwd_kernel, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
-                     (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, M, D, T);
+  REED_KLAUNCH(ln_mod_bwd_kernel<false>, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
+               (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, (const bf16*)nullptr,
+               (const bf16*)nullptr, 0l, (bf16*)nullptr, (float*)nullptr, (float*)nullptr, M, D, T);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+extern "C" int reed_ln_modulate_bwd_gate(const void* dh, const float* x, const float* mean, const float* rstd,
+                                         const void* scale, int64_t ldmod, float* dx, float* part, const void* y,
+                                         const void* gate, int64_t ldgate, void* dy, float* part_g, float* part_dy,
+                                         int M, int D, int T, void* stream) {
+  REED_CHECK_ARG(dh && x && mean && rstd && scale && dx && part, "ln_modulate_bwd_gate: null pointer");
+  REED_CHECK_ARG(y && gate && dy && part_g && part_dy, "ln_modulate_bwd_gate: null gate operand");
+  REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
+  REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd_gate: T=%d, M=%d must be multiples of 16", T, M);
+  REED_KLAUNCH(ln_mod_bwd_kernel<true>, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
+               (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, (const bf16*)y,
+               (const bf16*)gate, (long)ldgate, (bf16*)dy, part_g, part_dy, M, D, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -251,7 +251,26 @@ class Engine:
                                  self.W("final_layer.linear.weight"), hbuf, dlin, dh, B, T, D, C, P)
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         partF = f32(M // 16, 2, D)
-        ops.ln_modulate_bwd(dh, tp.x_last, tp.meanF, tp.rstdF, mf + 2 * D, Nall, dx, partF, M, D, T)
+        # which projectors fire after block i's output?
+        pending = {j: d for j, d in enumerate(self.tap_depth)}
+
+        def tap_fires(depth_idx):   # a projector backward adds into dx at this depth (between block depth_idx-1 and depth_idx)
+            return any(dj == depth_idx and j in tp.proj for j, dj in pending.items())
+
+        def ln_bwd(dh_, x_, mean_, rstd_, scale_ptr, part_, nxt):
+            """LayerNorm+modulate backward into dx. nxt = index of the block whose MLP-branch gate consumes the finished
+            dx next (or None): its gate backward rides along in the same pass unless a projector tap adds into dx in
+            between. Returns (dy2, pg2, pb) of that block when fused."""
+            if nxt is None or nxt < 0 or tap_fires(nxt + 1):
+                ops.ln_modulate_bwd(dh_, x_, mean_, rstd_, scale_ptr, Nall, dx, part_, M, D, T)
+                return None
+            nb_ = tp.blocks[nxt]
+            dy_, pg_, pb_ = bf(M, D), f32(M // 16, D), f32(M // 16, D)
+            ops.ln_modulate_bwd_gate(dh_, x_, mean_, rstd_, scale_ptr, Nall, dx, part_, nb_.y2,
+                                     mp + 2 * (nxt * 6 * D) + 10 * D, Nall, dy_, pg_, pb_, M, D, T)
+            return dy_, pg_, pb_
+
+        pre = ln_bwd(dh, tp.x_last, tp.meanF, tp.rstdF, mf + 2 * D, partF, self.depth - 1)
         wsf = self.ws(ops.smallk_ws_floats(D, max(self.NO, C * P * P)), dev)
         ops.smallk_wgrad(hbuf, False, dlin, wsf, self.G("final_layer.linear.weight"), None,
                          self.G("final_layer.linear.bias"), M, D, self.NO, 1, acc)
@@ -262,8 +281,6 @@ class Engine:
         del hbuf, dlin, dh
         if self.reducer is not None:
             self.reducer.ready("final")
-        # which projectors fire after block i's output?
-        pending = {j: d for j, d in enumerate(self.tap_depth)}
         dz_by_proj = {}
         if dzs is not None:
             for k, j in enumerate(tp.zs_order):
@@ -275,9 +292,12 @@ class Engine:
             bk = tp.blocks[i]
             b = f"blocks.{i}."
             mb = mp + 2 * (i * 6 * D)
-            # MLP branch
-            pg2, dy2, pb = f32(M // 16, D), bf(M, D), f32(M // 16, D)
-            ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T, part_dy=pb)
+            # MLP branch (its gate backward usually came with the previous LayerNorm backward)
+            if pre is not None:
+                dy2, pg2, pb = pre
+            else:
+                pg2, dy2, pb = f32(M // 16, D), bf(M, D), f32(M // 16, D)
+                ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T, part_dy=pb)
             wsr = self.ws((M // 16 + 63) // 64 * D, dev)
             ops.rowsum_f32(pb, M // 16, self.G(b + "mlp.fc2.bias"), D, acc, ws=wsr)
             self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, bias_done=True)
@@ -286,12 +306,13 @@ class Engine:
             self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev)
             dh2 = dy2  # reuse
             self._dgrad(EPI_BF16, da1, b + "mlp.fc1.weight", M, Hm, D, dh2)
+            # LN2 backward + the attention branch's gate backward in one pass over dx
             pl2 = f32(M // 16, 2, D)
-            ops.ln_modulate_bwd(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, M, D, T)
-            # attention branch
-            pg1, dy1 = f32(M // 16, D), bf(M, D)
-            ops.gate_bwd(dx, bk.y1, mb + 4 * D, Nall, dy1, pg1, M, D, T, part_dy=pb)
-            ops.rowsum_f32(pb, M // 16, self.G(b + "attn.proj.bias"), D, acc, ws=wsr)
+            pg1, dy1, pb1 = f32(M // 16, D), bf(M, D), f32(M // 16, D)
+            ops.ln_modulate_bwd_gate(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, bk.y1, mb + 4 * D, Nall,
+                                     dy1, pg1, pb1, M, D, T)
+            ops.rowsum_f32(pb1, M // 16, self.G(b + "attn.proj.bias"), D, acc, ws=wsr)
+            del pb, pb1
             self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, bias_done=True)
             do = bf(M, D)
             self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
@@ -310,7 +331,7 @@ class Engine:
             dh1 = do  # reuse
             self._dgrad(EPI_BF16, dqkv, b + "attn.qkv.weight", M, 3 * D, D, dh1)
             pl1 = f32(M // 16, 2, D)
-            ops.ln_modulate_bwd(dh1, bk.x, bk.mean1, bk.rstd1, mb + 2 * D, Nall, dx, pl1, M, D, T)
+            pre = ln_bwd(dh1, bk.x, bk.mean1, bk.rstd1, mb + 2 * D, pl1, i - 1)
             o6 = i * 6 * D
             p1, p2 = pl1.data_ptr(), pl2.data_ptr()
             ops.reduce_mod_parts([(p1, 2 * D, o6), (p1 + 4 * D, 2 * D, o6 + D), (pg1.data_ptr(), D, o6 + 2 * D),

@@ -147,6 +147,11 @@ def ln_modulate_bwd(dh, x, mean, rstd, scale, ldmod, dx, part, M, D, T):
     _call("reed_ln_modulate_bwd", _p(dh), _p(x), _p(mean), _p(rstd), _p(scale), ldmod, _p(dx), _p(part), M, D, T, _stream())
 
 
+def ln_modulate_bwd_gate(dh, x, mean, rstd, scale, ldmod, dx, part, y, gate, ldgate, dy, part_g, part_dy, M, D, T):
+    _call("reed_ln_modulate_bwd_gate", _p(dh), _p(x), _p(mean), _p(rstd), _p(scale), ldmod, _p(dx), _p(part), _p(y),
+          _p(gate), ldgate, _p(dy), _p(part_g), _p(part_dy), M, D, T, _stream())
+
+
 def gate_bwd(dx, y, gate, ldgate, dy, part, M, D, T, part_dy=None):
     _call("reed_gate_bwd", _p(dx), _p(y), _p(gate), ldgate, _p(dy), _p(part), _p(part_dy), M, D, T, _stream())
 

@@ -72,6 +72,42 @@ def test_gate_bwd(dev):
     torch.testing.assert_close(part.view(B, T // 16, D).sum(1), ref, atol=1e-3, rtol=1e-4)
 
 
+def test_ln_bwd_with_gate_matches_two_passes(dev):
+    """reed_ln_modulate_bwd_gate == reed_ln_modulate_bwd followed by reed_gate_bwd on the finished dx."""
+    from reed_amd import ops
+    for B, T, D in ((2, 64, 384), (3, 16, 1152)):
+        M = B * T
+        g = torch.Generator().manual_seed(7 + D)
+        x = (torch.randn(M, D, generator=g) * 2).to(dev)
+        scale = (torch.randn(B, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        h = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        ops.ln_modulate_fwd(x, scale, scale, D, h, mean, rstd, M, D, T)
+        dh = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+        dx0 = torch.randn(M, D, generator=g).to(dev)
+        y = torch.randn(M, D, generator=g).to(torch.bfloat16).to(dev)
+        gate = torch.randn(B, 2 * D, generator=g).to(torch.bfloat16).to(dev)[:, D:]
+        # two passes
+        dx_a, part_a = dx0.clone(), torch.empty(M // 16, 2, D, device=dev)
+        dy_a = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+        pg_a, pd_a = torch.empty(M // 16, D, device=dev), torch.empty(M // 16, D, device=dev)
+        ops.ln_modulate_bwd(dh, x, mean, rstd, scale, D, dx_a, part_a, M, D, T)
+        ops.gate_bwd(dx_a, y, gate, 2 * D, dy_a, pg_a, M, D, T, part_dy=pd_a)
+        # one pass
+        dx_b, part_b = dx0.clone(), torch.empty(M // 16, 2, D, device=dev)
+        dy_b = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+        pg_b, pd_b = torch.empty(M // 16, D, device=dev), torch.empty(M // 16, D, device=dev)
+        ops.ln_modulate_bwd_gate(dh, x, mean, rstd, scale, D, dx_b, part_b, y, gate, 2 * D, dy_b, pg_b, pd_b, M, D, T)
+        # same arithmetic; the two instantiations may contract multiply-adds differently (last-bit differences in dx,
+        # hence the odd bf16 rounding flip downstream)
+        torch.testing.assert_close(dx_a, dx_b, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(part_a, part_b, atol=1e-4, rtol=1e-5)
+        assert ((dy_a.float() - dy_b.float()).abs() <= 2 ** -7 * dy_a.float().abs() + 1e-6).all()
+        assert (dy_a != dy_b).float().mean().item() < 1e-3
+        torch.testing.assert_close(pg_a, pg_b, atol=5e-2, rtol=1e-3)
+        torch.testing.assert_close(pd_a, pd_b, atol=5e-2, rtol=1e-3)
+
+
 def test_patch_embed_and_final_layer_index_maps_bit_exact(dev):
     """patchify order (c,pi,pj) on the way in, (pi,pj,c) on the way out, row-major tokens: exact vs the reference."""
     from reed_amd import ops
