@@ -63,8 +63,9 @@ def random_fill(model, seed):
     A.shadow_version = -1
 
 
-TRAFFIC_B256 = None
-TRAFFIC_NOTE = "traffic: PMC pass pending for the r1 kernel set"
+TRAFFIC_B256 = 3.01e9   # bytes per launch of the dominant kernel, rocprofv3 --pmc (profiles/r1_pmc_gemm.txt)
+TRAFFIC_NOTE = ("gemm_kernel<TN> fc1 wgrad (24 % of the step): algorithmic 0.82 GB/launch (dy 0.60 + x 0.15 + 3 fp32 slabs 0.06), "
+                "measured 2.94 GB L2-miss reads (FETCH_SIZE x2, counts Infinity-Cache hits) + 0.064 GB writes")
 
 
 def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):

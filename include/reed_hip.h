@@ -81,7 +81,7 @@ int reed_ln_modulate_bwd_gate(const void* dh, const float* x, const float* mean,
  * optional part_dy[(m/16),:] = sum dy  (bias gradient of the linear that produced y, reduce with reed_rowsum_f32) */
 int reed_gate_bwd(const float* dx, const void* y, const void* gate, int64_t ldgate, void* dy,
                   float* part, float* part_dy, int M, int D, int T, void* stream);
-/* dst bf16 [C,R] = src bf16 [R,C]^T (transposed weight shadow: turns every block dgrad into the NT layout) */
+/* dst bf16 [C,R] = src bf16 [R,C]^T (utility; the training path no longer needs transposed copies) */
 int reed_transpose_bf16(const void* src, void* dst, int R, int C, void* stream);
 /* out[n] (+)= sum_r part[r, n], f32 [R, N], fixed order; ws (optional, cdiv(R,64)*N floats) enables the two-stage
  * path for tall inputs */
