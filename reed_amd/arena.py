@@ -68,6 +68,30 @@ class ArenaLayout:
         e = max(self.seg[n][0] + _align(self.numel(n)) for n in names)
         return b, e
 
+    def update_chunks(self, tap_blocks=()):
+        """[(name, begin, end)] covering [0, n_total) exactly once, in the order the NEXT forward first touches the
+        weights: embedders + the adaLN group (arena start), blocks 0..L-1 with the projectors right after the last
+        block before the earliest tap, final layer + pos_embed. The fused optimiser walks these on its own stream and
+        the forward waits per chunk, so the HBM-bound update of block i+1.. runs under the MFMA-bound forward of
+        blocks ..i."""
+        bk = dict(self.buckets())
+        starts = sorted((r[0], n) for n, r in bk.items())
+        ends = {}
+        for (b0, n), nxt in zip(starts, starts[1:] + [(self.n_total, None)]):
+            ends[n] = (b0, nxt[0])
+        b0, e0 = ends["embed_adaln"]
+        order = [("embed_adaln", 0, e0)]
+        first_tap = min(tap_blocks) if tap_blocks else None   # 1-based depth: projectors read the output of block first_tap-1
+        for i in range(self.depth):
+            if first_tap is not None and i == first_tap and "projectors" in ends:
+                order.append(("projectors",) + ends["projectors"])
+            order.append((f"block{i}",) + ends[f"block{i}"])
+        if "projectors" in ends and not any(n == "projectors" for n, _, _ in order):
+            order.append(("projectors",) + ends["projectors"])
+        order.append(("final",) + ends["final"])
+        assert sum(e - b for _, b, e in order) == self.n_total and all(b % 4 == 0 and e % 4 == 0 for _, b, e in order)
+        return order
+
     def buckets(self):
         """Gradient all-reduce buckets in the order backward finishes them:
         final layer, blocks L-1..0 (projectors fire when their tap block is reached; reported separately),
@@ -92,6 +116,21 @@ class ParamArena:
         self.grad = None
         self.shadow = None
         self.shadow_version = -1
+        # name -> torch.cuda.Event: parameter ranges a fused optimiser step is still rewriting on its own stream
+        # (reed_amd/optim.py, overlap=True). Whoever reads weights waits for the range it needs (Engine.forward,
+        # per block) or for everything (state_dict, EMA forward): wait() / wait_all().
+        self.pending = OrderedDict()
+
+    def wait(self, name):
+        """Order the current stream after the optimiser's update of bucket `name` (no-op when none is in flight)."""
+        ev = self.pending.pop(name, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def wait_all(self):
+        while self.pending:
+            _, ev = self.pending.popitem(last=False)
+            torch.cuda.current_stream().wait_event(ev)
 
     def view(self, buf, name):
         off, shp = self.layout.seg[name]
@@ -110,6 +149,7 @@ class ParamArena:
             self.shadow = torch.empty(self.layout.n_total, dtype=torch.bfloat16, device=self.device)
             self.shadow_version = -1
         if self.shadow_version != self.master._version:
+            self.wait_all()   # an overlapped optimiser step may still be rewriting the master
             ops.cast_bf16(self.master, self.shadow, self.layout.n_total)
             self.shadow_version = self.master._version
         return self.shadow

@@ -212,6 +212,198 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
   }
 }
 
+// Two waves per token row (D % 128 == 0): the one-wave-per-row kernel above needs 288 registers in its GATE form
+// (18 floats of x, dh, dx, y per lane plus six per-column accumulators), i.e. ONE wave per SIMD — a quarter of a CU's
+// load slots — and measured 4.3 TB/s at b = 256 and 2.5 TB/s at b = 32 (one round of 512 four-wave blocks).  Here a
+// row's columns are split between a wave pair, per-lane state halves (<= 128 registers, four waves per SIMD) and the
+// pair exchanges its two row sums (sum gy, sum gy*xhat) through LDS once per row.  Block = 8 waves = 4 row groups x 2
+// halves, 16 rows per block as before, so the per-16-row column partials keep their layout and summation order.
+// A lane owns NF float4 column groups (stride 64 groups) plus TS single columns of the half row's tail, so that no
+// lane idles: D/128 = 4 NF + TS floats per lane (XL 1152: 2 + 1; L 1024: 2 + 0; B 768: 1 + 2; S 384: 0 + 3).
+// All global accesses go through raw buffer descriptors: one SGPR descriptor per array (based at the block's first
+// row), the row as a scalar byte offset, and 2 (NF + TS) per-lane column offsets shared by every array — with plain
+// pointers the compiler keeps a 64-bit VGPR address per array and column group and the GATE form spills.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
+}
+template <int NF, int TS>
+struct HalfRow {
+  static constexpr int NE = 4 * NF + TS, NV = NF + TS;
+  int vo[NV > 0 ? NV : 1];   // column (element) offset of each of the lane's vector / scalar accesses
+  __device__ __forceinline__ HalfRow(int hf, int lane) {
+    const int half0 = hf * 64 * NE;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) vo[k] = half0 + (lane + 64 * k) * 4;
+#pragma unroll
+    for (int t = 0; t < TS; ++t) vo[NF + t] = half0 + 256 * NF + 64 * t + lane;
+  }
+  __device__ __forceinline__ void ld_f32(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] * 4, soff, 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * k + j] = t[j];
+    }
+#pragma unroll
+    for (int t = 0; t < TS; ++t)
+      v[4 * NF + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[NF + t] * 4, soff, 0));
+  }
+  __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const {
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+      __builtin_amdgcn_raw_buffer_store_b128(
+          __builtin_bit_cast(u32x4_t, f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]}), rs, vo[k] * 4, soff, 0);
+#pragma unroll
+    for (int t = 0; t < TS; ++t)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[4 * NF + t]), rs, vo[NF + t] * 4, soff, 0);
+  }
+  __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const {   // bf16 -> f32
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] * 2, soff, 0);
+      v[4 * k + 0] = __builtin_bit_cast(float, t[0] << 16);
+      v[4 * k + 1] = __builtin_bit_cast(float, t[0] & 0xFFFF0000u);
+      v[4 * k + 2] = __builtin_bit_cast(float, t[1] << 16);
+      v[4 * k + 3] = __builtin_bit_cast(float, t[1] & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int t = 0; t < TS; ++t)
+      v[4 * NF + t] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo[NF + t] * 2, soff, 0) << 16);
+  }
+  __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(v[4 * k + j]);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), rs, vo[k] * 2, soff, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < TS; ++t)
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f2bf(v[4 * NF + t])), rs, vo[NF + t] * 2, soff, 0);
+  }
+  // LDS (column partials): plain pointers
+  __device__ __forceinline__ void st_lds(float* p, const float (&v)[NE]) const {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) *(f32x4*)(p + vo[k]) = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+#pragma unroll
+    for (int t = 0; t < TS; ++t) p[vo[NF + t]] = v[4 * NF + t];
+  }
+};
+
+template <bool GATE, int NF, int TS>
+__global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
+    const bf16* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const bf16* __restrict__ scale, long ldmod, float* __restrict__ dx,
+    float* __restrict__ part, const bf16* __restrict__ y, const bf16* __restrict__ gate, long ldgate,
+    bf16* __restrict__ dy, float* __restrict__ part_g, float* __restrict__ part_dy, int M, int T) {
+  using HR = HalfRow<NF, TS>;
+  constexpr int NE = HR::NE, D = 128 * NE;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 groups][2][D], then row sums [4][4][2 halves][2]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row offsets stay in SGPRs
+  const int rg = wave >> 1, hf = wave & 1;
+  const HR hr(hf, lane);
+  float* rsum = red + 8 * D;
+  const long blk0 = (long)blockIdx.x * 16;      // first row of the block
+  const long smp = blk0 / T;
+  const __amdgpu_buffer_rsrc_t rsX = row_rsrc(x + blk0 * D, 16 * D * 4), rsDX = row_rsrc(dx + blk0 * D, 16 * D * 4),
+                               rsDH = row_rsrc(dh + blk0 * D, 16 * D * 2),
+                               rsY = row_rsrc(GATE ? y + blk0 * D : nullptr, 16 * D * 2),
+                               rsDY = row_rsrc(GATE ? dy + blk0 * D : nullptr, 16 * D * 2);
+  // per-sample constants: bf16(1 + scale) and the gate (bf16 values held as f32)
+  float s1[NE], gv[GATE ? NE : 1], ps[NE], pq[NE], pg[GATE ? NE : 1], pd[GATE ? NE : 1];
+  hr.ld_bf(row_rsrc(scale + smp * ldmod, D * 2), 0, s1);
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    s1[e] = bfround(1.f + s1[e]);
+    ps[e] = 0.f;
+    pq[e] = 0.f;
+    if (GATE) { pg[e] = 0.f; pd[e] = 0.f; }
+  }
+  if constexpr (GATE) hr.ld_bf(row_rsrc(gate + smp * ldgate, D * 2), 0, gv);
+#pragma unroll 1
+  for (int rr = 0; rr < 4; ++rr) {
+    const int lr = rg * 4 + rr;      // row inside the block; global row < M: the grid is M / 16 blocks, M % 16 == 0
+    const float mu = mean[blk0 + lr], r = rstd[blk0 + lr];
+    float xh[NE], gy[NE], o[NE], yin[GATE ? NE : 1];
+    hr.ld_f32(rsX, lr * D * 4, xh);   // all of the row's loads first
+    hr.ld_bf(rsDH, lr * D * 2, gy);
+    hr.ld_f32(rsDX, lr * D * 4, o);
+    if constexpr (GATE) hr.ld_bf(rsY, lr * D * 2, yin);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float g = gy[e];
+      const float xv = (xh[e] - mu) * r;
+      xh[e] = xv;
+      gy[e] = g * s1[e];
+      a1 += gy[e];
+      a2 += gy[e] * xv;
+      ps[e] += g;
+      pq[e] += g * xv;
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) *(float2*)(rsum + (lr * 2 + hf) * 2) = make_float2(a1, a2);
+    __syncthreads();
+    {
+      const f32x4 t = *(const f32x4*)(rsum + lr * 4);   // (a1, a2) of half 0, (a1, a2) of half 1
+      a1 = (t[0] + t[2]) / D;
+      a2 = (t[1] + t[3]) / D;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) o[e] += r * (gy[e] - a1 - xh[e] * a2);
+    hr.st_f32(rsDX, lr * D * 4, o);
+    if constexpr (GATE) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const float dg = bfround(o[e]);
+        o[e] = dg * gv[e];
+        pg[e] += bfround(dg * yin[e]);
+        pd[e] += bfround(o[e]);
+      }
+      hr.st_bf(rsDY, lr * D * 2, o);
+    }
+  }
+  // column partials of the 16 rows: per row group in registers, summed over the 4 groups in a fixed order
+  hr.st_lds(red + (rg * 2 + 0) * D, ps);
+  hr.st_lds(red + (rg * 2 + 1) * D, pq);
+  __syncthreads();
+  float* out = part + (long)blockIdx.x * 2 * D;
+  for (int i = threadIdx.x; i < 2 * D; i += 512) out[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+  if constexpr (GATE) {
+    __syncthreads();
+    hr.st_lds(red + (rg * 2 + 0) * D, pg);
+    hr.st_lds(red + (rg * 2 + 1) * D, pd);
+    __syncthreads();
+    float* og = part_g + (long)blockIdx.x * D;
+    float* od = part_dy + (long)blockIdx.x * D;
+    for (int i = threadIdx.x; i < D; i += 512) {
+      og[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+      od[i] = red[D + i] + red[3 * D + i] + red[5 * D + i] + red[7 * D + i];
+    }
+  }
+}
+
+// D -> (NF, TS) instantiation; returns false when D has none (the caller falls back to the one-wave-per-row kernel)
+template <bool GATE>
+bool launch_ln_mod_bwd2(hipStream_t stream, const bf16* dh, const float* x, const float* mean, const float* rstd,
+                        const bf16* scale, long ldmod, float* dx, float* part, const bf16* y, const bf16* gate,
+                        long ldgate, bf16* dy, float* part_g, float* part_dy, int M, int D, int T) {
+#define REED_LNB2(NF_, TS_)                                                                                          \
+  if (D == 128 * (4 * NF_ + TS_)) {                                                                                   \
+    REED_KLAUNCH((ln_mod_bwd2_kernel<GATE, NF_, TS_>), dim3(M / 16), dim3(512), (8 * D + 64) * sizeof(float),  \
+                       stream, dh, x, mean, rstd, scale, ldmod, dx, part, y, gate, ldgate, dy, part_g, part_dy, M, T); \
+    return true;                                                                                                      \
+  }
+  REED_LNB2(0, 1) REED_LNB2(0, 2) REED_LNB2(0, 3) REED_LNB2(1, 0) REED_LNB2(1, 2) REED_LNB2(2, 0) REED_LNB2(2, 1)
+#undef REED_LNB2
+  return false;
+}
+
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y,
                                                        const bf16* __restrict__ gate, long ldgate,
                                                        bf16* __restrict__ dy, float* __restrict__ part,
@@ -421,9 +613,14 @@ extern "C" int reed_ln_modulate_bwd(const void* dh, const float* x, const float*
   REED_CHECK_ARG(dh && x && mean && rstd && scale && dx && part, "ln_modulate_bwd: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd: T=%d, M=%d must be multiples of 16", T, M);
-  REED_KLAUNCH(ln_mod_bwd_kernel<false>, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
-               (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, (const bf16*)nullptr,
-               (const bf16*)nullptr, 0l, (bf16*)nullptr, (float*)nullptr, (float*)nullptr, M, D, T);
+  if (launch_ln_mod_bwd2<false>((hipStream_t)stream, (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx,
+                                part, nullptr, nullptr, 0l, nullptr, nullptr, nullptr, M, D, T)) {
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
+    REED_KLAUNCH(ln_mod_bwd_kernel<false>, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
+                 (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, (const bf16*)nullptr,
+                 (const bf16*)nullptr, 0l, (bf16*)nullptr, (float*)nullptr, (float*)nullptr, M, D, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -436,9 +633,14 @@ extern "C" int reed_ln_modulate_bwd_gate(const void* dh, const float* x, const f
   REED_CHECK_ARG(y && gate && dy && part_g && part_dy, "ln_modulate_bwd_gate: null gate operand");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd_gate: T=%d, M=%d must be multiples of 16", T, M);
-  REED_KLAUNCH(ln_mod_bwd_kernel<true>, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
-               (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, (const bf16*)y,
-               (const bf16*)gate, (long)ldgate, (bf16*)dy, part_g, part_dy, M, D, T);
+  if (launch_ln_mod_bwd2<true>((hipStream_t)stream, (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx,
+                               part, (const bf16*)y, (const bf16*)gate, (long)ldgate, (bf16*)dy, part_g, part_dy, M, D, T)) {
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
+    REED_KLAUNCH(ln_mod_bwd_kernel<true>, dim3(M / 16), dim3(256), 8 * D * sizeof(float), (hipStream_t)stream,
+                 (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx, part, (const bf16*)y,
+                 (const bf16*)gate, (long)ldgate, (bf16*)dy, part_g, part_dy, M, D, T);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

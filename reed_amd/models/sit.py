@@ -166,6 +166,7 @@ class SiT(nn.Module):
         self._engine = None
 
     def _apply(self, fn, recurse=True):
+        self._arena.wait_all()
         new_master = fn(self._arena.master)
         if new_master.dtype != torch.float32:
             raise TypeError("reed_amd.SiT keeps fp32 master weights (bf16 compute copies are internal), as the "
@@ -179,6 +180,7 @@ class SiT(nn.Module):
 
     def __deepcopy__(self, memo):
         import copy
+        self._arena.wait_all()
         eng, self._engine = self._engine, None
         try:
             new = self.__class__.__new__(self.__class__)
@@ -261,6 +263,14 @@ class SiT(nn.Module):
         assert h * w == x.shape[1]
         x = x.reshape(x.shape[0], h, w, p, p, c).permute(0, 5, 1, 3, 2, 4)
         return x.reshape(x.shape[0], c, h * p, w * p)
+
+    def state_dict(self, *args, **kwargs):
+        self._arena.wait_all()   # an overlapped optimiser step (reed_amd/optim.py) may still be writing the arena
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._arena.wait_all()
+        return super().load_state_dict(*args, **kwargs)
 
     def engine(self):
         if self._engine is None:

@@ -2,6 +2,8 @@
 image/train.py:402-412 (accelerator.clip_grad_norm_, torch.optim.AdamW.step, zero_grad, update_ema) with three
 HIP launches and no host synchronisation (the gradient norm stays on the device until someone asks for it).
 """
+import os
+
 import torch
 
 from . import ops
@@ -11,8 +13,17 @@ _NB = 2048  # partial-sum blocks of the squared-norm reduction
 
 class FusedAdamWEMA:
     def __init__(self, model, ema=None, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8,
-                 max_grad_norm=1.0, ema_decay=0.9999):
+                 max_grad_norm=1.0, ema_decay=0.9999, overlap=False):
+        """overlap=True: the update runs on the optimiser's own HIP stream, one launch per parameter bucket in the
+        order the next forward touches them (ArenaLayout.update_chunks), each followed by an event that the forward
+        waits for just before the first kernel that reads the bucket. The pass is HBM-bound (38 B/param), the
+        forward MFMA-bound, so the two overlap; at b = 32/GPU it also fills the CUs that one-round GEMM grids leave
+        idle. Readers other than the model forward (state_dict, EMA sampling, torch ops on p.data) are ordered by
+        model.state_dict() / Engine.forward / flush()."""
         self.model, self.ema = model, ema
+        self.overlap = bool(overlap) and os.environ.get("REED_OPT_OVERLAP", "1") != "0"
+        self._stream = None
+        self._chunks = None
         self.lr, self.betas, self.weight_decay, self.eps = lr, tuple(betas), weight_decay, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.step_count = 0
@@ -51,11 +62,42 @@ class FusedAdamWEMA:
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
         ema_buf = self.ema._arena.master if self.ema is not None else None
-        ops.adamw_ema(A.master, A.grad, self.exp_avg, self.exp_avg_sq, ema_buf, A.shadow, L.n_train, L.n_total, nc,
-                      self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay)
+        if not self.overlap:
+            ops.adamw_ema(A.master, A.grad, self.exp_avg, self.exp_avg_sq, ema_buf, A.shadow, L.n_train, L.n_total, nc,
+                          self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay)
+        else:
+            A.wait_all()
+            main = torch.cuda.current_stream()
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=A.master.device)
+                eng = m.engine()
+                self._chunks = L.update_chunks(list(eng.tap_depth) if m.z_dims else ())
+            side = self._stream
+            side.wait_stream(main)  # grads, clip coefficient
+            pp, gp, sp = A.master.data_ptr(), A.grad.data_ptr(), A.shadow.data_ptr()
+            mp, vp = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+            ep = ema_buf.data_ptr() if ema_buf is not None else None
+            ev = None
+            with torch.cuda.stream(side):
+                for name, b, e in self._chunks:
+                    nt = max(0, min(e, L.n_train) - b)
+                    ops.adamw_ema(pp + 4 * b, gp + 4 * b if nt else None, mp + 4 * b if nt else None,
+                                  vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + 2 * b, nt,
+                                  e - b, nc, self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    A.pending[name] = ev
+            if self.ema is not None:
+                self.ema._arena.pending["all"] = ev
         A.mark_shadow_fresh()
         if self.ema is not None:
             self.ema._arena.shadow_version = -1  # EMA master changed behind torch's back: re-cast on next use
+
+    def flush(self):
+        """Order the current stream after an overlapped update (before reading parameters / EMA with torch ops)."""
+        self.model._arena.wait_all()
+        if self.ema is not None:
+            self.ema._arena.wait_all()
 
     def zero_grad(self, set_to_none=True):
         """The next backward overwrites the gradient arena (no memset needed)."""
@@ -67,6 +109,7 @@ class FusedAdamWEMA:
 
     # ---- checkpoint compatibility with torch.optim.AdamW.state_dict() (train.py:423) ----
     def state_dict(self):
+        self.flush()
         L = self.model._layout
         state, idx = {}, []
         for i, (name, p) in enumerate(self.model.named_parameters()):

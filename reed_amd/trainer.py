@@ -2,6 +2,8 @@
 backward, clip, AdamW, EMA) on the HIP path, without per-step host synchronisation: every returned scalar is a
 device tensor; call .item() only when logging.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -55,6 +57,8 @@ class TrainStep:
                  diffusion_decay="constant", max_train_steps=400000, latents_scale=0.18215, latents_bias=0.0,
                  grad_accum=1):
         self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
+        if hasattr(optimizer, "overlap") and os.environ.get("REED_OPT_OVERLAP", "1") != "0":
+            optimizer.overlap = True   # the step is always followed by a forward (or by flush()/state_dict())
         self.proj_coeff = proj_coeff
         self.sched = (repa_decay, repa_steps, start_diffusion_steps, diffusion_warm_up_steps, diffusion_decay,
                       max_train_steps)

@@ -264,3 +264,23 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_update_chunks_cover_arena_in_forward_order():
+    """ArenaLayout.update_chunks (overlapped optimiser): the chunks tile [0, n_total) exactly once, start with the
+    embedders + adaLN group, visit the blocks in forward order with the projectors right behind the tap block, and end
+    with the final layer (+ the frozen pos_embed, which only the EMA pass touches)."""
+    from reed_amd.models.sit import SiT
+    m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=4, num_heads=2, num_classes=10, z_dims=[128],
+            z_types=["i"], encoder_depth=2, projector_dim=128)
+    L = m._layout
+    ch = L.update_chunks([2])
+    names = [n for n, _, _ in ch]
+    assert names == ["embed_adaln", "block0", "block1", "projectors", "block2", "block3", "final"]
+    spans = sorted((b, e) for _, b, e in ch)
+    assert spans[0][0] == 0 and spans[-1][1] == L.n_total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    bk = dict(L.buckets())
+    for n, b, e in ch:   # every chunk contains its all-reduce bucket
+        assert b <= bk[n][0] and bk[n][1] <= e
+    assert L.update_chunks(()) [-1][0] == "final"

@@ -14,7 +14,7 @@ def bfr(x):
     return x.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("B,T,D", [(2, 256, 1152), (3, 16, 128), (1, 64, 384), (2, 32, 1024)])
+@pytest.mark.parametrize("B,T,D", [(2, 256, 1152), (3, 16, 128), (1, 64, 384), (2, 32, 1024), (1, 64, 768), (1, 16, 1280)])
 def test_ln_modulate_fwd_bwd(dev, B, T, D):
     from reed_amd import ops
     g = torch.Generator().manual_seed(D + T)

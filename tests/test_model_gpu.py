@@ -167,3 +167,50 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
     assert (d_fp32 <= np.maximum(2e-3, 1.5 * ref_gap)).all(), (d_fp32, ref_gap)  # vs fp32: the reference's own bf16 gap
     np.testing.assert_allclose(rec["grad_norm"], g["bf16.grad_norm"], rtol=3e-2)
     np.testing.assert_allclose(rec["proj_loss"], g["bf16.proj_loss"], atol=2e-3)
+
+
+def test_wgrad_side_stream_bit_identical(dev):
+    """The blocks' weight-gradient GEMMs on the second HIP stream (engine.wgrad_stream) are the same launches in a
+    different interleaving: every gradient must be bit-identical to the single-stream backward, also when the step is
+    repeated (buffers recycled by the caching allocator while the side stream is still reading would show up here)."""
+    from reed_amd.loss import SILoss
+    c = TINY_CASES["xl3"]   # hd 72, 16 heads, D 1152: the XL block shape
+    cfg = c["cfg"]
+    T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 5, c["zspec"], T, cfg["num_classes"])
+    drop = drop_u < cfg["class_dropout_prob"]
+    grads = {}
+    for mode in (False, True):
+        m = build_hip_model(cfg, dev, 5)
+        m.train()
+        m.force_drop_mask = drop
+        m.engine().wgrad_stream = mode
+        lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
+        for _ in range(3):
+            for p in m.parameters():
+                p.grad = None
+            m.engine().zero_grad()
+            out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+            (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+        torch.cuda.synchronize()
+        grads[mode] = m._arena.grad.clone()
+    assert torch.equal(grads[False], grads[True])
+
+
+def test_overlapped_optimizer_bit_identical(dev):
+    """FusedAdamWEMA(overlap=True): per-bucket update launches on the optimiser's own stream with the next forward
+    waiting per bucket. Same arithmetic, different schedule -> master weights, EMA and the bf16 shadow after 4 steps
+    must equal the single-launch optimiser bit for bit (a forward that read a bucket before its update landed, or an
+    update overtaking a backward still writing gradients, would show up here)."""
+    res = {}
+    for overlap in (False, True):
+        m, ema, opt, lf = _hip_trainer("SiT-S/2", dict(z_dims=[128], z_types=["i"], encoder_depth=4, projector_dim=256),
+                                       dev, ["dinov2"], [1.0], seed=2)
+        opt.overlap = overlap
+        _run_traj(m, opt, lf, dev, 8, 4, [(128, "i")], True)
+        sd = m.state_dict()   # orders the current stream after the pending update
+        ema.state_dict()
+        torch.cuda.synchronize()
+        res[overlap] = (m._arena.master.clone(), ema._arena.master.clone(), m._arena.shadow.clone(), sd)
+    for a, b in zip(res[False][:3], res[True][:3]):
+        assert torch.equal(a, b)
