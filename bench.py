@@ -208,6 +208,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(None, labels, zs, moments=moments)
+    t_enq = time.perf_counter() - t0    # host time to enqueue the K steps (the GPU runs behind; no sync inside a step)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -229,6 +230,7 @@ def main():
                                    "(fwd+bwd+clip+AdamW+EMA), bf16 MFMA / fp32 master",
                        "global_batch": args.global_batch, "local_batch": b, "parallelism": f"dp{world}"},
             "final_loss": round(loss_val, 5),
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
         }
         rows = None

@@ -16,6 +16,8 @@
 // Backward recomputes P from the saved log-sum-exp and is split in two deterministic phases inside
 // one workgroup (no atomics): phase 1 gives each wave 32 query rows (dQ), phase 2 gives each wave
 // 32 key rows (dK, dV); Q, K, V, dO stay resident in LDS (147 KiB) for both.
+#include <stdlib.h>
+
 #include "../../include/reed_hip.h"
 #include "common.hpp"
 
@@ -105,17 +107,27 @@ __device__ __forceinline__ bf16x8 pack2(f32x4 a, f32x4 b) {
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  One (batch, head) reads 144-byte (hd 72) or
+// 128-byte pieces of every token row of qkv, so the cache lines it touches are shared with the neighbouring heads of
+// the same token: give each XCD a contiguous run of (batch, head) pairs, so that the 16 heads of a sample run on one
+// XCD at about the same time and the shared lines (and the partial-line dqkv writes) meet in that L2.
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+  const int xcd = bid & 7, q = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                       float* __restrict__ lse, int B, int T, int H) {
+                                                       float* __restrict__ lse, int B, int T, int H, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int D = H * HD;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bh = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = bh / H, h = bh % H;
   const long tok = 3l * D;
   const bf16* base = qkv + (long)b * T * tok + h * HD;
   char* Kt = smem;
@@ -136,8 +148,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
   for (int kv0 = 0; kv0 < T; kv0 += 256) {
     __syncthreads();
     const int rows = min(256, T - kv0);
+    if (dbg != 2) {
     load_tile<HD>(Kt, base + (long)kv0 * tok + D, tok, rows, tid, 512);
     load_tile<HD>(Vt, base + (long)kv0 * tok + 2 * D, tok, rows, tid, 512);
+    }
     if (kv0 == 0) {  // Q fragments after the first tile loads: keeps the staging registers and Q from overlapping
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
     }
     __syncthreads();
     if (!active) continue;
-    const int nsub = (rows + 63) >> 6;
+    const int nsub = dbg == 1 ? 0 : (rows + 63) >> 6;
     for (int sub = 0; sub < nsub; ++sub) {
       const int kvs = sub * 64;
       f32x4 st[2][4];
@@ -236,14 +250,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
 template <int HD>
 __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                        const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                       bf16* __restrict__ dqkv, int B, int T, int H) {
+                                                       bf16* __restrict__ dqkv, int B, int T, int H, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int D = H * HD;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int bh = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = bh / H, h = bh % H;
   const long tok = 3l * D;
   const bf16* base = qkv + (long)b * T * tok + h * HD;
   bf16* dbase = dqkv + (long)b * T * tok + h * HD;
@@ -257,10 +272,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
 
+  if (dbg != 2) {
   load_tile<HD>(Qt, base, tok, T, tid, 512);
   load_tile<HD>(Kt, base + D, tok, T, tid, 512);
   load_tile<HD>(Vt, base + 2 * D, tok, T, tid, 512);
   load_tile<HD>(Gt, d_o + (long)b * T * D + h * HD, D, T, tid, 512);
+  }
   {
     // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per row
     const int row = tid >> 1, half = tid & 1;
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = zero4();
-    const int nblk = (T + 31) >> 5;
+    const int nblk = dbg == 1 ? 0 : (T + 31) >> 5;
     for (int kb = 0; kb < nblk; ++kb) {
       const int kv0 = kb * 32;
       f32x4 st[2][2], dp[2][2];
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
-    const int nblk = (T + 31) >> 5;
+    const int nblk = dbg == 1 ? 0 : (T + 31) >> 5;
     for (int qb = 0; qb < nblk; ++qb) {
       const int qq0 = qb * 32;
       f32x4 st[2][2], dp[2][2];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
@@ -444,6 +461,14 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   }
 }
 
+// timing experiments only (tools/time_attn.py): REED_ATTN_DBG=1 skips the MFMA/softmax loops, =2 skips the global->LDS
+// tile loads; results are garbage in both.  Unset (0) in every product run.
+int attn_dbg() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("REED_ATTN_DBG"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 template <typename K>
 int set_lds(K kernel, int bytes) {
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -464,12 +489,12 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
     static int once = set_lds(attn_fwd_kernel<64>, lds);
     if (once) return once;
     REED_KLAUNCH(attn_fwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (bf16*)o, lse, B, T, H);
+                       (bf16*)o, lse, B, T, H, attn_dbg());
   } else {
     static int once = set_lds(attn_fwd_kernel<72>, lds);
     if (once) return once;
     REED_KLAUNCH(attn_fwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (bf16*)o, lse, B, T, H);
+                       (bf16*)o, lse, B, T, H, attn_dbg());
   }
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -486,12 +511,12 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
     static int once = set_lds(attn_bwd_kernel<64>, lds);
     if (once) return once;
     REED_KLAUNCH(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H, attn_dbg());
   } else {
     static int once = set_lds(attn_bwd_kernel<72>, lds);
     if (once) return once;
     REED_KLAUNCH(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H, attn_dbg());
   }
   REED_LAUNCH_CHECK();
   return REED_OK;

@@ -59,31 +59,18 @@ __device__ __forceinline__ int voff_tr(int i, int tid, long ld) {
     asm volatile("" ::: "memory");                         \
   } while (0)
 
-template <int LAY, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// RAGGED = the tile is a last column tile of which only the first 128 columns exist (N = 1152 = 4.5 x 256 for every
+// D-wide output of SiT-XL/2: proj, fc2, and the dgrads of qkv, proj, fc1).  With the regular 2 x 4 wave grid half the
+// waves of such a tile would multiply zeros for the whole K loop; instead the tile is re-dealt: wave (wr, wc) takes
+// the 64-row quadrant (wc >> 1) of its A half-tile and the 64 columns (wc & 1) of B half-tile 0 — a 4 x 4 grid of
+// MFMA tiles per wave, two MFMA phases per K-tile instead of four, same staging, waits and barriers.  The two forms
+// are separate instantiations of the body (disjoint register live ranges), selected per workgroup.
+template <int LAY, int EPI, bool RAGGED>
+__device__ __forceinline__ void gemm256_body(const GemmArgs& a, char* smem, const int tm, const int tn) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
-  int tm, tn;
-  {
-    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, so blocks L, L+8, ... share an L2; give
-    // each XCD a contiguous run of tiles, walked in groups of GM tile rows x all tile columns.
-    const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
-    {
-      int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    constexpr int GM = 4;
-    const int per_group = GM * ntn;
-    const int group = bid / per_group, first_m = group * GM;
-    const int gs = min(ntm - first_m, GM);
-    tm = first_m + (bid % per_group) % gs;
-    tn = (bid % per_group) / gs;
-  }
   const int z = blockIdx.y;
   const int m0 = tm * BM2, n0 = tn * BN2;
   const int kbeg = z * a.ksplit_len;
@@ -138,6 +125,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
   const int rsw = (li >> 1) & 7;
   int rA = aoff + li * 128 + ((lg ^ rsw) << 4);
   int rB = boff + ((wc & 1) * 64 + li) * 128 + ((lg ^ rsw) << 4);
+  if constexpr (RAGGED) {   // A: quadrant (wc >> 1) of half-tile wr; B: columns (wc & 1) * 64 .. of half-tile 0
+    rA += (wc >> 1) * 8192;
+    tA ^= (wc >> 1) << 7;
+    rB -= (wc >> 1) * 2 * HT;
+    tB -= (wc >> 1) * 2 * HT;
+  }
 
   auto loadA = [&](int cur, int mh, bf16x8 (&f)[4][2]) {
     if constexpr (LAY == LAY_TN) {
@@ -183,9 +176,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     }
   };
 
-  f32x4 acc[8][4];
+  constexpr int NI = RAGGED ? 4 : 8;
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -233,7 +227,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     MMA(1, 0, A1r, BX);                                                         \
   } while (0)
 
-  bf16x8 A0r[4][2], A1r[4][2], Bp[2][2], Bq[2][2];
+  // ragged tile: the wave's 64 x 64 piece is the quadrants Q(0,0), Q(0,1) of A0r (= its A quadrant); phases p2 and p3
+  // keep their staging issues, waits and barriers but have no MFMAs
+#define KTILE_R(T, CUR, BX, BY)                                                 \
+  do {                                                                          \
+    const int t_ = (T);                                                         \
+    asm volatile("" : "+v"(S0), "+v"(tA), "+v"(tB), "+v"(rA), "+v"(rB));        \
+    BARRIER();                                                                  \
+    if (t_ + 1 < nt) issueA(t_ + 1, 1, 1 - (CUR));                              \
+    loadB((CUR), 1, BY);                                                        \
+    MMA(0, 0, A0r, BX);                                                         \
+    BARRIER();                                                                  \
+    if (t_ + 2 < nt) issueB(t_ + 2, 0, (CUR));                                  \
+    MMA(0, 1, A0r, BY);                                                         \
+    BARRIER();                                                                  \
+    if (t_ + 2 < nt) issueB(t_ + 2, 1, (CUR));                                  \
+    if (t_ + 1 < nt) {                                                          \
+      if (t_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+    }                                                                           \
+    BARRIER();                                                                  \
+    if (t_ + 2 < nt) issueA(t_ + 2, 0, (CUR));                                  \
+    if (t_ + 1 < nt) {                                                          \
+      loadA(1 - (CUR), 0, A0r);                                                 \
+      loadB(1 - (CUR), 0, BY);                                                  \
+    }                                                                           \
+  } while (0)
+
+  bf16x8 A0r[4][2], A1r[RAGGED ? 1 : 4][2], Bp[2][2], Bq[2][2];
   if (nt > 0) {
     // prologue: K-tile 0 complete, K-tile 1 minus its A1 half in flight
     issueB(0, 0, 0); issueB(0, 1, 0); issueA(0, 0, 0); issueA(0, 1, 0);
@@ -248,17 +269,58 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     loadB(0, 0, Bp);
   }
   int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    KTILE(t, 0, Bp, Bq);
-    KTILE(t + 1, 1, Bq, Bp);
+  if constexpr (!RAGGED) {
+    for (; t + 1 < nt; t += 2) {
+      KTILE(t, 0, Bp, Bq);
+      KTILE(t + 1, 1, Bq, Bp);
+    }
+    if (t < nt) KTILE(t, 0, Bp, Bq);
+  } else {
+    for (; t + 1 < nt; t += 2) {
+      KTILE_R(t, 0, Bp, Bq);
+      KTILE_R(t + 1, 1, Bq, Bp);
+    }
+    if (t < nt) KTILE_R(t, 0, Bp, Bq);
   }
-  if (t < nt) KTILE(t, 0, Bp, Bq);
 
   // One workgroup per output tile.  (A persistent variant — one workgroup per CU walking the tile list, the next
   // tile's prologue DMA issued under this epilogue, counted s_waitcnt across tiles — measured equal or slower at every
   // SiT-XL/2 shape: the hardware's workgroup hand-over already overlaps the store drain with the next launch.)
   // The epilogue stages through its own 32 KiB of LDS, so it needs no barrier against waves still in their last MFMAs.
-  tile_epilogue<EPI, 8>(a, acc, m0, wr * 128, n0 + wc * 64, lane, z, smem + 8 * HT + wave * EPI_STAGE_BYTES);
+  if constexpr (!RAGGED)
+    tile_epilogue<EPI, 8>(a, acc, m0, wr * 128, n0 + wc * 64, lane, z, smem + 8 * HT + wave * EPI_STAGE_BYTES);
+  else
+    tile_epilogue<EPI, 4>(a, acc, m0, wr * 128 + (wc >> 1) * 64, n0 + (wc & 1) * 64, lane, z,
+                          smem + 8 * HT + wave * EPI_STAGE_BYTES);
+}
+
+template <int LAY, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntm = (a.M + BM2 - 1) / BM2, ntn = (a.N + BN2 - 1) / BN2;
+  int tm, tn;
+  {
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, so blocks L, L+8, ... share an L2; give
+    // each XCD a contiguous run of tiles, walked in groups of GM tile rows x all tile columns.
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+      int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * ntn;
+    const int group = bid / per_group, first_m = group * GM;
+    const int gs = min(ntm - first_m, GM);
+    tm = first_m + (bid % per_group) % gs;
+    tn = (bid % per_group) / gs;
+  }
+  // fp32-output epilogues (pointer path: weight-gradient slabs, accumulating variants) and the TN layout (weight
+  // gradients run on the 128^2 kernel) keep the regular form only
+  if (LAY != LAY_TN && EpiOps<EPI, 8>::value > 0 && a.N - tn * BN2 <= 128)
+    gemm256_body<LAY, EPI, true>(a, smem, tm, tn);
+  else
+    gemm256_body<LAY, EPI, false>(a, smem, tm, tn);
 }
 
 template <int LAY, int EPI>

@@ -111,6 +111,7 @@ def gemm_force_tile(tile):
 
 
 WGRAD_SLOTS = 512  # resident 128x128 blocks: 256 CUs x 2 (64 KiB LDS, <=128 VGPRs... see gemm.hip launch bounds)
+WGRAD_SPLIT_MAX = int(__import__("os").environ.get("REED_WGRAD_SPLIT_MAX", "8"))  # experiments: cap the split count
 
 
 def plan_wgrad(Mtok, N, K):
@@ -122,7 +123,7 @@ def plan_wgrad(Mtok, N, K):
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     ktiles = (Mtok + 63) // 64
     best, best_key = 1, None
-    for s in range(1, 9):
+    for s in range(1, WGRAD_SPLIT_MAX + 1):
         if s > 1 and ktiles // s < 32:
             break
         blocks = tiles * s

@@ -52,9 +52,10 @@ def test_nt_asymmetric_identity(dev):
     assert torch.equal(out.float(), w.float().t().contiguous())
 
 
-def test_epilogues(dev):
+@pytest.mark.parametrize("N", [256, 384, 1152])   # 384, 1152: ragged last 256-column tile (re-dealt wave grid)
+def test_epilogues(dev, N):
     from reed_amd import ops
-    M, N, K, T = 512, 256, 128, 256
+    M, K, T = 512, 128, 256
     g = torch.Generator().manual_seed(1)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
     w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
@@ -197,10 +198,11 @@ def test_many_tiles(dev, lay, M, N, K):
     assert torch.equal(o128[:M], o256[:M])
 
 
-def test_fused_epilogues_many_tiles(dev):
+@pytest.mark.parametrize("N", [2304, 1152])   # 1152 = 4.5 x 256: the last column tile takes the ragged path
+def test_fused_epilogues_many_tiles(dev, N):
     """gate+residual and gelu epilogues over many tiles (gate rows change inside and across tiles)."""
     from reed_amd import ops
-    M, N, K, T = 16384, 2304, 128, 64
+    M, K, T = 16384, 128, 64
     g = torch.Generator().manual_seed(5)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
     w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
