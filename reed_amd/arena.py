@@ -68,27 +68,42 @@ class ArenaLayout:
         e = max(self.seg[n][0] + _align(self.numel(n)) for n in names)
         return b, e
 
+    ADA_HEAD_BLOCKS = 4   # adaLN rows of this many leading blocks are updated first (see update_chunks)
+
     def update_chunks(self, tap_blocks=()):
         """[(name, begin, end)] covering [0, n_total) exactly once, in the order the NEXT forward first touches the
-        weights: embedders + the adaLN group (arena start), blocks 0..L-1 with the projectors right after the last
-        block before the earliest tap, final layer + pos_embed. The fused optimiser walks these on its own stream and
-        the forward waits per chunk, so the HBM-bound update of block i+1.. runs under the MFMA-bound forward of
-        blocks ..i."""
+        weights. The fused optimiser walks these on its own stream and the forward waits per chunk, so the HBM-bound
+        update of later chunks runs under the MFMA-bound forward of earlier blocks. Order:
+          embed        adaLN biases + embedders (small; the conditioning path reads them first)
+          ada_head     adaLN weight rows of blocks 0..ADA_HEAD_BLOCKS-1  (the forward computes their modulation first)
+          block0..     blocks in forward order, with `ada_tail` (the other 2/3 of the adaLN matrix — a third of all
+                       parameters) after the head blocks and the projectors right after the earliest tap block
+          final        final layer + pos_embed (frozen; only the EMA pass touches it)."""
         bk = dict(self.buckets())
         starts = sorted((r[0], n) for n, r in bk.items())
         ends = {}
         for (b0, n), nxt in zip(starts, starts[1:] + [(self.n_total, None)]):
             ends[n] = (b0, nxt[0])
-        b0, e0 = ends["embed_adaln"]
-        order = [("embed_adaln", 0, e0)]
+        _, e0 = ends["embed_adaln"]
+        kh = min(self.ADA_HEAD_BLOCKS, self.depth)
+        per_block = (self.seg["blocks.0.adaLN_modulation.1.weight"][1][0] *
+                     self.seg["blocks.0.adaLN_modulation.1.weight"][1][1])
+        split = self.ada_w_off + kh * per_block
+        assert self.ada_w_off == 0 and split <= self.ada_b_off
+        order = [("embed", self.ada_b_off, e0), ("ada_head", 0, split)]
         first_tap = min(tap_blocks) if tap_blocks else None   # 1-based depth: projectors read the output of block first_tap-1
         for i in range(self.depth):
+            if i == kh:
+                order.append(("ada_tail", split, self.ada_b_off))
             if first_tap is not None and i == first_tap and "projectors" in ends:
                 order.append(("projectors",) + ends["projectors"])
             order.append((f"block{i}",) + ends[f"block{i}"])
+        if kh >= self.depth:
+            order.append(("ada_tail", split, self.ada_b_off))
         if "projectors" in ends and not any(n == "projectors" for n, _, _ in order):
             order.append(("projectors",) + ends["projectors"])
         order.append(("final",) + ends["final"])
+        order = [c for c in order if c[2] > c[1]]
         assert sum(e - b for _, b, e in order) == self.n_total and all(b % 4 == 0 and e % 4 == 0 for _, b, e in order)
         return order
 

@@ -92,7 +92,7 @@ class Engine:
         if "all" in pend:
             self.A.wait_all()
         elif pend:
-            self.A.wait("embed_adaln")
+            self.A.wait("embed")
         x = x.contiguous().float()
         t = t.contiguous().float()
         y = y.contiguous().long()
@@ -128,8 +128,14 @@ class Engine:
         Nall = L.ada_rows
         mod = bf(B, Nall)
         sp = self._shadow.data_ptr()
-        ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * L.ada_w_off, B, Nall, D, mod, D, D, Nall, bias=sp + 2 * L.ada_b_off)
         mp = mod.data_ptr()
+        # modulation of every block: one GEMM on silu(c) — or two when an overlapped optimiser step is still rewriting the
+        # tail of the adaLN matrix (a third of all parameters): the head blocks' rows now, the rest when block kh starts
+        kh = min(L.ADA_HEAD_BLOCKS, self.depth) if "ada_tail" in pend else 0
+        n_head = kh * 6 * D if kh else Nall
+        if pend:
+            self.A.wait("ada_head")
+        ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * L.ada_w_off, B, n_head, D, mod, D, D, Nall, bias=sp + 2 * L.ada_b_off)
         if need_grad:
             tp.sin, tp.t1p, tp.t1, tp.labels_eff, tp.c, tp.silu_c, tp.mod = sin, t1p, t1, labels_eff, c, silu_c, mod
 
@@ -142,6 +148,11 @@ class Engine:
         for i in range(self.depth):
             b = f"blocks.{i}."
             mb = mp + 2 * (i * 6 * D)
+            if kh and i == kh:
+                self.A.wait("ada_tail")
+                ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * (L.ada_w_off + n_head * D), B, Nall - n_head, D, mp + 2 * n_head,
+                         D, D, Nall, bias=sp + 2 * (L.ada_b_off + n_head))
+                kh = 0
             if pend:
                 self.A.wait(f"block{i}")
             if need_grad:
@@ -183,6 +194,10 @@ class Engine:
                     if dj == i + 1:
                         zs_by_proj[j] = self._projector_fwd(j, xcur, B, need_grad, tp)
         # -- final layer
+        if kh:   # depth <= ADA_HEAD_BLOCKS: the tail (final layer's rows) was never launched
+            self.A.wait("ada_tail")
+            ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * (L.ada_w_off + n_head * D), B, Nall - n_head, D, mp + 2 * n_head,
+                     D, D, Nall, bias=sp + 2 * (L.ada_b_off + n_head))
         if pend:
             self.A.wait_all()
         out = f32(B, C, HW, HW)

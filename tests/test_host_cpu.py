@@ -268,19 +268,28 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
 
 def test_update_chunks_cover_arena_in_forward_order():
     """ArenaLayout.update_chunks (overlapped optimiser): the chunks tile [0, n_total) exactly once, start with the
-    embedders + adaLN group, visit the blocks in forward order with the projectors right behind the tap block, and end
-    with the final layer (+ the frozen pos_embed, which only the EMA pass touches)."""
+    embedders + the head of the adaLN matrix, visit the blocks in forward order with the adaLN tail behind the head
+    blocks and the projectors right behind the tap block, and end with the final layer (+ the frozen pos_embed, which
+    only the EMA pass touches)."""
     from reed_amd.models.sit import SiT
-    m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=4, num_heads=2, num_classes=10, z_dims=[128],
+    m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=6, num_heads=2, num_classes=10, z_dims=[128],
             z_types=["i"], encoder_depth=2, projector_dim=128)
     L = m._layout
     ch = L.update_chunks([2])
     names = [n for n, _, _ in ch]
-    assert names == ["embed_adaln", "block0", "block1", "projectors", "block2", "block3", "final"]
+    assert names == ["embed", "ada_head", "block0", "block1", "projectors", "block2", "block3", "ada_tail", "block4",
+                     "block5", "final"]
     spans = sorted((b, e) for _, b, e in ch)
     assert spans[0][0] == 0 and spans[-1][1] == L.n_total
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     bk = dict(L.buckets())
-    for n, b, e in ch:   # every chunk contains its all-reduce bucket
-        assert b <= bk[n][0] and bk[n][1] <= e
-    assert L.update_chunks(()) [-1][0] == "final"
+    by = {n: (b, e) for n, b, e in ch}
+    for n in ("block0", "block5", "projectors", "final"):   # every such chunk contains its all-reduce bucket
+        assert by[n][0] <= bk[n][0] and bk[n][1] <= by[n][1]
+    D = 128
+    assert by["ada_head"] == (0, 4 * 6 * D * D) and by["ada_tail"] == (4 * 6 * D * D, L.ada_b_off)
+    assert L.update_chunks(())[-1][0] == "final"
+    m2 = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10, z_dims=[],
+             z_types=[], encoder_depth=2, projector_dim=128)
+    n2 = [n for n, _, _ in m2._layout.update_chunks(())]
+    assert n2 == ["embed", "ada_head", "block0", "block1", "block2", "ada_tail", "final"]
