@@ -84,7 +84,7 @@ class ArenaLayout:
         ends = {}
         for (b0, n), nxt in zip(starts, starts[1:] + [(self.n_total, None)]):
             ends[n] = (b0, nxt[0])
-        _, e0 = ends["embed_adaln"]
+        _, e0 = ends["embed"]
         kh = min(self.ADA_HEAD_BLOCKS, self.depth)
         per_block = (self.seg["blocks.0.adaLN_modulation.1.weight"][1][0] *
                      self.seg["blocks.0.adaLN_modulation.1.weight"][1][1])
@@ -107,19 +107,26 @@ class ArenaLayout:
         assert sum(e - b for _, b, e in order) == self.n_total and all(b % 4 == 0 and e % 4 == 0 for _, b, e in order)
         return order
 
+    def ada_row_range(self, i):
+        """[begin, end) of the adaLN weight rows of block i (i == depth: the final layer's 2D rows) in the arena."""
+        name = f"blocks.{i}.adaLN_modulation.1.weight" if i < self.depth else "final_layer.adaLN_modulation.1.weight"
+        off, shp = self.seg[name]
+        return off, off + _align(int(np.prod(shp)))
+
     def buckets(self):
-        """Gradient all-reduce buckets in the order backward finishes them:
-        final layer, blocks L-1..0 (projectors fire when their tap block is reached; reported separately),
-        then embedders + the adaLN group."""
-        out = [("final", self.range_of("final_layer.linear"))]
+        """Gradient all-reduce buckets in the order backward finishes them: final layer, blocks L-1..0, each followed
+        by ITS rows of the adaLN matrix (`ada{i}`; the engine computes those rows' gradient right after the block when
+        a reducer is attached, so that the adaLN third of the payload — 0.9 GB for XL/2 — rides under backward instead
+        of being reduced after it), the projectors (fired when the last tap's backward is done), and at the very end
+        the small rest: adaLN biases + embedders."""
+        out = [("final", self.range_of("final_layer.linear")), (f"ada{self.depth}", self.ada_row_range(self.depth))]
         for i in reversed(range(self.depth)):
             out.append((f"block{i}", self.range_of(f"blocks.{i}.attn.qkv")[0:1] + (self.range_of(f"blocks.{i}.mlp.fc2")[1],)))
+            out.append((f"ada{i}", self.ada_row_range(i)))
         names = [n for n in self.seg if n.startswith("projectors.")]
         if names:
             out.append(("projectors", self.range_of("projectors.")))
-        b, _ = self.range_of("blocks.0.adaLN")  # adaLN group is first in the arena
-        e = self.range_of("y_embedder")[1]
-        out.append(("embed_adaln", (0, e)))
+        out.append(("embed", (self.ada_b_off, self.range_of("y_embedder")[1])))
         return out
 
 

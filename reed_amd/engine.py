@@ -49,6 +49,7 @@ class Engine:
         self.reducer = None      # set by reed_amd.parallel.GradReducer
         self._ws = None
         self._ws_side = None
+        self.split_ada_wgrad = None   # None: per-block adaLN weight gradients iff a reducer is attached (see backward)
         self._side = None        # second HIP stream: the blocks' weight-gradient GEMMs run beside the dgrad chain
         # True / False / None = auto: on when the local batch is small enough that one-round GEMM grids leave CUs idle
         # (measured on MI355X, SiT-XL/2: +3.7 % at b = 32, -1 % at 64, -5 % at 128 and 256)
@@ -335,8 +336,26 @@ class Engine:
         ops.reduce_mod_parts([(partF.data_ptr(), 2 * D, offF), (partF.data_ptr() + 4 * D, 2 * D, offF + D)], dmod, Nall,
                              B, D, ch)
         del hbuf, dlin, dh
+        # With a reducer attached the adaLN weight gradient is computed block by block (rows of block i right after
+        # block i's backward: dW_ada[i] = dmod[:, i]^T silu(c), a K = b GEMM) instead of one GEMM at the end, so each
+        # slice's all-reduce overlaps the rest of backward; the arithmetic per output element is the same.
+        split_ada = self.reducer is not None if self.split_ada_wgrad is None else self.split_ada_wgrad
+        gp = self.A.grad.data_ptr()
+        dmp = dmod.data_ptr()
+
+        def ada_wgrad(i):
+            c0 = i * 6 * D
+            rows = 6 * D if i < self.depth else 2 * D
+            ops.gemm(TN, EPI_F32, dmp + 2 * c0, tp.silu_c, rows, D, B, gp + 4 * (L.ada_w_off + c0 * D), Nall, D, D,
+                     dbias=gp + 4 * (L.ada_b_off + c0), accumulate=acc)
+
+        if split_ada:
+            ada_wgrad(self.depth)
         if self.reducer is not None:
             self.reducer.ready("final")
+            if split_ada:
+                self.reducer.ready(f"ada{self.depth}")
+        proj_left = len([j for j in pending if j in tp.proj])
         dz_by_proj = {}
         if dzs is not None:
             for k, j in enumerate(tp.zs_order):
@@ -345,6 +364,9 @@ class Engine:
             for j, dj in pending.items():
                 if dj == i + 1 and j in tp.proj:
                     self._projector_bwd(j, tp, dz_by_proj.get(j), dx, B, acc, dev)
+                    proj_left -= 1
+                    if proj_left == 0 and self.reducer is not None:
+                        self.reducer.ready("projectors")
             bk = tp.blocks[i]
             b = f"blocks.{i}."
             mb = mp + 2 * (i * 6 * D)
@@ -394,20 +416,26 @@ class Engine:
                                   (p2, 2 * D, o6 + 3 * D), (p2 + 4 * D, 2 * D, o6 + 4 * D),
                                   (pg2.data_ptr(), D, o6 + 5 * D)], dmod, Nall, B, D, ch)
             tp.blocks[i] = None  # free this block's activations
+            if split_ada:
+                ada_wgrad(i)
             if self.reducer is not None:
                 if side is None:
                     self.reducer.ready(f"block{i}")
+                    if split_ada:
+                        self.reducer.ready(f"ada{i}")
                 else:  # the bucket holds gradients written on both streams: fire it from the side stream, after main
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         self.reducer.ready(f"block{i}")
-        if m.z_dims and self.reducer is not None:
+                        if split_ada:
+                            self.reducer.ready(f"ada{i}")
+        if proj_left > 0 and m.z_dims and self.reducer is not None:   # projector outputs unused by the loss
             self.reducer.ready("projectors")
         # -- adaLN (all blocks + final): dW = dmod^T silu(c); d silu(c) = dmod @ W   (one GEMM each)
         sp = self._shadow.data_ptr()
-        gp = self.A.grad.data_ptr()
-        ops.gemm(TN, EPI_F32, dmod, tp.silu_c, Nall, D, B, gp + 4 * L.ada_w_off, Nall, D, D,
-                 dbias=gp + 4 * L.ada_b_off, accumulate=acc)
+        if not split_ada:
+            ops.gemm(TN, EPI_F32, dmod, tp.silu_c, Nall, D, B, gp + 4 * L.ada_w_off, Nall, D, D,
+                     dbias=gp + 4 * L.ada_b_off, accumulate=acc)
         ksteps = Nall // 64
         split = min(64, max(1, ksteps // 8))
         slab = B * D
@@ -437,7 +465,10 @@ class Engine:
         ops.smallk_wgrad(dx, True, xb, wsf, self.G("x_embedder.proj.weight"), self.G("x_embedder.proj.bias"), None, M, D,
                          K, 0, acc)
         if self.reducer is not None:
-            self.reducer.ready("embed_adaln")
+            if not split_ada:
+                for i in reversed(range(self.depth + 1)):
+                    self.reducer.ready(f"ada{i}")
+            self.reducer.ready("embed")
         if side is not None:  # the optimiser / next micro-step (same stream as this backward) sees every weight gradient
             torch.cuda.current_stream().wait_stream(side)
         self.grad_live = True

@@ -131,7 +131,8 @@ def test_bucket_plan_covers_every_parameter_once():
         L = ArenaLayout(shapes, cfg["depth"], len(cfg["z_dims"]))
         bk = check_buckets(L)
         names = [b[0] for b in bk]
-        assert names[0] == "final" and names[1] == f"block{cfg['depth'] - 1}" and names[-1] == "embed_adaln"
+        d = cfg["depth"]
+        assert names[:4] == ["final", f"ada{d}", f"block{d - 1}", f"ada{d - 1}"] and names[-1] == "embed"
         covered = sum(e - b for _, (b, e) in bk)
         assert covered <= L.n_train
     # XL/2: 683,472,144 trainable elements = the gradient all-reduce payload
@@ -237,7 +238,12 @@ torch.manual_seed(rank_seed(0, rank))
 grad = torch.randn(L.n_train)
 mine = grad.clone()
 red = TorchDistGradReducer(L, grad, world)
-order = ["final"] + [f"block{i}" for i in reversed(range(cfg["depth"]))] + ["projectors", "embed_adaln"]
+d = cfg["depth"]
+order = ["final", f"ada{d}"]
+for i in reversed(range(d)):
+    order += [f"block{i}", f"ada{i}"]
+    if i + 1 == cfg["encoder_depth"]: order.append("projectors")
+order.append("embed")
 for name in order:            # the order in which Engine.backward fires buckets
     red.ready(name)
 red.sync()
