@@ -63,9 +63,9 @@ def random_fill(model, seed):
     A.shadow_version = -1
 
 
-TRAFFIC_B256 = 3.01e9   # bytes per launch of the dominant kernel, rocprofv3 --pmc (profiles/r1_pmc_gemm.txt)
+TRAFFIC_B256 = 2.96e9   # bytes per launch of the dominant kernel, rocprofv3 --pmc (profiles/r1_pmc_gemm.txt, last section)
 TRAFFIC_NOTE = ("gemm_kernel<TN> fc1 wgrad (24 % of the step): algorithmic 0.82 GB/launch (dy 0.60 + x 0.15 + 3 fp32 slabs 0.06), "
-                "measured 2.94 GB L2-miss reads (FETCH_SIZE x2, counts Infinity-Cache hits) + 0.064 GB writes")
+                "measured 2.90 GB L2-miss reads (FETCH_SIZE x2, counts Infinity-Cache hits) + 0.064 GB writes")
 
 
 def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
@@ -240,6 +240,11 @@ def main():
             tot_ms = sum(r["ms"] for r in rows)
             agg = sum(r["tflops"] * r["ms"] for r in rows) / tot_ms
             dom = max(rows, key=lambda r: r["ms"])
+            # the single kernel with the largest share of the step (rocprofv3 --stats: gemm_kernel<2, 6>, ~25 %): the
+            # 128^2 TN weight-gradient kernel; its launches are the block's four wgrads (incl. their slab reduce)
+            wg = [r for r in rows if r["kernel"].startswith("wgrad")]
+            wg_ms = sum(r["ms"] for r in wg)
+            wg_tf = sum(r["tflops"] * r["ms"] for r in wg) / wg_ms
             # HBM-side traffic of the slowest GEMM launch, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             # (profiles/; FETCH_SIZE doubled per the gfx950 correction). Valid for the b=256 workload only.
             traffic = TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None
@@ -248,6 +253,9 @@ def main():
                                "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm_kernel<TN> (time-weighted over "
                                          "the block's 12 GEMM launches; flop per launch / event-timed duration)",
                                "dominant": TRAFFIC_NOTE,
+                               "dominant_kernel": {"name": "gemm_kernel<TN, F32> (weight gradients, 128^2 tile, split-K slabs)",
+                                                   "avg_ms_per_launch": round(wg_ms / len(wg), 4),
+                                                   "tflops": round(wg_tf, 1), "frac": round(wg_tf * 1e12 / PEAK_BF16, 4)},
                                "slowest_shape": dom}
             out["gemm_table"] = rows
         if world == 1 and not args.no_cpu_baseline:
