@@ -179,21 +179,28 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
           st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
         }
       bf16x8 pb[2][2];
+      // keys past T exist only in a ragged last sub-block: mask them there (wave-uniform branch), nowhere else
+      if (kv0 + kvs + 64 > T) {
+        asm volatile("; ragged key sub-block" ::);   // keeps this a real (wave-uniform) branch: no if-conversion
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kv0 + kvs + 16 * kt + 4 * g + r >= T) st[qt][kt][r] = -INFINITY;
+      }
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
+        // running maximum on the raw scores (the scale is positive); the scale rides in the exponent's FMA
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int kv = kv0 + kvs + 16 * kt + 4 * g + r;
-            float s = kv < T ? st[qt][kt][r] * sc2 : -INFINITY;
-            st[qt][kt][r] = s;
-            mx = fmaxf(mx, s);
-          }
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m[qt], mx);
+        const float mnew = fmaxf(m[qt], mx * sc2);
         const float alpha = __builtin_amdgcn_exp2f(m[qt] - mnew);
         m[qt] = mnew;
         float sum = 0.f;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = __builtin_amdgcn_exp2f(st[qt][kt][r] - mnew);
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sc2, -mnew));
             st[qt][kt][r] = p;
             sum += p;
           }
@@ -344,12 +351,22 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            int kv = kv0 + 16 * kt + 4 * g + r;
-            float p = kv < T ? __builtin_amdgcn_exp2f(st[qt][kt][r] * sc2 - lq[qt]) : 0.f;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sc2, -lq[qt]));
             st[qt][kt][r] = p * (dp[qt][kt][r] - dq_[qt]);
           }
-        dsb[qt] = pack2(st[qt][0], st[qt][1]);
       }
+      if (kv0 + 32 > T) {   // keys past T exist only in a ragged last key block
+        asm volatile("; ragged key block" ::);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kv0 + 16 * kt + 4 * g + r >= T) st[qt][kt][r] = 0.f;
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) dsb[qt] = pack2(st[qt][0], st[qt][1]);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         bf16x8 ktf = frag_trT(Kt, kv0, 16 * dt, lane);
@@ -421,8 +438,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         f32x4 p0, p1, s0, s1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p0[r] = __builtin_amdgcn_exp2f(st[0][ct][r] * sc2 - lq4[0][r]);
-          p1[r] = __builtin_amdgcn_exp2f(st[1][ct][r] * sc2 - lq4[1][r]);
+          p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
+          p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
           s0[r] = p0[r] * (dp[0][ct][r] - dl4[0][r]);
           s1[r] = p1[r] * (dp[1][ct][r] - dl4[1][r]);
         }
