@@ -265,6 +265,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    if world > 1:   # rank 0 is still timing the kernel table: nobody tears a communicator down under it
+        torch.cuda.synchronize()
+        dist.barrier()
     if reducer is not None:
         reducer.close()
     if world > 1:
