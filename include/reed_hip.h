@@ -35,7 +35,8 @@ int reed_version(void);
  * epilogue codes: see reed_amd/csrc/gemm.h (0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
  *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic).  N%128==0; K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
- *   dbias likewise holds split_k slabs of M floats; reduce both with reed_reduce_slabs: deterministic).
+ *   dbias likewise holds split_k slabs of M floats AT THE SAME slab_stride — put slab 0 of dbias right behind slab 0
+ *   of C and one reed_reduce_slabs call over M*N + M floats finishes both; deterministic).
  * ------------------------------------------------------------------------------------------- */
 int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* Q, int64_t ldq,
               int M, int N, int K, void* C, int64_t ldc, void* C2, int64_t ldc2, const void* R,

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + (lane & 15);
         if (m < a.M) {
-          if (gridDim.y > 1) a.dbias[(long)z * a.M + m] = accb[i][0];  // split-K: per-slice slab, reduced by the caller
+          if (gridDim.y > 1) a.dbias[(long)z * a.slab_stride + m] = accb[i][0];  // split-K: per-slice slab (C's stride)
           else if (a.accumulate) a.dbias[m] += accb[i][0];
           else a.dbias[m] = accb[i][0];
         }

@@ -82,19 +82,22 @@ def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, 
         gemm(TN, EPI_F32, dy, x, N, K, Mtok, dw, N, K, K, dbias=dbias, accumulate=accumulate)
         return
     slab = N * K
+    stride = slab + N if dbias is not None else slab   # slab z = [dW slice z | dbias slice z]
     if ws is None:
-        ws = torch.empty(split_k * (slab + N), dtype=torch.float32, device=dw.device if torch.is_tensor(dw) else "cuda")
+        ws = torch.empty(split_k * stride, dtype=torch.float32, device=dw.device if torch.is_tensor(dw) else "cuda")
     wsp = ws if isinstance(ws, int) else ws.data_ptr()
-    bslab = wsp + split_k * slab * 4
-    gemm(TN, EPI_F32, dy, x, N, K, Mtok, wsp, N, K, K, dbias=bslab if dbias is not None else None,
-         accumulate=False, split_k=split_k, slab_stride=slab)
+    gemm(TN, EPI_F32, dy, x, N, K, Mtok, wsp, N, K, K, dbias=wsp + 4 * slab if dbias is not None else None,
+         accumulate=False, split_k=split_k, slab_stride=stride)
     # the launcher may round the split count down; it reports nothing back, so recompute it the same way
     ksteps = (Mtok + 63) // 64
     per = (ksteps + split_k - 1) // split_k
     eff = (ksteps + per - 1) // per
-    reduce_slabs(wsp, slab, eff, dw, slab, accumulate)
+    if dbias is not None and _p(dbias) == _p(dw) + 4 * slab:   # bias right behind its weight (the gradient arena): one pass
+        reduce_slabs(wsp, stride, eff, dw, stride, accumulate)
+        return
+    reduce_slabs(wsp, stride, eff, dw, slab, accumulate)
     if dbias is not None:
-        reduce_slabs(bslab, N, eff, dbias, N, accumulate)
+        reduce_slabs(wsp + 4 * slab, stride, eff, dbias, N, accumulate)
 
 
 def colsum_ws_floats(M, N):
