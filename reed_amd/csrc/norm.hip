@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16* __restrict_
     }
     __syncthreads();
     float* og = part_g + (long)blockIdx.x * D;
-    float* od = part_dy + (long)blockIdx.x * D;
-    for (int i = threadIdx.x; i < D; i += 256) {
-      og[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
-      od[i] = red[D + i] + red[3 * D + i] + red[5 * D + i] + red[7 * D + i];
+    for (int i = threadIdx.x; i < D; i += 256) og[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+    if (part_dy) {
+      float* od = part_dy + (long)blockIdx.x * D;
+      for (int i = threadIdx.x; i < D; i += 256) od[i] = red[D + i] + red[3 * D + i] + red[5 * D + i] + red[7 * D + i];
     }
   }
 }
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
     hr.st_lds(red + (rg * 2 + 1) * D, pd);
     __syncthreads();
     float* og = part_g + (long)blockIdx.x * D;
-    float* od = part_dy + (long)blockIdx.x * D;
-    for (int i = threadIdx.x; i < D; i += 512) {
-      og[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
-      od[i] = red[D + i] + red[3 * D + i] + red[5 * D + i] + red[7 * D + i];
+    for (int i = threadIdx.x; i < D; i += 512) og[i] = red[i] + red[2 * D + i] + red[4 * D + i] + red[6 * D + i];
+    if (part_dy) {   // column sums of dy (bias gradient of the linear that produced y) — optional: the wgrad GEMM can fuse it
+      float* od = part_dy + (long)blockIdx.x * D;
+      for (int i = threadIdx.x; i < D; i += 512) od[i] = red[D + i] + red[3 * D + i] + red[5 * D + i] + red[7 * D + i];
     }
   }
 }
@@ -630,7 +630,7 @@ extern "C" int reed_ln_modulate_bwd_gate(const void* dh, const float* x, const f
                                          const void* gate, int64_t ldgate, void* dy, float* part_g, float* part_dy,
                                          int M, int D, int T, void* stream) {
   REED_CHECK_ARG(dh && x && mean && rstd && scale && dx && part, "ln_modulate_bwd_gate: null pointer");
-  REED_CHECK_ARG(y && gate && dy && part_g && part_dy, "ln_modulate_bwd_gate: null gate operand");
+  REED_CHECK_ARG(y && gate && dy && part_g, "ln_modulate_bwd_gate: null gate operand");   // part_dy is optional
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "ln_modulate: D=%d unsupported", D);
   REED_CHECK_ARG(T % 16 == 0 && M % 16 == 0, "ln_modulate_bwd_gate: T=%d, M=%d must be multiples of 16", T, M);
   if (launch_ln_mod_bwd2<true>((hipStream_t)stream, (const bf16*)dh, x, mean, rstd, (const bf16*)scale, (long)ldmod, dx,

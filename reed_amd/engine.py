@@ -317,15 +317,15 @@ class Engine:
         def ln_bwd(dh_, x_, mean_, rstd_, scale_ptr, part_, nxt):
             """LayerNorm+modulate backward into dx. nxt = index of the block whose MLP-branch gate consumes the finished
             dx next (or None): its gate backward rides along in the same pass unless a projector tap adds into dx in
-            between. Returns (dy2, pg2, pb) of that block when fused."""
+            between. Returns (dy2, pg2) of that block when fused."""
             if nxt is None or nxt < 0 or tap_fires(nxt + 1):
                 ops.ln_modulate_bwd(dh_, x_, mean_, rstd_, scale_ptr, Nall, dx, part_, M, D, T)
                 return None
             nb_ = tp.blocks[nxt]
-            dy_, pg_, pb_ = bf(M, D), f32(M // 16, D), f32(M // 16, D)
+            dy_, pg_ = bf(M, D), f32(M // 16, D)
             ops.ln_modulate_bwd_gate(dh_, x_, mean_, rstd_, scale_ptr, Nall, dx, part_, nb_.y2,
-                                     mp + 2 * (nxt * 6 * D) + 10 * D, Nall, dy_, pg_, pb_, M, D, T)
-            return dy_, pg_, pb_
+                                     mp + 2 * (nxt * 6 * D) + 10 * D, Nall, dy_, pg_, None, M, D, T)
+            return dy_, pg_
 
         pre = ln_bwd(dh, tp.x_last, tp.meanF, tp.rstdF, mf + 2 * D, partF, self.depth - 1)
         wsf = self.ws(ops.smallk_ws_floats(D, max(self.NO, C * P * P)), dev)
@@ -371,14 +371,13 @@ class Engine:
             b = f"blocks.{i}."
             mb = mp + 2 * (i * 6 * D)
             # MLP branch (its gate backward usually came with the previous LayerNorm backward)
+            # (bias gradients of fc2 / proj = column sums of dy2 / dy1: fused into their weight-gradient GEMMs)
             if pre is not None:
-                dy2, pg2, pb = pre
+                dy2, pg2 = pre
             else:
-                pg2, dy2, pb = f32(M // 16, D), bf(M, D), f32(M // 16, D)
-                ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T, part_dy=pb)
-            wsr = self.ws((M // 16 + 63) // 64 * D, dev)
-            ops.rowsum_f32(pb, M // 16, self.G(b + "mlp.fc2.bias"), D, acc, ws=wsr)
-            self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, bias_done=True, side=side)
+                pg2, dy2 = f32(M // 16, D), bf(M, D)
+                ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T)
+            self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, side=side)
             da1 = bf(M, Hm)
             self._dgrad(EPI_DGELU, dy2, b + "mlp.fc2.weight", M, D, Hm, da1, R=bk.a1, ldr=Hm)
             self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev, side=side)
@@ -386,12 +385,10 @@ class Engine:
             self._dgrad(EPI_BF16, da1, b + "mlp.fc1.weight", M, Hm, D, dh2)
             # LN2 backward + the attention branch's gate backward in one pass over dx
             pl2 = f32(M // 16, 2, D)
-            pg1, dy1, pb1 = f32(M // 16, D), bf(M, D), f32(M // 16, D)
+            pg1, dy1 = f32(M // 16, D), bf(M, D)
             ops.ln_modulate_bwd_gate(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, bk.y1, mb + 4 * D, Nall,
-                                     dy1, pg1, pb1, M, D, T)
-            ops.rowsum_f32(pb1, M // 16, self.G(b + "attn.proj.bias"), D, acc, ws=wsr)
-            del pb, pb1
-            self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, bias_done=True, side=side)
+                                     dy1, pg1, None, M, D, T)
+            self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, side=side)
             do = bf(M, D)
             self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
             dqkv = bf(M, 3 * D)
