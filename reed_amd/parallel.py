@@ -57,7 +57,13 @@ def check_buckets(layout):
 
 
 class GradReducer:
-    """RCCL-backed reducer. Needs torch.distributed initialised (any backend) only to ship the 128-byte RCCL id."""
+    """RCCL-backed reducer. Needs torch.distributed initialised (any backend) only to ship the 128-byte RCCL id.
+
+    Two bindings of the same collective (RCCL all-reduce(avg), fp32, in place, on a stream beside backward):
+      native   libreed_hip.so's own communicator + high-priority stream (csrc/comm.cpp) — the default;
+      torch    torch.distributed's NCCL(=RCCL) process group on a torch side stream — `REED_COMM=torch`, and the
+               automatic fall-back (with a warning) when the native communicator cannot be created, so that a
+               multi-GPU job still runs on RCCL rather than not at all."""
 
     def __init__(self, model, rank=None, world=None):
         self.rank = dist.get_rank() if rank is None else rank
@@ -66,7 +72,26 @@ class GradReducer:
         self.buckets = dict(check_buckets(model._layout))
         self.enabled = True
         self.force = os.environ.get("REED_FORCE_REDUCER", "0") == "1"  # run the RCCL calls even at world == 1 (tests)
-        L = _lib.load()
+        self._lib = _lib.load()
+        self.comm = None
+        self._tstream = None
+        mode = os.environ.get("REED_COMM", "native")
+        if mode != "torch":
+            try:
+                self._init_native()
+            except RuntimeError as e:   # e.g. a second RCCL instance that cannot bootstrap next to torch's
+                import warnings
+                warnings.warn(f"reed_amd: native RCCL communicator unavailable ({e}); gradient all-reduce goes "
+                              "through torch.distributed's RCCL process group instead")
+                self.comm = None
+        if self.comm is None:
+            if not dist.is_initialized():
+                raise RuntimeError("GradReducer: torch.distributed must be initialised for the torch RCCL binding")
+            self._tstream = torch.cuda.Stream(device=model._arena.master.device, priority=-1)
+        model.engine().reducer = self
+
+    def _init_native(self):
+        L = self._lib
         idbuf = ctypes.create_string_buffer(128)
         if self.rank == 0:
             _lib.check(L.reed_comm_unique_id(idbuf), "comm_unique_id")
@@ -76,16 +101,22 @@ class GradReducer:
         comm = ctypes.c_void_p()
         _lib.check(L.reed_comm_init(obj[0], self.rank, self.world, ctypes.byref(comm)), "comm_init")
         self.comm = comm
-        self._lib = L
-        model.engine().reducer = self
+
+    @property
+    def binding(self):
+        return "native" if self.comm is not None else "torch"
 
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
 
     def broadcast_params(self, root=0):
         A = self.model._arena
-        _lib.check(self._lib.reed_comm_broadcast(self.comm, A.master.data_ptr(), A.master.numel(), root, self._stream()),
-                   "comm_broadcast")
+        A.wait_all()
+        if self.comm is not None:
+            _lib.check(self._lib.reed_comm_broadcast(self.comm, A.master.data_ptr(), A.master.numel(), root,
+                                                     self._stream()), "comm_broadcast")
+        else:
+            dist.broadcast(A.master, src=root)
         A.shadow_version = -1
 
     def ready(self, name):
@@ -93,13 +124,21 @@ class GradReducer:
             return
         b, e = self.buckets[name]
         g = self.model._arena.grad
-        _lib.check(self._lib.reed_comm_allreduce_avg(self.comm, g.data_ptr() + 4 * b, e - b, self._stream()),
-                   "comm_allreduce_avg")
+        if self.comm is not None:
+            _lib.check(self._lib.reed_comm_allreduce_avg(self.comm, g.data_ptr() + 4 * b, e - b, self._stream()),
+                       "comm_allreduce_avg")
+            return
+        self._tstream.wait_stream(torch.cuda.current_stream())   # the bucket's gradients are written
+        with torch.cuda.stream(self._tstream):
+            dist.all_reduce(g[b:e], op=dist.ReduceOp.AVG)           # stream-ordered: no host wait
 
     def sync(self):
         if not self.enabled or (self.world == 1 and not self.force):
             return
-        _lib.check(self._lib.reed_comm_sync(self.comm, self._stream()), "comm_sync")
+        if self.comm is not None:
+            _lib.check(self._lib.reed_comm_sync(self.comm, self._stream()), "comm_sync")
+        else:
+            torch.cuda.current_stream().wait_stream(self._tstream)
 
     def close(self):
         if self.comm:

@@ -48,10 +48,20 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
     assert lat.shape == (8, 4, 32, 32) and np.isfinite(lat).all()
 
 
-def test_rccl_reducer_world1(dev):
+@pytest.mark.parametrize("binding", ["native", "torch"])
+def test_rccl_reducer_world1(dev, binding):
     """Exercise every RCCL entry point (unique id, init, broadcast, bucketed all-reduce(avg) fired from backward on the
-    side stream, sync, destroy) with a 1-rank communicator: averaging over one rank must leave gradients unchanged."""
+    side stream, sync, destroy) with a 1-rank communicator: averaging over one rank must leave gradients unchanged.
+    binding="torch": the same bucket plan through torch.distributed's RCCL process group (REED_COMM=torch, the
+    fall-back when the native communicator cannot be created)."""
     import copy
+    import torch.distributed as dist
+    if binding == "torch":
+        os.environ["REED_COMM"] = "torch"
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29741")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from oracle import detfill
     from reed_amd.loss import SILoss
     from reed_amd.models.sit import SiT
@@ -66,6 +76,7 @@ def test_rccl_reducer_world1(dev):
             m.force_drop_mask = torch.tensor([False, True, False, False])
             red = GradReducer(m, rank=0, world=1) if with_reducer else None
             if red:
+                assert red.binding == binding
                 red.broadcast_params(0)
             lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
             x, n = detfill.normal((4, 4, 8, 8), 1).to(dev), detfill.normal((4, 4, 8, 8), 2)
@@ -83,3 +94,6 @@ def test_rccl_reducer_world1(dev):
         assert torch.equal(g0, g1)
     finally:
         os.environ.pop("REED_FORCE_REDUCER", None)
+        os.environ.pop("REED_COMM", None)
+        if binding == "torch" and dist.is_initialized():
+            dist.destroy_process_group()
