@@ -214,3 +214,50 @@ def test_overlapped_optimizer_bit_identical(dev):
         res[overlap] = (m._arena.master.clone(), ema._arena.master.clone(), m._arena.shadow.clone(), sd)
     for a, b in zip(res[False][:3], res[True][:3]):
         assert torch.equal(a, b)
+
+
+def test_full_size_properties(dev):
+    """C2 at the bench's own size (SiT-XL/2 + 1024-d projector, local batch 256: no oracle finishes there), through
+    properties that hold at any size:
+      (1) reference init: adaLN / final layers are zero -> every block is the identity and the velocity is exactly 0
+          (sit.py:246-254), the projector output is not;
+      (2) determinism: the same step twice from the same state gives bit-identical losses and gradients;
+      (3) linearity of backward: 2 x loss -> every gradient exactly doubled (bf16 / fp32 roundings commute with a
+          power-of-two scale), which a dropped or double-counted term, or an accumulation into stale memory, breaks."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import random_fill
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT_models
+    torch.manual_seed(0)
+    m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8).to(dev).train()
+    B = 256
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(B, 4, 32, 32, device=dev, generator=g)
+    noise = torch.randn(B, 4, 32, 32, device=dev, generator=g)
+    t = torch.rand(B, device=dev, generator=g) * 0.9 + 0.05
+    y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    zs = [torch.randn(B, 256, 1024, device=dev, generator=g)]
+    m.force_drop_mask = torch.rand(B, device=dev, generator=g) < 0.1
+    with torch.no_grad():
+        v, z = m(x, t, y, inference=False)
+    assert float(v.abs().max()) == 0.0 and float(z[0].float().abs().max()) > 0.0
+    random_fill(m, 1234)
+    lf = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
+
+    def step(scale):
+        for p in m.parameters():
+            p.grad = None
+        m.engine().zero_grad()
+        out = lf(m, x, dict(y=y), zs=zs, time_input=t.cpu(), noises=noise)
+        loss = out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), m._arena.grad.clone()
+
+    l1, g1 = step(1.0)
+    l2, g2 = step(1.0)
+    assert l1 == l2 and torch.equal(g1, g2)
+    assert np.isfinite(l1) and float(g1.abs().max()) > 0 and bool(torch.isfinite(g1).all())
+    _, g3 = step(2.0)
+    assert torch.equal(g3, 2.0 * g1)
