@@ -33,7 +33,7 @@ int reed_version(void);
  *   layout 1 NN: C[M,N] = P[M,K] Q[K,N]       (dgrad    dx = dy W)
  *   layout 2 TN: C[M,N] = P[K,M]^T Q[K,N]     (wgrad    dW = dy^T x), optional dbias[M] = colsum(P)
  * epilogue codes: see reed_amd/csrc/gemm.h (0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
- *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic).  N%128==0; K%64==0 (NT/NN);
+ *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual).  N%128==0; K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
  *   dbias likewise holds split_k slabs of M floats AT THE SAME slab_stride — put slab 0 of dbias right behind slab 0
  *   of C and one reed_reduce_slabs call over M*N + M floats finishes both; deterministic).
@@ -212,6 +212,23 @@ int reed_comm_allreduce_avg(void* comm, float* buf, int64_t count, void* compute
 int reed_comm_sync(void* comm, void* compute_stream);       /* compute_stream waits for all pending reductions */
 int reed_comm_broadcast(void* comm, float* buf, int64_t count, int root, void* compute_stream);
 int reed_comm_destroy(void* comm);
+
+/* ---------------------------------------------------------------------------------------------
+ * Frozen CLIP image encoder, forward only: the producer of the alignment targets that
+ * image/train.py:351-357 runs under autocast every step (image/models/clip_vit.py:208-230 UpdatedVisionTransformer:
+ * conv1 14x14/14 -> [class token | patches] + positional embedding -> ln_pre -> ResidualAttentionBlocks (:173-195,
+ * nn.MultiheadAttention + QuickGELU MLP) -> tokens without the class token; no ln_post, no projection).
+ * The contractions go through reed_gemm (epilogues 0, 9 QuickGELU, 10 + bf16 residual) and reed_attention_fwd (hd 64,
+ * T = 257); these are the row passes around them.
+ * ------------------------------------------------------------------------------------------- */
+/* out bf16 [B*(S/P)^2, Kp]: row (b, gy, gx), column c*P*P + py*P + px of img f32 [B,3,S,S]; columns >= 3 P^2 zero */
+int reed_clip_im2col(const float* img, void* out, int B, int S, int P, int Kp, void* stream);
+/* out bf16 [B,T,D]: row 0 = bf16(bf16(cls) + bf16(pos[0])), row t = bf16(patches[b,t-1] + bf16(pos[t])); T = patches+1 */
+int reed_clip_tokens(const void* patches, const float* cls, const float* pos, void* out, int B, int T, int D,
+                     void* stream);
+/* out bf16 = bf16(LayerNorm_fp32(float(x bf16 [M,D]); eps) * w + b)   (clip_vit.py:159-165) */
+int reed_ln_affine_bf16(const void* x, const float* w, const float* b, void* out, int M, int D, float eps,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,8 +46,10 @@ extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, c
   a.dbias = dbias;
   a.accumulate = accumulate;
   a.slab_stride = slab_stride;
-  REED_CHECK_ARG(P && Q && (C || epilogue == EPI_GELU || epilogue == EPI_SILU), "reed_gemm: null operand");
-  if (epilogue == EPI_GELU || epilogue == EPI_SILU) REED_CHECK_ARG(C2, "reed_gemm: activation epilogue needs C2");
+  const bool act_epi = epilogue == EPI_GELU || epilogue == EPI_SILU || epilogue == EPI_QGELU;
+  REED_CHECK_ARG(P && Q && (C || act_epi), "reed_gemm: null operand");
+  if (act_epi) REED_CHECK_ARG(C2, "reed_gemm: activation epilogue needs C2");
+  if (epilogue == EPI_RES_BF16) REED_CHECK_ARG(R, "reed_gemm: residual epilogue needs R");
   if (epilogue == EPI_GATE_RES) REED_CHECK_ARG(R && gate, "reed_gemm: gate-residual epilogue needs R and gate");
   if (epilogue == EPI_DGELU || epilogue == EPI_DSILU) REED_CHECK_ARG(R, "reed_gemm: activation-grad epilogue needs R");
   return reed_gemm_launch(layout, epilogue, a, split_k, (hipStream_t)stream);

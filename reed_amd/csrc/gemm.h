@@ -12,7 +12,10 @@ enum {
   EPI_DSILU = 5,      // C bf16 = bf16(bf16(acc) * silu'(R bf16))
   EPI_F32 = 6,        // C f32 (+)= acc [+bias]; split-K writes slabs C + z*slab_stride
   EPI_ADDF32_RB = 7,  // C f32 += float(bf16(acc))
-  EPI_ATOMIC_F32 = 8  // atomicAdd(C f32, acc)   (split-K into a pre-zeroed / accumulating buffer)
+  EPI_ATOMIC_F32 = 8, // atomicAdd(C f32, acc)   (split-K into a pre-zeroed / accumulating buffer)
+  // inference-only epilogues of the frozen CLIP image encoder (bf16 residual stream):
+  EPI_QGELU = 9,      // C2 bf16 = QuickGELU(pre) = bf16(pre * bf16(sigmoid(bf16(1.702 pre)))), pre = bf16(acc+bias) (C optional)
+  EPI_RES_BF16 = 10   // C bf16 = bf16(bf16(acc+bias) + R bf16)
 };
 
 struct GemmArgs {

@@ -350,6 +350,8 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
     case EPI_F32: return launch256<LAY, EPI_F32>(a, splits, s);
     case EPI_ADDF32_RB: return launch256<LAY, EPI_ADDF32_RB>(a, splits, s);
     case EPI_ATOMIC_F32: return launch256<LAY, EPI_ATOMIC_F32>(a, splits, s);
+    case EPI_QGELU: return launch256<LAY, EPI_QGELU>(a, splits, s);
+    case EPI_RES_BF16: return launch256<LAY, EPI_RES_BF16>(a, splits, s);
   }
   reed_set_error("reed_gemm: unknown epilogue %d", epi);
   return REED_ERR_ARG;

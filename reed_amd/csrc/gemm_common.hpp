@@ -78,7 +78,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int EPI, int NI>
 struct EpiOps {
   static constexpr int value = EPI == EPI_BF16 ? 1 + NI * 2
-                               : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU) ? 1 + NI * 4
+                               : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU ||
+                                  EPI == EPI_QGELU || EPI == EPI_RES_BF16) ? 1 + NI * 4
                                : EPI == EPI_GATE_RES ? 1 + NI * 12
                                                      : -1;  // fp32-accumulate epilogues: pointer path, not counted
 };
@@ -174,7 +175,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           st_bf16x8(o, rsC, oc + h * s8);
         }
       }
-    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU) {
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU) {
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsC2 = tile_rsrc(a.C2, a.ldc2, 2);
       int oc = lane_off(a.ldc, 2), oc2 = lane_off(a.ldc2, 2);
       const int s8 = (int)(8 * a.ldc * 2), t8 = (int)(8 * a.ldc2 * 2);
@@ -189,7 +190,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           for (int e = 0; e < 8; ++e) {
             pre[e] = f2bf(v[h][e]);
             float x = bf2f(pre[e]);
-            act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
+            if constexpr (EPI == EPI_QGELU)   // x * sigmoid(1.702 x) with eager-mode bf16 roundings (clip_vit.py:168-170)
+              act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+            else
+              act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
           }
           st_bf16x8(pre, rsC, oc + h * s8);    // empty descriptor when the pre-activation is not wanted
           st_bf16x8(act, rsC2, oc2 + h * t8);
@@ -243,7 +247,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           st_f32x4(xo[1], rsC, oc + h * s8 + 16);
         }
       }
-    } else {  // EPI_DGELU / EPI_DSILU
+    } else {  // EPI_DGELU / EPI_DSILU / EPI_RES_BF16
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsR = tile_rsrc(a.R, a.ldr, 2);
       int oc = lane_off(a.ldc, 2), orr = lane_off(a.ldr, 2);
       const int s8 = (int)(8 * a.ldc * 2), r8 = (int)(8 * a.ldr * 2);
@@ -261,7 +265,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           for (int e = 0; e < 8; ++e) {
             float du = bfround(v[h][e]);
             float x = bf2f(pre[h][e]);
-            o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
+            if constexpr (EPI == EPI_RES_BF16) o[e] = f2bf(du + x);   // bf16 residual stream (frozen encoder)
+            else o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
           }
           st_bf16x8(o, rsC, oc + h * s8);
         }

@@ -13,7 +13,8 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
-EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32 = range(9)
+(EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32, EPI_QGELU,
+ EPI_RES_BF16) = range(11)
 
 
 def _p(t):
@@ -249,6 +250,19 @@ def final_layer_fwd(x, shift, scale, ldmod, w, bias, out, mean, rstd, B, T, D, C
 def final_layer_bwd_rows(dout, x, mean, rstd, shift, scale, ldmod, w, hbuf, dlin, dh, B, T, D, C, P):
     _call("reed_final_layer_bwd_rows", _p(dout), _p(x), _p(mean), _p(rstd), _p(shift), _p(scale), ldmod, _p(w),
           _p(hbuf), _p(dlin), _p(dh), B, T, D, C, P, _stream())
+
+
+# ---------------- frozen CLIP image encoder (forward only) ----------------
+def clip_im2col(img, out, B, S, P, Kp):
+    _call("reed_clip_im2col", _p(img), _p(out), B, S, P, Kp, _stream())
+
+
+def clip_tokens(patches, cls, pos, out, B, T, D):
+    _call("reed_clip_tokens", _p(patches), _p(cls), _p(pos), _p(out), B, T, D, _stream())
+
+
+def ln_affine_bf16(x, w, b, out, M, D, eps=1e-5):
+    _call("reed_ln_affine_bf16", _p(x), _p(w), _p(b), _p(out), M, D, eps, _stream())
 
 
 # ---------------- loss ----------------

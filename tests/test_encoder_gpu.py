@@ -1,0 +1,107 @@
+"""Frozen CLIP image encoder on the HIP path vs the oracle under bf16 autocast (same precision) and
+vs the reference's own fp32 output (tests/golden/clip.npz): row kernels exactly / to bf16 resolution, the full tower to
+bf16 noise; ViT-L/14-shaped smoke at the real token count (T = 257: ragged attention tile, ragged GEMM rows)."""
+import pytest
+import torch
+
+from oracle import clip_vit as oclip
+from oracle import detfill
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _hip_encoder(cfg, dev, seed):
+    from reed_amd.encoders import ClipVisionEncoder
+    enc = ClipVisionEncoder(**cfg)
+    enc.load_state_dict(oclip.fill_params(cfg, base_seed=seed), strict=True)
+    return enc.to(dev).eval()
+
+
+def test_row_kernels(dev):
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(0)
+    M, D = 37, 1024
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(torch.bfloat16).to(dev)
+    w, b = (1 + 0.1 * torch.randn(D, generator=g)).to(dev), (0.1 * torch.randn(D, generator=g)).to(dev)
+    out = torch.empty_like(x)
+    ops.ln_affine_bf16(x, w, b, out, M, D)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-5)
+    torch.testing.assert_close(out.float(), bfr(ref), atol=2e-2, rtol=1e-2)
+    # im2col: exact bf16 rounding of the gathered pixels, zero padding
+    B, S, P, Kp = 2, 28, 14, 640
+    img = torch.randn(B, 3, S, S, generator=g).to(dev)
+    cols = torch.full((B * 4, Kp), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.clip_im2col(img, cols, B, S, P, Kp)
+    ref = torch.nn.functional.unfold(img, P, stride=P).transpose(1, 2).reshape(B * 4, 3 * P * P)
+    assert torch.equal(cols[:, :588].float(), bfr(ref)) and float(cols[:, 588:].abs().max()) == 0.0
+    # tokens: [class | patches] + positional embedding with the eager-mode bf16 roundings
+    T, D = 5, 128
+    patches = torch.randn(B * (T - 1), D, generator=g).to(torch.bfloat16).to(dev)
+    cls, pos = torch.randn(D, generator=g).to(dev), torch.randn(T, D, generator=g).to(dev)
+    tok = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
+    ops.clip_tokens(patches, cls, pos, tok, B, T, D)
+    ref = torch.cat([bfr(cls).expand(B, 1, D), patches.float().view(B, T - 1, D)], 1) + bfr(pos)
+    assert torch.equal(tok.float(), bfr(ref))
+
+
+def test_quickgelu_and_residual_epilogues(dev):
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 300, 384, 128
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    pre = bfr(x.float() @ w.float().t() + b.float())
+    for tile in (0, 128, 256):
+        ops.gemm_force_tile(tile)
+        act = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.NT, ops.EPI_QGELU, x, w, M, N, K, None, K, K, N, C2=act, ldc2=N, bias=b)
+        ref = bfr(pre * bfr(torch.sigmoid(bfr(1.702 * pre))))
+        torch.testing.assert_close(act.float(), ref, atol=2e-2, rtol=2e-2)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.NT, ops.EPI_RES_BF16, x, w, M, N, K, out, K, K, N, R=r, ldr=N, bias=b)
+        torch.testing.assert_close(out.float(), bfr(pre + r.float()), atol=3e-2, rtol=2e-2)
+    ops.gemm_force_tile(0)
+
+
+@pytest.mark.parametrize("tag,cfg,B", [("t2", oclip.make_config(width=128, layers=2, heads=2, patch=14, image=56), 3),
+                                       ("t3", oclip.make_config(width=256, layers=3, heads=4, patch=14, image=28), 2)])
+def test_tower_vs_oracle_and_reference(dev, tag, cfg, B):
+    enc = _hip_encoder(cfg, dev, 5)
+    x = detfill.normal((B, 3, cfg["image"], cfg["image"]), 77)
+    out = enc(x.to(dev)).float().cpu()
+    with torch.no_grad():
+        o16 = oclip.forward(oclip.fill_params(cfg, base_seed=5), cfg, x, autocast_bf16=True).float()
+    ref32 = torch.from_numpy(load("clip")[tag + ".fp32"])
+    assert out.shape == ref32.shape
+    scale = ref32.abs().max().item()
+    # same-precision oracle: bf16 noise of a 2-3 block tower; reference fp32: the reference's own bf16 gap
+    assert (out - o16).abs().max().item() <= 3e-2 * scale
+    assert (out - ref32).abs().max().item() <= 4e-2 * scale
+    cs = torch.nn.functional.cosine_similarity(out.flatten(), ref32.flatten(), dim=0).item()
+    assert cs > 0.9995, cs
+
+
+def test_vit_l14_shape_and_preprocess(dev):
+    """ViT-L/14 width / heads / token count (2 blocks keep the CPU oracle quick): T = 257 exercises the ragged second
+    key tile of the attention kernel and ragged GEMM rows (M = B·257); preprocess = train.py:53-57."""
+    from reed_amd.encoders import ClipVisionEncoder
+    cfg = oclip.make_config(width=1024, layers=2, heads=16, patch=14, image=224)
+    enc = _hip_encoder(cfg, dev, 9)
+    raw = (torch.arange(2 * 3 * 256 * 256) * 7 % 251).reshape(2, 3, 256, 256).to(torch.uint8)
+    pre_hip = ClipVisionEncoder.preprocess(raw.to(dev)).cpu()
+    pre_ref = oclip.preprocess(raw)
+    torch.testing.assert_close(pre_hip, pre_ref, atol=1e-4, rtol=1e-4)
+    out = enc.encode_raw(raw.to(dev)).float().cpu()
+    with torch.no_grad():
+        o16 = oclip.forward(oclip.fill_params(cfg, base_seed=9), cfg, pre_ref, autocast_bf16=True).float()
+    assert out.shape == (2, 256, 1024)
+    scale = o16.abs().max().item()
+    assert (out - o16).abs().max().item() <= 3e-2 * scale
+    assert torch.nn.functional.cosine_similarity(out.flatten(), o16.flatten(), dim=0).item() > 0.9995

@@ -259,3 +259,28 @@ def test_optim_toy():
             ema[i] = ema[i] * 0.99 + ps[i] * 0.01
             np.testing.assert_allclose(ps[i].numpy(), g[f"p{s}_{i}"], rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(ema[i].numpy(), g[f"e{s}_{i}"], rtol=2e-5, atol=1e-6)
+
+
+def test_clip_encoder_oracle_vs_reference():
+    """Frozen CLIP image encoder: oracle/clip_vit.py against the outputs of the reference's own
+    LayerNorm / ResidualAttentionBlock / Transformer / UpdatedVisionTransformer (clip_vit.py:159-230), fp32 ≤ 2e-5 and
+    bf16-autocast within bf16 noise; the 'clip' preprocessing geometry (train.py:53-57) on a fixed ramp."""
+    from oracle import clip_vit as oclip
+    g = load("clip")
+    for tag, cfg, B in (("t2", oclip.make_config(width=128, layers=2, heads=2, patch=14, image=56), 3),
+                        ("t3", oclip.make_config(width=256, layers=3, heads=4, patch=14, image=28), 2)):
+        P = oclip.fill_params(cfg, base_seed=5)
+        x = detfill.normal((B, 3, cfg["image"], cfg["image"]), 77)
+        with torch.no_grad():
+            o32 = oclip.forward(P, cfg, x)
+            o16 = oclip.forward(P, cfg, x, autocast_bf16=True).float()
+        ref32, ref16 = torch.from_numpy(g[tag + ".fp32"]), torch.from_numpy(g[tag + ".bf16"])
+        assert o32.shape == ref32.shape == (B, (cfg["image"] // 14) ** 2, cfg["width"])
+        torch.testing.assert_close(o32, ref32, atol=2e-5, rtol=2e-5)
+        torch.testing.assert_close(o16, ref16, atol=2e-2, rtol=2e-2)
+    raw = (torch.arange(2 * 3 * 256 * 256) % 251).reshape(2, 3, 256, 256).to(torch.uint8)
+    pre = oclip.preprocess(raw)
+    mean = torch.tensor(oclip.CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(oclip.CLIP_STD).view(1, 3, 1, 1)
+    assert pre.shape == (2, 3, 224, 224)
+    torch.testing.assert_close((pre * std + mean)[:, :, ::37, ::41], torch.from_numpy(g["pre.sample"]), atol=1e-5, rtol=1e-5)

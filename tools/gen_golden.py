@@ -389,6 +389,41 @@ def g_xl_c4(ref_sit, ref_loss, ref_samplers):
     save("xl2_c4", **{k: np.array(v) for k, v in rec.items()}, **{"w." + k: v for k, v in probe.items()})
 
 
+def g_clip(ref_sit, ref_loss, ref_samplers):
+    """Frozen CLIP image encoder: the reference's own LayerNorm / ResidualAttentionBlock / Transformer
+    / UpdatedVisionTransformer.forward (image/models/clip_vit.py:159-230) on a container that holds what openai/CLIP's
+    VisionTransformer holds (that class itself lives in the un-vendored `clip` package; the module's top-level
+    `import clip` is satisfied by an empty stand-in). fp32 and bf16-autocast outputs for two tiny configurations."""
+    import types
+    sys.modules.setdefault("clip", types.ModuleType("clip"))
+    from models import clip_vit as ref_clip
+    from oracle import clip_vit as oclip
+    out = {}
+    for tag, cfg, B in (("t2", oclip.make_config(width=128, layers=2, heads=2, patch=14, image=56), 3),
+                        ("t3", oclip.make_config(width=256, layers=3, heads=4, patch=14, image=28), 2)):
+        P = oclip.fill_params(cfg, base_seed=5)
+        vis = torch.nn.Module()
+        vis.conv1 = torch.nn.Conv2d(3, cfg["width"], cfg["patch"], cfg["patch"], bias=False)
+        vis.class_embedding = torch.nn.Parameter(P["class_embedding"].clone())
+        vis.positional_embedding = torch.nn.Parameter(P["positional_embedding"].clone())
+        vis.ln_pre = ref_clip.LayerNorm(cfg["width"])
+        vis.transformer = ref_clip.Transformer(cfg["width"], cfg["layers"], cfg["heads"])
+        missing = vis.load_state_dict({k: v for k, v in P.items()}, strict=True)
+        enc = ref_clip.UpdatedVisionTransformer(vis).eval()
+        x = detfill.normal((B, 3, cfg["image"], cfg["image"]), 77)
+        with torch.no_grad():
+            out[tag + ".fp32"] = enc(x).numpy()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out[tag + ".bf16"] = enc(x).float().numpy()
+    # preprocess_raw_image (train.py:53-57, 'clip' branch) cannot be imported (train.py needs diffusers/wandb): its
+    # three torch calls are restated in oracle.clip_vit.preprocess; pin the bicubic geometry on a fixed ramp
+    raw = (torch.arange(2 * 3 * 256 * 256) % 251).reshape(2, 3, 256, 256).to(torch.uint8)
+    xr = raw.float() / 255.
+    xr = torch.nn.functional.interpolate(xr, 224, mode='bicubic')
+    out["pre.sample"] = xr[:, :, ::37, ::41].numpy()
+    save("clip", **out)
+
+
 def g_sched(ref_sit, ref_loss, ref_samplers):
     """G-j: optimiser toy (clip + AdamW + EMA on a 3-tensor toy) — schedules are pure python in train.py's main()
     (not importable: needs diffusers/wandb), so they are pinned by hand-derived values in tests instead."""
@@ -430,7 +465,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "clip": g_clip}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
