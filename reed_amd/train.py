@@ -14,7 +14,8 @@ Deliberate fixes of reference defects: `--enc-type None` = align
 sampling at step 1 / every --sampling-steps runs only if a VAE decoder is importable (§9-2); checkpoints and
 args.json are written regardless of --report-to (§9-11); gradients are clipped once and the pre-clip norm is
 logged (§9-5); unknown --text-embeds-dir names get their width from the first .npy (§9-9).
-Additive flags: --features-dirs (precomputed frozen-encoder features, §8f N2), --synthetic N (random latents),
+Additive flags: --features-dirs (precomputed frozen-encoder features, §8f N2), --encoder-ckpts (clip-vit-* encoder run
+on the GPU every step from a user-supplied state dict, reed_amd/encoders.py), --synthetic N (random latents),
 --log-every.
 """
 import argparse
@@ -96,6 +97,9 @@ def parse_args(input_args=None):
     # additive (not in the reference)
     parser.add_argument("--features-dirs", type=str, nargs="*", default=None,
                         help="precomputed frozen-encoder features, one dir per --enc-type entry")
+    parser.add_argument("--encoder-ckpts", type=str, nargs="*", default=None,
+                        help="state dicts of the frozen image encoders, one per --enc-type entry: the encoder runs on the "
+                             "GPU every step as in the reference (clip-vit-* only: reed_amd/encoders.py, SURVEY.md §8f N2)")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir")
     parser.add_argument("--log-every", type=int, default=1)
     return parser.parse_args(input_args) if input_args is not None else parser.parse_args()
@@ -197,10 +201,25 @@ def main(args):
         assert len(args.repa_coeff) == len(enc_names), \
             f"Number of alignment loss coefficients {len(args.repa_coeff)} must match the total number of encoders {len(enc_names)}."
     n_img_enc = z_types.count("i")
-    if n_img_enc and not args.synthetic and not args.features_dirs:
+    encoders = []
+    if args.encoder_ckpts:   # on-the-fly frozen encoders, as train.py:182-186,351-357 (CLIP towers only)
+        from .encoders import load_clip_encoder
+        if args.features_dirs or args.synthetic:
+            raise ValueError("--encoder-ckpts excludes --features-dirs / --synthetic")
+        items = args.enc_type.split(",")
+        if len(args.encoder_ckpts) != n_img_enc:
+            raise ValueError("--encoder-ckpts needs one checkpoint per --enc-type entry")
+        for item, path in zip(items, args.encoder_ckpts):
+            etype, _arch, cfg = item.split("-")
+            if etype != "clip":
+                raise NotImplementedError(f"on-device frozen encoder '{item}': only clip-vit-* is built (its definition is "
+                                          "in the reference, image/models/clip_vit.py); use --features-dirs for the others")
+            encoders.append(load_clip_encoder(cfg[0].upper(), path, device))
+    if n_img_enc and not args.synthetic and not args.features_dirs and not encoders:
         raise NotImplementedError(
-            "on-the-fly frozen encoders (DINOv2/CLIP/...) are outside this build (no weights offline; SURVEY.md §8f N2). "
-            "Pass --features-dirs <dir per encoder> with precomputed [256,z] features, --synthetic N, or --enc-type None.")
+            "this build ships no encoder weights (no network; SURVEY.md §8f N2). Pass --encoder-ckpts <state dict per "
+            "clip-vit-* encoder> to run the frozen encoder on the GPU every step, --features-dirs <dir per encoder> with "
+            "precomputed [256,z] features, --synthetic N, or --enc-type None.")
     if args.features_dirs and len(args.features_dirs) != n_img_enc:
         raise ValueError("--features-dirs needs one directory per --enc-type entry")
 
@@ -225,7 +244,7 @@ def main(args):
                                    latent=latent_size)
     else:
         dataset = CustomDataset(args.data_dir, text_embeds_dir=args.text_embeds_dir,
-                                features_dirs=args.features_dirs, need_images=False)
+                                features_dirs=args.features_dirs, need_images=bool(encoders))
     # every rank sees the same shuffled order and takes every world-th batch (accelerate BatchSamplerShard, §8a T6)
     gen = torch.Generator().manual_seed(args.seed or 0)
     sampler = torch.utils.data.RandomSampler(dataset, generator=gen)
@@ -270,6 +289,9 @@ def main(args):
         for item in loader:
             _raw, moments, y, textemb = item[:4]
             zs = [z.to(device, non_blocking=True) for z in item[4:]]
+            if encoders:   # train.py:351-357: frozen encoder forward on the raw images, no grad
+                raw = _raw.to(device, non_blocking=True)
+                zs = [enc.encode_raw(raw) for enc in encoders]
             moments = moments.squeeze(dim=1).to(device, non_blocking=True)
             y = y.to(device, non_blocking=True)
             if args.legacy:  # label dropping applied twice (train.py:338-343), kept for reproducibility

@@ -97,3 +97,40 @@ def test_rccl_reducer_world1(dev, binding):
         os.environ.pop("REED_COMM", None)
         if binding == "torch" and dist.is_initialized():
             dist.destroy_process_group()
+
+
+def test_train_with_on_device_clip_encoder(dev, tmp_path, monkeypatch):
+    """train.py counterpart on the reference's on-disk format (images/*.png + vae-sd/*.npy + dataset.json,
+    image/dataset.py:18-85) with the frozen CLIP image encoder running on the GPU every step from a user-supplied
+    state dict (--encoder-ckpts). A 1-block tower of ViT-L/14 width stands in for the 24-block one."""
+    import PIL.Image
+    from oracle import clip_vit as oclip
+    from reed_amd import encoders, train
+    data = tmp_path / "data"
+    (data / "images" / "00000").mkdir(parents=True)
+    (data / "vae-sd" / "00000").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    labels = []
+    for i in range(8):
+        img = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+        PIL.Image.fromarray(img).save(data / "images" / "00000" / f"img{i:08d}.png")
+        mom = np.concatenate([rng.standard_normal((4, 32, 32)) * 5.0, np.full((4, 32, 32), 0.5)]).astype(np.float32)
+        np.save(data / "vae-sd" / "00000" / f"img-mean-std-{i:08d}.npy", mom)
+        labels.append([f"00000/img-mean-std-{i:08d}.npy", int(i % 5)])
+    json.dump({"labels": labels}, open(data / "vae-sd" / "dataset.json", "w"))
+    cfg = oclip.make_config(width=1024, layers=1, heads=16, patch=14, image=224)
+    monkeypatch.setitem(encoders.CLIP_CONFIGS, "L", cfg)
+    sd = {"visual." + k: v for k, v in oclip.fill_params(cfg, base_seed=1).items()}   # a full-CLIP style state dict
+    sd["visual.proj"] = torch.zeros(1024, 768)
+    ck = str(tmp_path / "clip_visual.pt")
+    torch.save(sd, ck)
+    a = train.parse_args(["--exp-name", "clip", "--model", "SiT-S/2", "--output-dir", str(tmp_path / "exps"),
+                          "--data-dir", str(data), "--enc-type", "clip-vit-L", "--encoder-ckpts", ck,
+                          "--mixed-precision", "bf16", "--batch-size", "4", "--num-workers", "0",
+                          "--diffusion-warm-up-steps", "0", "--report-to", "none", "--max-train-steps", "3",
+                          "--num-classes", "5", "--checkpointing-steps", "100"])
+    d = train.main(a)
+    logs = [json.loads(l) for l in open(os.path.join(d, "metrics.jsonl"))]
+    assert len(logs) == 3 and all(np.isfinite(r["proj_loss"]) and np.isfinite(r["training_denoising_loss"]) for r in logs)
+    assert logs[0]["img_proj_loss"] != 0.0
+    torch.set_grad_enabled(True)
