@@ -167,8 +167,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # REED_FORCE_REDUCER=1 drives the whole multi-GPU code path (process group, RCCL reducer, barriers, MAX over ranks)
+    # with a single rank: the only rehearsal of it a one-GPU box allows
+    use_dist = world > 1 or os.environ.get("REED_FORCE_REDUCER", "0") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import copy
     from reed_amd.loss import SILoss
@@ -198,7 +203,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +217,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(res["loss"])
@@ -265,12 +270,12 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:   # rank 0 is still timing the kernel table: nobody tears a communicator down under it
+    if use_dist:   # rank 0 is still timing the kernel table: nobody tears a communicator down under it
         torch.cuda.synchronize()
         dist.barrier()
     if reducer is not None:
         reducer.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
