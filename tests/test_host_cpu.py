@@ -299,3 +299,54 @@ def test_update_chunks_cover_arena_in_forward_order():
              z_types=[], encoder_depth=2, projector_dim=128)
     n2 = [n for n, _, _ in m2._layout.update_chunks(())]
     assert n2 == ["embed", "ada_head", "block0", "block1", "block2", "ada_tail", "final"]
+
+
+def _tiny_dataset(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tools", "gen_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    root = str(tmp_path / "tinyds")
+    os.makedirs(root)
+    mod.make_tiny_dataset(root)
+    return root
+
+
+def test_dataset_and_packed_dataset_match_reference_bit_exact(tmp_path):
+    """Data path: `CustomDataset` on the reference's on-disk format returns, item by item and field
+    by field, exactly what the reference's own loader returned (tests/golden/dataset.npz, image/dataset.py:18-85 run by
+    tools/gen_golden.py on the same bytes): image bytes, moments, label from the un-sorted dataset.json, text embedding
+    or its zeros_like(moments) stand-in. `pack_dataset` + `PackedDataset` return the same items again, with and without
+    images / text / precomputed features."""
+    from reed_amd.dataset import CustomDataset, PackedDataset, pack_dataset
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dataset.npz"))
+    root = _tiny_dataset(tmp_path)
+    for tag, td in (("plain", None), ("text", "text_embeds_t")):
+        ds = CustomDataset(root, text_embeds_dir=td)
+        meta = pack_dataset(root, str(tmp_path / f"packed_{tag}"), text_embeds_dir=td)
+        pk = PackedDataset(str(tmp_path / f"packed_{tag}"))
+        assert len(ds) == len(pk) == int(g[tag + ".len"]) == meta["n"]
+        for i in range(len(ds)):
+            for item in (ds[i], pk[i]):
+                im, mo, la, tx = item[:4]
+                assert im.dtype == torch.uint8 and np.array_equal(im.numpy(), g[f"{tag}.{i}.image"])
+                assert mo.dtype == torch.float32 and np.array_equal(mo.numpy(), g[f"{tag}.{i}.moments"])
+                assert la.dtype == torch.int64 and int(la) == int(g[f"{tag}.{i}.label"])
+                assert np.array_equal(tx.numpy(), g[f"{tag}.{i}.text"]) and tx.dtype == torch.float32
+    # precomputed features, no images: packed == unpacked
+    import shutil
+    fz = os.path.join(root, "feat_a")
+    for i in range(6):
+        os.makedirs(os.path.join(fz, f"{i // 4:05d}"), exist_ok=True)
+        np.save(os.path.join(fz, f"{i // 4:05d}", f"img{i:08d}.npy"), np.full((4, 8), float(i), dtype=np.float32))
+    ds = CustomDataset(root, features_dirs=["feat_a"], need_images=False)
+    pack_dataset(root, str(tmp_path / "packed_z"), features_dirs=["feat_a"], with_images=False)
+    pk = PackedDataset(str(tmp_path / "packed_z"))
+    assert "images" not in pk.arr and pk.zkeys == ["z0"]
+    for i in range(6):
+        a, b = ds[i], pk[i]
+        assert len(a) == len(b) == 5 and a[0].numel() == b[0].numel() == 0
+        for x, y in zip(a[1:], b[1:]):
+            assert x.dtype == y.dtype and torch.equal(x, y)
+        assert float(a[4][0, 0]) == float(i)
+    shutil.rmtree(root)

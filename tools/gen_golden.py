@@ -424,6 +424,44 @@ def g_clip(ref_sit, ref_loss, ref_samplers):
     save("clip", **out)
 
 
+def make_tiny_dataset(root, n=6, text_dim=16):
+    """Deterministic tiny dataset in the reference's on-disk format (image/dataset.py:18-85; written by
+    preprocessing/dataset_tools.py): images/XXXXX/imgNNNNNNNN.png, vae-sd/XXXXX/img-mean-std-NNNNNNNN.npy,
+    vae-sd/dataset.json, text_embeds_t/XXXXX/imgNNNNNNNN.npy. Used by the generator (reference loader) and by the tests
+    (build loaders), so both read identical bytes."""
+    import json
+    import PIL.Image
+    labels = []
+    for i in range(n):
+        sub = f"{i // 4:05d}"
+        for d in ("images", "vae-sd", "text_embeds_t"):
+            os.makedirs(os.path.join(root, d, sub), exist_ok=True)
+        img = (detfill.uniform((64, 64, 3), 1000 + i, 0, 256).numpy()).astype(np.uint8)
+        PIL.Image.fromarray(img).save(os.path.join(root, "images", sub, f"img{i:08d}.png"))
+        np.save(os.path.join(root, "vae-sd", sub, f"img-mean-std-{i:08d}.npy"), detfill.normal((8, 8, 8), 2000 + i).numpy())
+        np.save(os.path.join(root, "text_embeds_t", sub, f"img{i:08d}.npy"), detfill.normal((text_dim,), 3000 + i).numpy())
+        labels.append([f"{sub}/img-mean-std-{i:08d}.npy", int((i * 7) % 10)])
+    with open(os.path.join(root, "vae-sd", "dataset.json"), "w") as f:
+        json.dump({"labels": labels[::-1]}, f)   # file order differs from sorted order on purpose
+
+
+def g_dataset(ref_sit, ref_loss, ref_samplers):
+    """image/dataset.py:18-85 CustomDataset (the module imports here: torch, numpy, PIL only) on the tiny dataset above,
+    with and without text embeddings: every field of every item."""
+    import dataset as ref_dataset
+    root = tempfile.mkdtemp(prefix="tinyds_")
+    make_tiny_dataset(root)
+    out = {}
+    for tag, td in (("plain", None), ("text", "text_embeds_t")):
+        ds = ref_dataset.CustomDataset(root, text_embeds_dir=td)
+        out[tag + ".len"] = np.array(len(ds))
+        for i in range(len(ds)):
+            im, mo, la, tx = ds[i]
+            out[f"{tag}.{i}.image"], out[f"{tag}.{i}.moments"] = im.numpy(), mo.numpy()
+            out[f"{tag}.{i}.label"], out[f"{tag}.{i}.text"] = la.numpy(), tx.numpy()
+    save("dataset", **out)
+
+
 def g_sched(ref_sit, ref_loss, ref_samplers):
     """G-j: optimiser toy (clip + AdamW + EMA on a 3-tensor toy) — schedules are pure python in train.py's main()
     (not importable: needs diffusers/wandb), so they are pinned by hand-derived values in tests instead."""
@@ -465,7 +503,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "clip": g_clip}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "clip": g_clip, "dataset": g_dataset}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
