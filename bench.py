@@ -89,8 +89,8 @@ def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
     ws = torch.empty(8 * (Hm * D + Hm), device=dev)
 
     def wgrad(dy, xx, N, K, with_bias=True):
-        _, split = ops.plan_wgrad(M, N, K)
-        ops.linear_wgrad(dy, xx, gw, dbias=gb if with_bias else None, split_k=split, Mtok=M, N=N, K=K, ws=ws)
+        lay, split = ops.plan_wgrad(M, N, K)
+        ops.linear_wgrad(dy, xx, gw, dbias=gb if with_bias else None, split_k=split, Mtok=M, N=N, K=K, ws=ws, lay=lay)
 
     def dgrad(epi, dy, w, N, K, out, **kw):
         ops.gemm(ops.NN, epi, dy, w, M, K, N, out, N, K, K, **kw)

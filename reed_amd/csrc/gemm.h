@@ -2,7 +2,8 @@
 #pragma once
 #include "common.hpp"
 
-enum { LAY_NT = 0, LAY_NN = 1, LAY_TN = 2 };
+enum { LAY_NT = 0, LAY_NN = 1, LAY_TN = 2,
+       LAY_TN_TALL = 3, LAY_TN_WIDE = 4 };   // TN on gemm_tn.hip's 256x128 / 128x256 tile (fp32 epilogue only)
 enum {
   EPI_BF16 = 0,       // C bf16 = bf16(acc [+bias])
   EPI_GELU = 1,       // C bf16 = pre = bf16(acc+bias) (optional), C2 bf16 = gelu_tanh(pre)

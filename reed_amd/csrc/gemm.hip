@@ -21,6 +21,7 @@
 #include "gemm_common.hpp"
 
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);
+int reed_gemm_tn_launch(int tile, GemmArgs a, int splits, hipStream_t stream);   // gemm_tn.hip
 bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits);
 
 namespace {
@@ -223,6 +224,11 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                  "reed_gemm: output/residual leading dims must be multiples of 8 below 2^20 (32-bit tile offsets)");
   REED_CHECK_ARG(((uintptr_t)a.P % 16) == 0 && ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
                  "reed_gemm: operands must be 16-byte aligned");
+  const int tn_tile = layout == LAY_TN_TALL ? 1 : layout == LAY_TN_WIDE ? 2 : 0;   // gemm_tn.hip's 256x128 / 128x256 tiles
+  if (tn_tile) {
+    REED_CHECK_ARG(epi == EPI_F32, "reed_gemm(TN 256x128 / 128x256): fp32 (weight-gradient) epilogue only");
+    layout = LAY_TN;
+  }
   if (layout == LAY_TN) {
     REED_CHECK_ARG(a.M % BM == 0, "reed_gemm(TN): M=%d must be a multiple of %d", a.M, BM);
   } else {
@@ -238,6 +244,7 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
     REED_CHECK_ARG(epi == EPI_ATOMIC_F32 || (epi == EPI_F32 && a.slab_stride > 0),
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
+  if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
   if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, a, splits)) &&
       !(layout == LAY_TN && a.dbias))
     return reed_gemm256_launch(layout, epi, a, splits, stream);

@@ -1,0 +1,171 @@
+// Weight-gradient GEMM (TN: C[M,N] f32 (+)= P[K,M]^T Q[K,N], K = tokens) on a 256x128 (or 128x256) output tile with
+// 128x64 (64x128) wave tiles — the dominant kernel of the SiT train step (reference: autograd of every nn.Linear,
+// image/models/sit.py:17-24,114-129; timm Attention / Mlp).
+//
+// Why another tile: the 128^2 kernel of gemm.hip gives each of its 4 waves a 64x64 piece, i.e. 8 fragment reads (16
+// ds_read_b64_tr_b16, 8 KiB) per 16 MFMAs; with two workgroups per CU the LDS pipe is then as loaded as the MFMA pipe
+// (profiles/r1_pmc_gemm.txt: MFMA busy 50 %).  Here a wave owns 128x64: 12 fragments per 32 MFMAs (0.375 instead of
+// 0.5 reads per MFMA) and the workgroup stages 24 KiB instead of 32 KiB per 32 MFMAs per wave.  BK = 32 keeps the
+// barrier cadence (one per 32 MFMAs per wave), the LDS footprint (48 KiB double-buffered) and the occupancy (4 waves,
+// two workgroups per CU) of the 128^2 kernel.  256x128 suits outputs whose row count is a multiple of 256 or large
+// (fc1 4608x1152, qkv 3456x1152: the half-empty 14th tile row costs 3.6 %); WIDE = 128x256 is the same kernel turned
+// for fc2 (1152x4608).  Ragged M needs no masking: rows >= M read whatever the descriptor returns and are never stored.
+// Operand tiles use gemm_common.hpp's k-strided format ([k][128 columns], 256-B rows, chunk swizzle tr_sw) at 32
+// k-rows per tile and are read with the transposing LDS read; staging is LDS-DMA as in gemm.hip.
+#include "gemm_common.hpp"
+
+namespace {
+using namespace gemm_detail;
+
+constexpr int TBK = 32;
+constexpr int SUB_BYTES = 32 * 256;   // one [32 k][128 col] sub-tile
+
+// stage one [32][128] sub-tile: 512 16-byte chunks, 2 per thread; rs is based at the tile's first column of row 0
+__device__ __forceinline__ void stage_sub(__amdgpu_buffer_rsrc_t rs, char* tile, long ld, int k0, int col0, int tid,
+                                          int wave) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int L = i * 256 + tid;
+    const int r = L >> 4, chp = L & 15;
+    const int ch = chp ^ tr_sw(r);
+    const int voff = (int)(((long)(k0 + r) * ld + col0 + ch * 8) * 2);
+    char* dst = tile + (i * 256 + wave * 64) * 16;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+  }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
+  constexpr int TM = WIDE ? 4 : 8, TNN = WIDE ? 8 : 4;        // 16x16 MFMA tiles per wave along M / N
+  constexpr int PSUB = WIDE ? 1 : 2, QSUB = WIDE ? 2 : 1;     // 128-column sub-tiles of the P / Q operand tile
+  constexpr int BMT = PSUB * 128, BNT = QSUB * 128;
+  constexpr int STAGE = (PSUB + QSUB) * SUB_BYTES;            // 24 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntm = (a.M + BMT - 1) / BMT, ntn = a.N / BNT;
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = bid / per_group, first_m = group * GM;
+  const int gs = min(ntm - first_m, GM);
+  const int tm = first_m + (bid % per_group) % gs;
+  const int tn = (bid % per_group) / gs;
+  const int z = blockIdx.y;
+  const int m0 = tm * BMT, n0 = tn * BNT;
+  const int kbeg = z * a.ksplit_len;
+  const int kend = min(a.K, kbeg + a.ksplit_len);
+  const int nt = (kend - kbeg + TBK - 1) / TBK;
+
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
+  auto stage = [&](int t, int buf) {
+    char* tp = smem + buf * STAGE;
+    const int k0 = kbeg + t * TBK;
+#pragma unroll
+    for (int s = 0; s < PSUB; ++s) stage_sub(rsP, tp + s * SUB_BYTES, a.ldp, k0, s * 128, tid, wave);
+#pragma unroll
+    for (int s = 0; s < QSUB; ++s) stage_sub(rsQ, tp + (PSUB + s) * SUB_BYTES, a.ldq, k0, s * 128, tid, wave);
+  };
+
+  f32x4 acc[TM][TNN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TNN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_dbias = a.dbias != nullptr && tn == 0 && wn == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  // the wave's rows / columns inside the operand tiles: sub-tile + column base
+  const int prow = wm * (TM * 16), pcol = wn * (TNN * 16);
+
+  if (nt > 0) stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const char* tp = smem + buf * STAGE;
+    const char* tq = tp + PSUB * SUB_BYTES;
+    bf16x8 pf[TM], qf[TNN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int c = prow + i * 16;
+      pf[i] = frag_tr(tp + (c >> 7) * SUB_BYTES, c & 127, 0, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < TNN; ++j) {
+      const int c = pcol + j * 16;
+      qf[j] = frag_tr(tq + (c >> 7) * SUB_BYTES, c & 127, 0, lane);
+    }
+    REED_LDS_WAIT();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TNN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+    if (do_dbias) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], accb[i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // fp32 output (slabs / accumulate): pointer-path epilogue, 64 columns at a time
+#pragma unroll
+  for (int h = 0; h < TNN / 4; ++h) {
+    f32x4 part[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[i][j] = acc[i][h * 4 + j];
+    tile_epilogue_ptr<EPI_F32, TM>(a, part, m0 + prow, n0 + pcol + h * 64, lane, z);
+  }
+  if (do_dbias && (lane >> 4) == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + prow + i * 16 + (lane & 15);
+      if (m < a.M) {
+        if (gridDim.y > 1) a.dbias[(long)z * a.slab_stride + m] = accb[i][0];
+        else if (a.accumulate) a.dbias[m] += accb[i][0];
+        else a.dbias[m] = accb[i][0];
+      }
+    }
+  }
+}
+
+template <bool WIDE>
+int launch_tn(const GemmArgs& a, int splits, hipStream_t stream) {
+  constexpr int BMT = WIDE ? 128 : 256, BNT = WIDE ? 256 : 128;
+  constexpr int LDS = 2 * 3 * SUB_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BMT) * (a.N / BNT), splits, 1);
+  REED_KLAUNCH((gemm_tn_kernel<WIDE>), grid, dim3(256), LDS, stream, a);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+}  // namespace
+
+// tile: 1 = 256x128, 2 = 128x256.  EPI_F32 only (weight gradients); the caller has validated the arguments.
+int reed_gemm_tn_launch(int tile, GemmArgs a, int splits, hipStream_t stream) {
+  if (tile == 2) {
+    REED_CHECK_ARG(a.N % 256 == 0, "reed_gemm(TN 128x256): N=%d must be a multiple of 256", a.N);
+    return launch_tn<true>(a, splits, stream);
+  }
+  return launch_tn<false>(a, splits, stream);
+}

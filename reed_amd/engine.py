@@ -250,25 +250,25 @@ class Engine:
 
     # ---- backward ------------------------------------------------------------------
     def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev, bias_done=False, side=None):
-        """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena: the 128^2 TN kernel with wave-quantised
-        split-K through slabs (deterministic reduce, ops.plan_wgrad); the bias gradient rides along as an extra
+        """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena: the TN kernel / tile ops.plan_wgrad picks
+        (256x128, 128x256 or 128x128) with wave-quantised split-K through slabs (deterministic reduce); the bias gradient rides along as an extra
         ones-MFMA in the blocks of the first column tile unless the caller already has it (bias_done).
         side = the weight-gradient stream: the launch is ordered after everything queued on the current stream so far
         (dy is the newest tensor it reads) and runs beside the dgrad chain, which nothing downstream of it in
         backward depends on — it fills the CUs the chain's ragged last tile rounds leave idle (at b = 32/GPU a
         256-row-tile dgrad grid covers 56-84 % of the 256 CUs)."""
         bname = wname.replace("weight", "bias")
-        _, split = ops.plan_wgrad(Mtok, N, K)
+        lay, split = ops.plan_wgrad(Mtok, N, K)
         if side is None:
             ws = self.ws(split * (N * K + N), dev) if split > 1 else None
             ops.linear_wgrad(dy, x, self.G(wname), dbias=None if bias_done else self.G(bname), accumulate=acc,
-                             split_k=split, Mtok=Mtok, N=N, K=K, ws=ws)
+                             split_k=split, Mtok=Mtok, N=N, K=K, ws=ws, lay=lay)
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             ws = self.ws_side(split * (N * K + N), dev) if split > 1 else None
             ops.linear_wgrad(dy, x, self.G(wname), dbias=None if bias_done else self.G(bname), accumulate=acc,
-                             split_k=split, Mtok=Mtok, N=N, K=K, ws=ws)
+                             split_k=split, Mtok=Mtok, N=N, K=K, ws=ws, lay=lay)
         dy.record_stream(side)   # allocated on the main stream: the caching allocator must not hand these
         x.record_stream(side)    # blocks out again before the side stream's reads have finished
 

@@ -13,6 +13,7 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
+TN_TALL, TN_WIDE = 3, 4   # TN on the 256x128 / 128x256 tile of csrc/gemm_tn.hip (weight gradients)
 (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32, EPI_QGELU,
  EPI_RES_BF16) = range(11)
 
@@ -73,21 +74,21 @@ def linear_dgrad(dy, w, dx, epi=EPI_BF16, R=None, M=None, N=None, K=None, ldw=No
     gemm(NN, epi, dy, w, M, K, N, dx, N, ldw, K, R=R, ldr=K if R is not None else 0)
 
 
-def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, N=None, K=None, ws=None):
+def linear_wgrad(dy, x, dw, dbias=None, accumulate=False, split_k=1, Mtok=None, N=None, K=None, ws=None, lay=TN):
     """dw f32 [N,K] (+)= dy^T x ; dbias f32 [N] (+)= colsum(dy). dy bf16 [Mtok,N], x bf16 [Mtok,K].
     split_k>1 goes through slabs in `ws` (f32, >= split_k*(N*K+N) floats) and a deterministic reduce."""
     if Mtok is None:
         Mtok, N = dy.shape
         K = x.shape[1]
     if split_k <= 1:
-        gemm(TN, EPI_F32, dy, x, N, K, Mtok, dw, N, K, K, dbias=dbias, accumulate=accumulate)
+        gemm(lay, EPI_F32, dy, x, N, K, Mtok, dw, N, K, K, dbias=dbias, accumulate=accumulate)
         return
     slab = N * K
     stride = slab + N if dbias is not None else slab   # slab z = [dW slice z | dbias slice z]
     if ws is None:
         ws = torch.empty(split_k * stride, dtype=torch.float32, device=dw.device if torch.is_tensor(dw) else "cuda")
     wsp = ws if isinstance(ws, int) else ws.data_ptr()
-    gemm(TN, EPI_F32, dy, x, N, K, Mtok, wsp, N, K, K, dbias=wsp + 4 * slab if dbias is not None else None,
+    gemm(lay, EPI_F32, dy, x, N, K, Mtok, wsp, N, K, K, dbias=wsp + 4 * slab if dbias is not None else None,
          accumulate=False, split_k=split_k, slab_stride=stride)
     # the launcher may round the split count down; it reports nothing back, so recompute it the same way
     ksteps = (Mtok + 63) // 64
@@ -118,25 +119,35 @@ WGRAD_SLOTS = 512  # resident 128x128 blocks: 256 CUs x 2 (64 KiB LDS, <=128 VGP
 WGRAD_SPLIT_MAX = int(__import__("os").environ.get("REED_WGRAD_SPLIT_MAX", "8"))  # experiments: cap the split count
 
 
+WGRAD_TILES = ((TN, 128, 128, 1.0), (TN_TALL, 256, 128, 1.10), (TN_WIDE, 128, 256, 1.10))   # layout, rows, cols, rate
+
+
 def plan_wgrad(Mtok, N, K):
-    """(use_256_tile, split_k) for dw[N,K] = dy[Mtok,N]^T x[Mtok,K] on the 128x128 TN kernel.
-    Split-K is chosen for WAVE QUANTISATION: tiles*split should fill a whole number of rounds of the 512 resident
-    blocks (SiT-XL qkv: 243 tiles x 4 = 972 of 1024 slots; fc1/fc2: 324 x 3; proj: 81 x 6), and among equally full
-    choices the one whose K slice is closest to 256 K-tiles (16384 tokens) wins: long enough to amortise the
-    prologue/epilogue + slab traffic, short enough that two rounds overlap their tails (tools/wgrad_sweep.py)."""
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    """(layout, split_k) for dw[N,K] = dy[Mtok,N]^T x[Mtok,K]: which TN kernel and how many K slices.
+    Tiles: gemm.hip's 128x128 (64x64 per wave) or gemm_tn.hip's 256x128 / 128x256 (128x64 / 64x128 per wave: 0.375
+    instead of 0.5 LDS fragment reads per MFMA, measured ~1.10x per flop — tools/wgrad_sweep.py); all keep two
+    workgroups per CU, i.e. 512 resident blocks. Split-K is chosen for WAVE QUANTISATION: tiles*split should fill a
+    whole number of rounds of those 512 blocks (SiT-XL/2 at b=256: fc1 162 tiles of 256x128 x 3, fc2 162 of 128x256
+    x 3, qkv 126 of 256x128 x 4 with 3.6 % of the 14th tile row empty, proj 81 of 128x128 x 6), and among equally
+    good choices the one whose K slice is closest to 256 K-tiles (16384 tokens) wins: long enough to amortise the
+    prologue/epilogue + slab traffic, short enough that two rounds overlap their tails."""
     ktiles = (Mtok + 63) // 64
-    best, best_key = 1, None
-    for s in range(1, WGRAD_SPLIT_MAX + 1):
-        if s > 1 and ktiles // s < 32:
-            break
-        blocks = tiles * s
-        eff = blocks / (((blocks + WGRAD_SLOTS - 1) // WGRAD_SLOTS) * WGRAD_SLOTS)
-        dist = abs(math.log((ktiles / s) / 256.0))
-        key = (-round(eff / 0.03), dist)   # 3 % efficiency buckets, then slice length
-        if best_key is None or key < best_key:
-            best, best_key = s, key
-    return False, best
+    best, best_key = (TN, 1), None
+    for lay, bm, bn, rate in WGRAD_TILES:
+        if K % bn or N % 128:
+            continue
+        tiles = ((N + bm - 1) // bm) * (K // bn)
+        fill = (N * K) / (tiles * bm * bn)          # rows of a ragged last tile row are computed and dropped
+        for s in range(1, WGRAD_SPLIT_MAX + 1):
+            if s > 1 and ktiles // s < 32:
+                break
+            blocks = tiles * s
+            eff = blocks / (((blocks + WGRAD_SLOTS - 1) // WGRAD_SLOTS) * WGRAD_SLOTS)
+            dist = abs(math.log((ktiles / s) / 256.0))
+            key = (-round(rate * fill * eff / 0.03), dist)   # 3 % buckets of estimated throughput, then slice length
+            if best_key is None or key < best_key:
+                best, best_key = (lay, s), key
+    return best
 
 
 def reduce_slabs(slabs, stride, n, out, count, accumulate=False):

@@ -144,6 +144,55 @@ def test_tn_wgrad(dev, Mtok, N, K, split, force_tile):
         torch.testing.assert_close(db, 2 * dy.float().sum(0), atol=2e-2, rtol=1e-3)
 
 
+@pytest.mark.parametrize("lay", ["tall", "wide"])
+@pytest.mark.parametrize("Mtok,N,K,split", [(256, 128, 256, 1), (1000, 384, 256, 1), (40, 128, 512, 1), (2048, 256, 256, 4),
+                                            (4100, 1152, 768, 1), (8192, 384, 1280, 3), (8192, 3456, 1152, 4),
+                                            (4096, 1152, 4608, 3)])
+def test_tn_wgrad_tall_wide_tiles(dev, lay, Mtok, N, K, split, force_tile):
+    """gemm_tn.hip: the 256x128 / 128x256 weight-gradient tiles (128x64 / 64x128 per wave, BK 32) against fp32 torch
+    and against the 128^2 kernel: ragged last tile row (N % 256 != 0), ragged token count (Mtok % 32 != 0), split-K
+    slabs with the fused bias gradient in the slab, accumulate."""
+    from reed_amd import ops
+    if force_tile != 0:
+        pytest.skip("tile forcing does not apply to the explicit TN tile layouts")
+    L = ops.TN_TALL if lay == "tall" else ops.TN_WIDE
+    if lay == "wide" and K % 256:
+        pytest.skip("128x256 tile needs K % 256 == 0")
+    g = torch.Generator().manual_seed(13)
+    dy = _bf(torch.randn(Mtok, N, generator=g)).to(dev)
+    x = _bf(torch.randn(Mtok, K, generator=g)).to(dev)
+    out = torch.full((N * K + N,), float("nan"), device=dev)
+    dw, db = out[:N * K].view(N, K), out[N * K:]
+    ops.linear_wgrad(dy, x, dw, dbias=db, split_k=split, lay=L)       # bias right behind the weight: one slab reduce
+    ref = dy.float().t() @ x.float()
+    torch.testing.assert_close(dw, ref, atol=1e-2, rtol=1e-3)
+    torch.testing.assert_close(db, dy.float().sum(0), atol=1e-2, rtol=1e-3)
+    dw0, db0 = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.linear_wgrad(dy, x, dw0, dbias=db0, split_k=split, lay=ops.TN)
+    torch.testing.assert_close(dw, dw0, atol=2e-3, rtol=1e-4)        # same products, different summation split
+    if split == 1:
+        ops.linear_wgrad(dy, x, dw, dbias=db, accumulate=True, lay=L)
+        torch.testing.assert_close(dw, 2 * ref, atol=2e-2, rtol=1e-3)
+        torch.testing.assert_close(db, 2 * dy.float().sum(0), atol=2e-2, rtol=1e-3)
+    # identity operand: catches a transposed / shifted fragment map exactly
+    if Mtok == 256:
+        eye = torch.eye(Mtok, N, device=dev).to(torch.bfloat16)
+        xx = (torch.arange(Mtok * K, device=dev).reshape(Mtok, K) % 251).float().to(torch.bfloat16)
+        d2 = torch.zeros(N, K, device=dev)
+        ops.linear_wgrad(eye, xx, d2, lay=L)
+        assert torch.equal(d2, xx.float()[:N])
+
+
+def test_plan_wgrad_choices():
+    """ops.plan_wgrad on the SiT-XL/2 block shapes: the tile the wave-quantisation model picks (tools/wgrad_sweep.py)."""
+    from reed_amd import ops
+    M = 256 * 256
+    assert ops.plan_wgrad(M, 4608, 1152) == (ops.TN_TALL, 3)
+    assert ops.plan_wgrad(M, 1152, 4608) == (ops.TN_WIDE, 3)
+    assert ops.plan_wgrad(M, 3456, 1152) == (ops.TN_TALL, 4)
+    assert ops.plan_wgrad(M, 1152, 1152) == (ops.TN, 6)
+
+
 def test_tn_asymmetric(dev):
     from reed_amd import ops
     Mtok, N, K = 128, 128, 128

@@ -50,7 +50,7 @@ for lay in lays:
             def fn():
                 tile = ops._FORCED
                 if tile == 256:
-                    big, split = ops.plan_wgrad(M, N, K)
+                    _lay, split = ops.plan_wgrad(M, N, K)
                     ops.colsum_bf16(x, N, ws, gb, M, N)
                     ops.linear_wgrad(x, w, out, split_k=split, ws=ws.data_ptr() + 4 * ops.colsum_ws_floats(M, N))
                 else:

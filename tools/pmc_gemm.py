@@ -11,10 +11,10 @@ x, w1, b1 = bf(M, D), bf(Hm, D), bf(Hm)
 pre, act = torch.empty(M, Hm, dtype=torch.bfloat16, device=dev), torch.empty(M, Hm, dtype=torch.bfloat16, device=dev)
 dw = torch.empty(Hm, D, device=dev); db = torch.empty(Hm, device=dev); ws = torch.empty(8 * (Hm * D + Hm), device=dev)
 dx = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
-_, split = ops.plan_wgrad(M, Hm, D)
+lay, split = ops.plan_wgrad(M, Hm, D)
 for _ in range(3):
     ops.linear_fwd(x, w1, b1, pre, epi=ops.EPI_GELU, act_out=act)
-    ops.linear_wgrad(act, x, dw, dbias=db, split_k=split, Mtok=M, N=Hm, K=D, ws=ws)
+    ops.linear_wgrad(act, x, dw, dbias=db, split_k=split, Mtok=M, N=Hm, K=D, ws=ws, lay=lay)
     ops.gemm(ops.NN, ops.EPI_BF16, act, w1, M, D, Hm, dx, Hm, D, D)
 torch.cuda.synchronize()
 print("done")

@@ -18,11 +18,11 @@ xf, dxf = torch.randn(M, D, device=dev), torch.randn(M, D, device=dev)
 mod = bf(b, 6 * D); mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
 part, pg = torch.empty(M // 16, 2, D, device=dev), torch.empty(M // 16, D, device=dev)
 dy = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
-_, split = ops.plan_wgrad(M, Hm, D)
+lay, split = ops.plan_wgrad(M, Hm, D)
 mp = mod.data_ptr()
 for _ in range(3):
     ops.linear_fwd(x, w1, b1, pre, epi=ops.EPI_GELU, act_out=act)
-    ops.linear_wgrad(act, x, dw.data_ptr(), dbias=dw.data_ptr() + 4 * Hm * D, split_k=split, Mtok=M, N=Hm, K=D, ws=ws)
+    ops.linear_wgrad(act, x, dw.data_ptr(), dbias=dw.data_ptr() + 4 * Hm * D, split_k=split, Mtok=M, N=Hm, K=D, ws=ws, lay=lay)
     ops.gemm(ops.NN, ops.EPI_BF16, act, w1, M, D, Hm, dx, Hm, D, D)
     ops.attention_fwd(qkv, o, lse, b, T, H, hd)
     ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd)
