@@ -63,9 +63,10 @@ def random_fill(model, seed):
     A.shadow_version = -1
 
 
-TRAFFIC_B256 = 2.96e9   # bytes per launch of the dominant kernel, rocprofv3 --pmc (profiles/r1_pmc_gemm.txt, last section)
-TRAFFIC_NOTE = ("gemm_kernel<TN> fc1 wgrad (24 % of the step): algorithmic 0.82 GB/launch (dy 0.60 + x 0.15 + 3 fp32 slabs 0.06), "
-                "measured 2.90 GB L2-miss reads (FETCH_SIZE x2, counts Infinity-Cache hits) + 0.064 GB writes")
+TRAFFIC_B256 = 2.32e9   # bytes per launch of the dominant kernel, rocprofv3 --pmc (profiles/r1_pmc_gemm.txt, last section)
+TRAFFIC_NOTE = ("gemm256_kernel<NN, bf16> (the dgrads of fc1 / qkv / proj: 15.9 % of the step), fc1 dgrad launch: algorithmic "
+                "0.77 GB (da1 0.60 + W 0.01 + dx 0.15), measured 2.17 GB L2-miss reads (FETCH_SIZE x2, counts Infinity-Cache "
+                "hits: each 256-row slice of da1 is fetched by every XCD that holds one of its 5 column tiles) + 0.151 GB writes")
 
 
 def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
@@ -245,9 +246,9 @@ def main():
             tot_ms = sum(r["ms"] for r in rows)
             agg = sum(r["tflops"] * r["ms"] for r in rows) / tot_ms
             dom = max(rows, key=lambda r: r["ms"])
-            # the single kernel with the largest share of the step (rocprofv3 --stats: gemm_kernel<2, 6>, ~25 %): the
-            # 128^2 TN weight-gradient kernel; its launches are the block's four wgrads (incl. their slab reduce)
-            wg = [r for r in rows if r["kernel"].startswith("wgrad")]
+            # the single kernel with the largest share of the step (rocprofv3 --stats: gemm256_kernel<1, 0>, ~16 %): the
+            # 256^2 NN kernel with the plain bf16 epilogue; its launches are the block's dgrads of fc1, proj and qkv
+            wg = [r for r in rows if r["kernel"] in ("dgrad fc1 NN", "dgrad proj NN", "dgrad qkv NN")]
             wg_ms = sum(r["ms"] for r in wg)
             wg_tf = sum(r["tflops"] * r["ms"] for r in wg) / wg_ms
             # HBM-side traffic of the slowest GEMM launch, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -255,10 +256,10 @@ def main():
             traffic = TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None
             out["roofline"] = {"bound": "mfma", "achieved": round(agg, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(agg * 1e12 / PEAK_BF16, 4), "traffic": traffic,
-                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm_kernel<TN> (time-weighted over "
-                                         "the block's 12 GEMM launches; flop per launch / event-timed duration)",
+                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm_tn_kernel / gemm_kernel<TN> (time-"
+                                         "weighted over the block's 12 GEMM launches; flop per launch / event-timed duration)",
                                "dominant": TRAFFIC_NOTE,
-                               "dominant_kernel": {"name": "gemm_kernel<TN, F32> (weight gradients, 128^2 tile, split-K slabs)",
+                               "dominant_kernel": {"name": "gemm256_kernel<NN, bf16> (dgrads of fc1 / proj / qkv on the weight shadow)",
                                                    "avg_ms_per_launch": round(wg_ms / len(wg), 4),
                                                    "tflops": round(wg_tf, 1), "frac": round(wg_tf * 1e12 / PEAK_BF16, 4)},
                                "slowest_shape": dom}
