@@ -261,3 +261,37 @@ def test_full_size_properties(dev):
     assert np.isfinite(l1) and float(g1.abs().max()) > 0 and bool(torch.isfinite(g1).all())
     _, g3 = step(2.0)
     assert torch.equal(g3, 2.0 * g1)
+
+
+def test_c4_xl2_two_encoders_vs_reference_bf16(dev):
+    """C4 (BASELINE.json configs[3]): SiT-XL/2 with CLIP-L-shaped image tokens (1024-d, tap after block 8) and a pooled
+    text / VLM vector (3584-d, tap after block 16), repa coefficients 1.0 / 0.5, B=4, 2 optimiser steps on injected
+    draws. Golden = the reference under bf16 autocast (tools/gen_golden.py: g_xl_c4). Step 1 is a pure forward/backward
+    comparison (bar 1e-3); step 2 comes after one AdamW update of every weight by ±lr on deterministic-fill weights,
+    where the reference's own loss jumps from 2.4 to 8.5: there the bound is relative."""
+    g = load("xl2_c4")
+    kw = dict(z_dims=[1024, 3584], z_types=["i", "t"], encoder_depth=8, encoder_depth_text=16)
+    m, ema, opt, lf = _hip_trainer("SiT-XL/2", kw, dev, ["clip", "text_embeds_qwenvl_7b"], [1.0, 0.5])
+    rec = _run_traj(m, opt, lf, dev, 4, 2, [(1024, "i"), (3584, "t")], True)
+    print("HIP :", rec["loss"], rec["proj_loss"], rec["grad_norm"])
+    print("REF :", g["loss"], g["proj_loss"], g["grad_norm"])
+    assert abs(rec["loss"][0] - g["loss"][0]) <= 1e-3
+    assert abs(rec["proj_loss"][0] - g["proj_loss"][0]) <= 1e-3
+    np.testing.assert_allclose(rec["grad_norm"][0], g["grad_norm"][0], rtol=3e-2)
+    assert abs(rec["loss"][1] - g["loss"][1]) <= 2e-3            # measured 4.2e-4 (loss 8.478)
+    np.testing.assert_allclose(rec["proj_loss"][1], g["proj_loss"][1], atol=1e-4)
+
+
+def test_b2_alignment_trajectory_vs_reference_bf16(dev):
+    """SiT-B/2 (12 blocks, 12 heads of 64) with alignment on, B=8, 3 steps: golden = the reference in bf16 autocast and
+    fp32 (tools/gen_golden.py: g_b2). Same bars as C2."""
+    g = load("b2_align")
+    kw = dict(z_dims=[768], z_types=["i"], encoder_depth=4)
+    m, ema, opt, lf = _hip_trainer("SiT-B/2", kw, dev, ["dinov2"], [1.0])
+    rec = _run_traj(m, opt, lf, dev, 8, 3, [(768, "i")], True)
+    d_bf16 = np.abs(np.array(rec["loss"]) - g["bf16.loss"])
+    ref_gap = np.abs(g["bf16.loss"] - g["fp32.loss"])
+    print("HIP  loss:", rec["loss"], " REF bf16:", g["bf16.loss"], " REF fp32:", g["fp32.loss"])
+    assert (d_bf16 <= np.maximum(1e-3, 1.5 * ref_gap)).all(), (d_bf16, ref_gap)
+    np.testing.assert_allclose(rec["grad_norm"], g["bf16.grad_norm"], rtol=5e-2)
+    np.testing.assert_allclose(rec["proj_loss"], g["bf16.proj_loss"], atol=2e-3)
