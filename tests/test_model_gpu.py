@@ -295,3 +295,28 @@ def test_b2_alignment_trajectory_vs_reference_bf16(dev):
     assert (d_bf16 <= np.maximum(1e-3, 1.5 * ref_gap)).all(), (d_bf16, ref_gap)
     np.testing.assert_allclose(rec["grad_norm"], g["bf16.grad_norm"], rtol=5e-2)
     np.testing.assert_allclose(rec["proj_loss"], g["bf16.proj_loss"], atol=2e-3)
+
+
+@pytest.mark.parametrize("input_size,B", [(64, 2), (16, 3), (32, 1)])
+def test_inference_other_resolutions_vs_oracle(dev, input_size, B):
+    """generate.py --resolution 512 (latent 64x64 -> T = 1024 tokens: four 256-key attention tiles with online softmax,
+    M = B*1024 rows) and odd batch sizes: the HIP inference forward against the oracle under bf16 autocast; also the
+    Euler sampler with CFG on top of it (same model evaluations, fp64 state)."""
+    from oracle import samplers as osamplers
+    from reed_amd.samplers import euler_sampler
+    cfg = TINY_CASES["hd64"]["cfg"].copy()
+    cfg.update(input_size=input_size, num_classes=1000, depth=2)
+    m = build_hip_model(cfg, dev, 21).eval()
+    P = detfill.fill_state_dict(osit.init_params(cfg), base_seed=21)
+    om = osit.OracleModel(P, cfg, autocast_bf16=True, training=False)
+    x, _, t, y, _, _ = inputs(B, 4, input_size, 3, [], 0, 1000)
+    with torch.no_grad():
+        o, z = m(x.to(dev), t.to(dev), y.to(dev))
+        ro = om(x, t, y)[0].float()
+    assert z is None and o.shape == (B, 4, input_size, input_size)
+    assert (o.cpu() - ro).abs().max().item() <= 3e-2 * ro.abs().max().item() + 1e-3
+    with torch.no_grad():
+        s_hip = euler_sampler(m, x.to(dev), y.to(dev), num_steps=3, heun=True, cfg_scale=1.5).cpu()
+        s_ref = osamplers.euler_sampler(om, x, y, num_steps=3, heun=True, cfg_scale=1.5)
+    assert s_hip.dtype == torch.float64 and s_hip.shape == x.shape
+    assert (s_hip - s_ref).abs().max().item() <= 5e-2 * s_ref.abs().max().item() + 1e-3
