@@ -22,7 +22,7 @@
 
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);
 int reed_gemm_tn_launch(int tile, GemmArgs a, int splits, hipStream_t stream);   // gemm_tn.hip
-bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits);
+bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits);
 
 namespace {
 using namespace gemm_detail;
@@ -245,7 +245,7 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
-  if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, a, splits)) &&
+  if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, epi, a, splits)) &&
       !(layout == LAY_TN && a.dbias))
     return reed_gemm256_launch(layout, epi, a, splits, stream);
   switch (layout) {

@@ -14,6 +14,8 @@
 //   p3      Q(1,0)  A1r,B0r    A-mh0,B-nh0(t+1)    (next p0)   A0(t+2)      [vmcnt(4) + barrier first]
 // Each phase starts with s_waitcnt lgkmcnt(0) + s_barrier, which orders (WAR) the reads of a half-tile before the
 // DMA that overwrites it two K-tiles later, and (RAW, at p3) the landed K-tile t+1 before its first fragment read.
+#include <math.h>
+
 #include "gemm_common.hpp"
 
 namespace {
@@ -377,11 +379,25 @@ static int reed_num_cus() {
 //   t256 = ceil(tiles256 / CUs) * 4 / 1.18        t128 = ceil(tiles128 / (2 CUs)) * 2
 // TN (wgrad) stays on the 128^2 kernel with wave-quantised split-K (ops.plan_wgrad); its 256^2 variant is reachable
 // through reed_gemm_force_tile only.
-bool reed_gemm256_preferred(int layout, const GemmArgs& a, int splits) {
+bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits) {
   if (layout == LAY_TN || splits > 1 || a.K < 256) return false;
   const int ncu = reed_num_cus();
-  const long t256 = (long)cdiv(a.M, BM2) * cdiv(a.N, BN2), t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-  const double c256 = (double)((t256 + ncu - 1) / ncu) * 4.0 / 1.18;
+  const long tm = cdiv(a.M, BM2), tn = cdiv(a.N, BN2);
+  // a ragged last column tile (<= 128 live columns; bf16-output epilogues) runs the re-dealt two-phase body: ~0.6 of a
+  // full tile, and such tiles fill the tail of the last round — count rounds in halves when there are any
+  // (A/B at b = 128: fc2 forward 0.407 -> 0.362 ms, fc1 / qkv dgrads 0.385 -> 0.322 / 0.285 -> 0.237 ms on 256^2)
+  const bool ragged = (a.N % BN2) != 0 && (a.N % BN2) <= 128 &&
+                      (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES || epi == EPI_DGELU ||
+                       epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_RES_BF16);
+  double rounds256;
+  if (ragged) {
+    const double w = (double)tm * (tn - 1) + 0.6 * tm;
+    rounds256 = ceil(2.0 * w / ncu) / 2.0;
+  } else {
+    rounds256 = (double)((tm * tn + ncu - 1) / ncu);
+  }
+  const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+  const double c256 = rounds256 * 4.0 / 1.18;
   const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
   return c256 < c128;
 }
