@@ -320,3 +320,46 @@ def test_inference_other_resolutions_vs_oracle(dev, input_size, B):
         s_ref = osamplers.euler_sampler(om, x, y, num_steps=3, heun=True, cfg_scale=1.5)
     assert s_hip.dtype == torch.float64 and s_hip.shape == x.shape
     assert (s_hip - s_ref).abs().max().item() <= 5e-2 * s_ref.abs().max().item() + 1e-3
+
+
+def test_gradient_accumulation_matches_full_batch(dev):
+    """--gradient-accumulation-steps 2 (reference: accelerate accumulate()): two micro-steps on the
+    halves of a batch — loss / 2 each, gradients accumulated in the arena, optimiser + EMA + step counter only on the
+    second — must leave the same gradients and weights as one step on the whole batch (same per-sample arithmetic,
+    only the fp32 summation split differs)."""
+    import copy
+    from reed_amd.loss import SILoss
+    from reed_amd.optim import FusedAdamWEMA
+    from reed_amd.trainer import TrainStep
+    c = TINY_CASES["hd64"]
+    cfg = c["cfg"]
+    T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(8, 4, cfg["input_size"], 31, c["zspec"], T, cfg["num_classes"])
+    drop = drop_u < cfg["class_dropout_prob"]
+    out = {}
+    for accum in (1, 2):
+        m = build_hip_model(cfg, dev, 31).train()
+        ema = copy.deepcopy(m).requires_grad_(False).eval()
+        opt = FusedAdamWEMA(m, ema, lr=1e-3)
+        step = TrainStep(m, SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"]))), opt, None,
+                         proj_coeff=0.5, diffusion_warm_up_steps=0, grad_accum=accum)
+        n = 8 // accum
+        for k in range(accum):
+            sl = slice(k * n, (k + 1) * n)
+            m.force_drop_mask = drop[sl]
+            res = step(x[sl].to(dev), y[sl].to(dev), [z[sl].to(dev) for z in zs], time_input=t[sl], noises=noise[sl])
+            assert ("grad_norm" in res) == (k == accum - 1)
+        assert step.global_step == 1 and opt.step_count == 1
+        sd = m.state_dict()
+        torch.cuda.synchronize()
+        out[accum] = (m._arena.grad.clone(), m._arena.master.clone(), ema._arena.master.clone(), float(res["grad_norm"]))
+    g1, g2 = out[1][0], out[2][0]
+    assert torch.nn.functional.cosine_similarity(g1, g2, dim=0).item() > 0.9995
+    torch.testing.assert_close(g2.norm(), g1.norm(), rtol=5e-3, atol=0)
+    np.testing.assert_allclose(out[2][3], out[1][3], rtol=5e-3)
+    # Adam's first step moves every weight by +-lr: compare where the gradient sign is not in the rounding noise
+    big = g1.abs() > 1e-3 * g1.abs().max()
+    nt = g1.numel()
+    dw = (out[1][1][:nt] - out[2][1][:nt])[big]
+    assert (dw.abs() > 1e-6).float().mean().item() < 0.02
+    torch.testing.assert_close(out[2][2], out[1][2], atol=1e-6, rtol=0)
