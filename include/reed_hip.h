@@ -44,7 +44,8 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
               int64_t ldr, const void* bias, const void* gate, int64_t ldgate, int rows_per_gate,
               float* dbias, int accumulate, int split_k, int64_t slab_stride, void* stream);
 
-/* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel */
+/* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel, 144 = force
+ * the 256x144 kernel wherever it applies (NT / NN, bf16-output epilogue, N % 144 == 0, no split-K) */
 int reed_gemm_force_tile(int tile);
 
 /* bias gradient: out[n] (+)= sum_m x[m,n], x bf16 [M,N] (row stride ld); ws: caller scratch of

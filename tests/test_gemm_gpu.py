@@ -6,9 +6,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 128, 256], autouse=True)
+@pytest.fixture(params=[0, 128, 256, 144], autouse=True)
 def force_tile(request):
-    """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined)."""
+    """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined,
+    256x144 ring — the last only takes NT / NN shapes whose N is a multiple of 144, others fall to the heuristic)."""
     from reed_amd import ops
     ops.gemm_force_tile(request.param)
     yield request.param
@@ -280,3 +281,54 @@ def test_fused_epilogues_many_tiles(dev, N):
                    rows_per_gate=T2, M=Mr, N=N, K=K, ldx=K, ldw=K, ldo=N)
     ref2 = xin[:Mr] + _bf(gate2.float().repeat_interleave(T2, 0) * pre_ref[:Mr].float()).float()
     torch.testing.assert_close(xout2, ref2, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("lay", ["NT", "NN"])
+@pytest.mark.parametrize("M,N,K", [(256, 144, 64), (300, 288, 192), (8, 144, 128), (8192, 1152, 1152), (2050, 3456, 128),
+                                   (512, 4608, 64), (1000, 1152, 4608), (256, 1152, 192)])
+def test_tile144(dev, lay, M, N, K, force_tile):
+    """gemm144.hip (256x144 tile, 4 x 2 waves of 64x80 / 64x64, 3-slot LDS-DMA ring): 1, 2, 3 and many K-tiles, ragged M,
+    N not a multiple of 128, the 16-column strip and the B piece (columns 128..143 of a tile); bit-identical to the 128^2
+    kernel where that one applies (same products, same k order inside a lane)."""
+    from reed_amd import ops
+    if force_tile != 144:
+        pytest.skip("runs once, forcing the tiles itself")
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    wq = w if lay == "NT" else w.t().contiguous()
+
+    def run(tile):
+        ops.gemm_force_tile(tile)
+        out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        if lay == "NT":
+            ops.gemm(ops.NT, ops.EPI_BF16, x, wq, M, N, K, out, K, K, N, bias=b)
+        else:
+            ops.gemm(ops.NN, ops.EPI_BF16, x, wq, M, N, K, out, K, N, N, bias=b)
+        return out
+
+    o = run(144)
+    assert torch.isnan(o[M]).all() and not torch.isnan(o[:M]).any()
+    ref = x.float() @ w.float().t() + b.float()
+    err = (o[:M].float() - ref).abs().max().item()
+    assert err <= ref.abs().max().item() * 2 ** -7, err
+    if N % 128 == 0:
+        assert torch.equal(o[:M], run(128)[:M])
+    ops.gemm_force_tile(144)
+
+
+def test_tile144_identity(dev, force_tile):
+    """A = I against an asymmetric B on the 256x144 tile, both layouts: exact fragment / piece maps."""
+    from reed_amd import ops
+    if force_tile != 144:
+        pytest.skip("runs once")
+    M, N, K = 256, 288, 256
+    x = torch.eye(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.arange(N * K, device=dev).reshape(N, K) % 251).float().to(torch.bfloat16)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(ops.NT, ops.EPI_BF16, x, w, M, N, K, out, K, K, N)
+    assert torch.equal(out.float(), w.float().t().contiguous())
+    out.zero_()
+    ops.gemm(ops.NN, ops.EPI_BF16, x, w.t().contiguous(), M, N, K, out, K, N, N)
+    assert torch.equal(out.float(), w.float().t().contiguous())

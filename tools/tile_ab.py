@@ -7,7 +7,7 @@ import bench
 from reed_amd import ops
 for b in [int(x) for x in sys.argv[1:]] or [256]:
     res = {}
-    for tile in (0, 128, 256, 0, 128, 256):
+    for tile in (0, 128, 256, 144, 0, 128, 256, 144):
         ops.gemm_force_tile(tile)
         for r in bench.time_gemms(b):
             if "wgrad" not in r["kernel"]:
@@ -15,4 +15,4 @@ for b in [int(x) for x in sys.argv[1:]] or [256]:
     ops.gemm_force_tile(0)
     print(f"b={b}")
     for k, v in res.items():
-        print(f"   {k:24s} heuristic {min(v[0]):.4f}   128^2 {min(v[128]):.4f}   256^2 {min(v[256]):.4f} ms")
+        print(f"   {k:24s} heuristic {min(v[0]):.4f}   128^2 {min(v[128]):.4f}   256^2 {min(v[256]):.4f}   256x144 {min(v[144]):.4f} ms")
