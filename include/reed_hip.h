@@ -34,7 +34,8 @@ int reed_version(void);
  *   layout 2 TN: C[M,N] = P[K,M]^T Q[K,N]     (wgrad    dW = dy^T x), optional dbias[M] = colsum(P)
  *   layout 3 / 4: TN on a 256x128 / 128x256 output tile (128x64 / 64x128 per wave; epilogue 6 only; 4 needs N%256==0)
  * epilogue codes: see reed_amd/csrc/gemm.h (0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
- *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual).  N%128==0; K%64==0 (NT/NN);
+ *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual).  N%128==0 (NT/NN with a
+ *   bf16-output epilogue also N%144==0: the 256x144 tile of csrc/gemm144.hip); K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
  *   dbias likewise holds split_k slabs of M floats AT THE SAME slab_stride — put slab 0 of dbias right behind slab 0
  *   of C and one reed_reduce_slabs call over M*N + M floats finishes both; deterministic).

@@ -24,6 +24,7 @@ int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t
 int reed_gemm_tn_launch(int tile, GemmArgs a, int splits, hipStream_t stream);   // gemm_tn.hip
 bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits);
 bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits);              // gemm144.hip
+bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits);
 int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 
 namespace {
@@ -220,7 +221,7 @@ extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
   REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   const bool can144 = reed_gemm144_eligible(layout, epi, a, splits);
-  REED_CHECK_ARG(a.N % BN == 0 || (can144 && g_force_tile == 144), "reed_gemm: N=%d must be a multiple of %d", a.N, BN);
+  REED_CHECK_ARG(a.N % BN == 0 || can144, "reed_gemm: N=%d must be a multiple of %d (or, NT / NN with a bf16-output epilogue, of 144)", a.N, BN);
   REED_CHECK_ARG(a.ldp % 8 == 0 && a.ldq % 8 == 0, "reed_gemm: leading dims must be multiples of 8 elements");
   REED_CHECK_ARG(a.ldc >= 0 && a.ldc < (1 << 20) && a.ldc2 >= 0 && a.ldc2 < (1 << 20) && a.ldr >= 0 && a.ldr < (1 << 20) &&
                      a.ldc % 8 == 0 && a.ldc2 % 8 == 0 && a.ldr % 8 == 0,
@@ -248,7 +249,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
-  if (can144 && g_force_tile == 144) return reed_gemm144_launch(layout, epi, a, stream);
+  if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits))))
+    return reed_gemm144_launch(layout, epi, a, stream);
   if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, epi, a, splits)) &&
       !(layout == LAY_TN && a.dbias))
     return reed_gemm256_launch(layout, epi, a, splits, stream);

@@ -49,6 +49,70 @@ __device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1)
     __builtin_amdgcn_sched_barrier(0);                     \
   } while (0)
 
+// The 16-column strip (columns 64..79 of a tile, held by the wave-column-0 waves as one extra MFMA tile per 16 rows)
+// straight from the MFMA layout: lane (r = lane & 15, g = lane >> 4) owns row 16 i + r, columns 4 g .. 4 g + 3, i.e.
+// 8-byte bf16 / 16-byte fp32 accesses, four lanes per 32 / 64 contiguous bytes of a row.  It is a ninth of the
+// output; sending it through tile_epilogue's 64-column LDS round trip (lane-masked) doubled those waves' epilogue.
+// Same arithmetic and rounding points as tile_epilogue.
+template <int EPI>
+__device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&acc)[4], int mbase, int nbase, int lane) {
+  const int n = nbase + 4 * (lane >> 4);
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+    const bf16x4 b = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs[e] = bf2f(b[e]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mbase + 16 * i + (lane & 15);
+    if (m >= a.M) continue;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[i][e] + bs[e];
+    if constexpr (EPI == EPI_BF16) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+      *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU) {
+      bf16x4 pre, act;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pre[e] = f2bf(v[e]);
+        const float x = bf2f(pre[e]);
+        if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+        else act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
+      }
+      if (a.C) *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = pre;
+      *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = act;
+    } else if constexpr (EPI == EPI_GATE_RES) {
+      const bf16x4 g = *(const bf16x4*)(a.gate + (long)(m / a.rows_per_gate) * a.ldgate + n);
+      const f32x4 xin = *(const f32x4*)((const float*)a.R + (long)m * a.ldr + n);
+      bf16x4 y;
+      f32x4 xo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = f2bf(v[e]);
+        xo[e] = xin[e] + bfround(bf2f(g[e]) * bf2f(y[e]));
+      }
+      if (a.C2) *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = y;
+      *(f32x4*)((float*)a.C + (long)m * a.ldc + n) = xo;
+    } else {  // EPI_DGELU / EPI_DSILU / EPI_RES_BF16
+      const bf16x4 pre = *(const bf16x4*)((const bf16*)a.R + (long)m * a.ldr + n);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float du = bfround(v[e]);
+        const float x = bf2f(pre[e]);
+        if constexpr (EPI == EPI_RES_BF16) o[e] = f2bf(du + x);
+        else o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
+      }
+      *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
+    }
+  }
+}
+
 template <int LAY, int EPI>
 __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,12 +271,19 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
   LOADF(0, 0u, A0f, B0f);
   LDS_WAIT0();   // landed before the loop header: a register copy the compiler may place on the loop edges is then safe
 
+  // The two waves of a SIMD (w and w + 4 = wave columns 0 and 1) issue their share of a K-tile's DMA half a K-tile
+  // apart — column 0 right behind the barrier of half 1, column 1 in the following half 0 — so that one of them is in
+  // its MFMAs while the other spends its ~6 x 100 issue cycles on buffer_load ... lds.
+  const bool late = wc != 0;
+  int pend_t = 0, pend_slot = 0;
+  bool pend = false;
   int slot = 0;   // ring slot of K-tile t
   for (int t = 0; t < nt; ++t) {
     const unsigned so = (unsigned)slot * STAGE4;
     const int nslot = slot == 2 ? 0 : slot + 1;
     // ---- half 0 ----  (reads(t, ks0) landed: waited at the end of the previous iteration / the prologue)
     LOADF(1, so, A1f, B1f);
+    if (pend) { issue(pend_t, pend_slot); pend = false; }
     __builtin_amdgcn_sched_barrier(0);
     MMA(A0f, B0f);
     __builtin_amdgcn_sched_barrier(0);
@@ -227,7 +298,10 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
       LDS_WAIT0();                   // reads(t, ks1) landed: this wave is done with slot(t)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (t + 3 < nt) issue(t + 3, slot);
+      if (t + 3 < nt) {
+        if (late) { pend = true; pend_t = t + 3; pend_slot = slot; }
+        else issue(t + 3, slot);
+      }
       LOADF(0, (unsigned)nslot * STAGE4, A0f, B0f);
     } else {
       LDS_WAIT0();
@@ -242,16 +316,7 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
 
   char* patch = smem + wave * EPI_STAGE_BYTES;
   tile_epilogue<EPI, 4>(a, accm, m0, wr * 64, n0 + wc * 80, lane, 0, patch);
-  if (wc == 0) {     // columns 64 .. 79 of the tile: a 16-column strip through the lane-masked form
-    f32x4 part[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      part[i][0] = accx[i];
-#pragma unroll
-      for (int j = 1; j < 4; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    tile_epilogue<EPI, 4, true>(a, part, m0, wr * 64, n0 + 64, lane, 0, patch, n0 + 80);
-  }
+  if (wc == 0) strip_epilogue<EPI>(a, accx, m0 + wr * 64, n0 + 64, lane);   // columns 64 .. 79 of the tile
 }
 
 template <int LAY, int EPI>
@@ -293,6 +358,28 @@ bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits) {
                         epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_RES_BF16;
   return (layout == LAY_NT || layout == LAY_NN) && bf16_epi && splits <= 1 && a.N % BN4 == 0 && a.K % BK4 == 0 &&
          a.K >= BK4;
+}
+
+int reed_num_cus();   // gemm256.hip
+
+// Kernel selection against the 256^2 / 128^2 kernels, in gemm256.hip's units (one CU x one 128^2 tile; 256^2 tile = 4 /
+// 1.18).  A 256x144 tile is 0.5625 of a 256^2 tile; its main loop runs at the chip's dense-MFMA ceiling when all 256 CUs
+// are busy, but per round it exposes the same epilogue as the 256^2 kernel on 0.56 of the work, so over the block
+// shapes it is worth ~0.80 of the 256^2 kernel per flop (tools/tile_ab.py, b = 32 .. 256): cost = rounds x 2.25 / 0.80.
+// The 256^2 side is counted in WHOLE rounds here (ragged column tiles as workgroups): at 1.25 rounds (b = 64, N = 1152)
+// the second, quarter-full round costs a full tile time.  Outcome on SiT-XL/2: the five 1152-wide outputs (proj / fc2
+// forward, dgrads of qkv / proj / fc1) at b <= 64 per GPU (-14 .. -28 % at b = 32, -7 .. -17 % at b = 64); everything
+// else stays where it was.
+bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits) {
+  if (!reed_gemm144_eligible(layout, epi, a, splits) || a.K < 256) return false;
+  const int ncu = reed_num_cus();
+  const long t144 = (long)cdiv(a.M, BM4) * (a.N / BN4);
+  const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
+  const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+  const double c144 = (double)((t144 + ncu - 1) / ncu) * 2.25 / 0.80;
+  const double c256 = (double)((t256 + ncu - 1) / ncu) * 4.0 / 1.18;
+  const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
+  return c144 < c256 && c144 < c128;
 }
 
 int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream) {

@@ -361,7 +361,7 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int reed_num_cus() {
+int reed_num_cus() {
   static int n = 0;
   if (!n) {
     int dev = 0;

@@ -109,11 +109,9 @@ __device__ __forceinline__ void tile_epilogue_ptr(const GemmArgs& a, const f32x4
                                                   int lane, int z);
 
 // stage: this wave's EPI_STAGE_BYTES of LDS (no other wave touches it; the caller made sure the K loop is done with it)
-// LANE_MASK: the wave's 64-column window is only valid below column nlim (per-lane instead of wave-uniform column check;
-// gemm144.hip's 16-column strip).
-template <int EPI, int NI, bool LANE_MASK = false>
+template <int EPI, int NI>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[NI][4], int m0, int mw, int nbase,
-                                              int lane, int z, char* stage, int nlim = 0) {
+                                              int lane, int z, char* stage) {
   if constexpr (EpiOps<EPI, NI>::value < 0) {
     tile_epilogue_ptr<EPI, NI>(a, acc, m0 + mw, nbase, lane, z);
   } else {
@@ -125,8 +123,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
     const char* rd_base1 = stage + (rd_row + 8) * 256;
     const int rd_sw0 = ((2 * rd_c) ^ rd_row) << 4, rd_sw1 = ((2 * rd_c) ^ (rd_row + 8)) << 4;  // chunk c0; c0+1 = ^16
 
-    // wave-uniform unless LANE_MASK: N % 128 == 0 and a wave spans 64 columns
-    const bool cv = LANE_MASK ? (nbase + 8 * rd_c < nlim) : (nbase < a.N);
+    const bool cv = nbase < a.N;            // wave-uniform: a wave spans 64 columns, N is a multiple of 16
     const long rows = a.M - m0;             // rows of C from the tile's first row on (> 0)
     const int col = nbase + 8 * rd_c;       // lane's first column
     const int rt = mw + rd_row;             // lane's first row inside the tile (i = 0, h = 0)
