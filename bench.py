@@ -256,10 +256,12 @@ def main():
             traffic = TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None
             out["roofline"] = {"bound": "mfma", "achieved": round(agg, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                                "frac": round(agg * 1e12 / PEAK_BF16, 4), "traffic": traffic,
-                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm_tn_kernel / gemm_kernel<TN> (time-"
+                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm144_kernel<NT|NN> (1152-wide outputs at b <= 64) / "
+                                         "gemm_tn_kernel / gemm_kernel<TN> (time-"
                                          "weighted over the block's 12 GEMM launches; flop per launch / event-timed duration)",
                                "dominant": TRAFFIC_NOTE,
-                               "dominant_kernel": {"name": "gemm256_kernel<NN, bf16> (dgrads of fc1 / proj / qkv on the weight shadow)",
+                               "dominant_kernel": {"name": ("gemm144_kernel<NN, bf16>" if b <= 64 else "gemm256_kernel<NN, bf16>") +
+                                                           " (dgrads of fc1 / proj / qkv on the weight shadow)",
                                                    "avg_ms_per_launch": round(wg_ms / len(wg), 4),
                                                    "tflops": round(wg_tf, 1), "frac": round(wg_tf * 1e12 / PEAK_BF16, 4)},
                                "slowest_shape": dom}

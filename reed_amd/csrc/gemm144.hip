@@ -22,6 +22,8 @@
 //   half 0:  wait reads(t, ks0) | issue reads(t, ks1) | MFMA(t, ks0)
 //   half 1:  wait DMA(t+1), reads(t, ks1) | barrier | issue DMA(t+3) into t's slot | issue reads(t+1, ks0) | MFMA(t, ks1)
 // NT / NN layouts, bf16-output epilogues (tile_epilogue's LDS-staged row-contiguous stores), no split-K.
+#include <stdlib.h>
+
 #include "gemm_common.hpp"
 
 namespace {
@@ -376,7 +378,8 @@ bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits) 
   const long t144 = (long)cdiv(a.M, BM4) * (a.N / BN4);
   const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
   const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-  const double c144 = (double)((t144 + ncu - 1) / ncu) * 2.25 / 0.80;
+  static const double eta = getenv("REED_GEMM144_ETA") ? atof(getenv("REED_GEMM144_ETA")) : 0.80;   // experiments
+  const double c144 = (double)((t144 + ncu - 1) / ncu) * 2.25 / eta;
   const double c256 = (double)((t256 + ncu - 1) / ncu) * 4.0 / 1.18;
   const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
   return c144 < c256 && c144 < c128;
