@@ -214,6 +214,12 @@ int reed_comm_init(const void* id128, int rank, int world, void** comm_out);
 int reed_comm_allreduce_avg(void* comm, float* buf, int64_t count, void* compute_stream); /* async on the comm stream, ordered after compute_stream */
 int reed_comm_sync(void* comm, void* compute_stream);       /* compute_stream waits for all pending reductions */
 int reed_comm_broadcast(void* comm, float* buf, int64_t count, int root, void* compute_stream);
+/* all-gather of `bytes` bytes per rank (recv = world * bytes, rank-major), async on the comm stream, ordered after
+ * compute_stream; reed_comm_sync_gather makes compute_stream wait for the gathers issued so far (not for reductions
+ * queued behind them).  Used to exchange the K = local-batch factors of the adaLN weight gradient instead of
+ * all-reducing the matrix (reed_amd/parallel.py). */
+int reed_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes, void* compute_stream);
+int reed_comm_sync_gather(void* comm, void* compute_stream);
 int reed_comm_destroy(void* comm);
 
 /* ---------------------------------------------------------------------------------------------

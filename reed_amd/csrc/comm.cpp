@@ -13,7 +13,7 @@
 struct ReedComm {
   ncclComm_t comm;
   hipStream_t stream;
-  hipEvent_t ready, done;
+  hipEvent_t ready, done, gdone;
   int rank, world;
 };
 
@@ -56,6 +56,7 @@ extern "C" int reed_comm_init(const void* id128, int rank, int world, void** com
   HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
   HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->gdone, hipEventDisableTiming));
   *comm_out = c;
   return REED_OK;
 }
@@ -77,6 +78,29 @@ extern "C" int reed_comm_sync(void* comm, void* compute_stream) {
   return REED_OK;
 }
 
+// Factor exchange for weight gradients whose contraction length is the LOCAL batch (the adaLN matrix: dW = dmod^T
+// silu(c), K = b): every rank contributes its [b, rows] factor, receives all of them ([world * b, rows], rank-major) and
+// forms the global-batch product itself — world * b * rows bf16 on the wire instead of an all-reduce of rows * D fp32.
+// Same stream discipline as the bucket reductions; completion has its own event so that the consumer does not wait
+// for bucket reductions queued behind the last gather.
+extern "C" int reed_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes, void* compute_stream) {
+  ReedComm* c = (ReedComm*)comm;
+  REED_CHECK_ARG(c && send && recv && bytes > 0, "comm_allgather: bad args");
+  HIP_TRY(hipEventRecord(c->ready, (hipStream_t)compute_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
+  NCCL_TRY(ncclAllGather(send, recv, (size_t)bytes, ncclUint8, c->comm, c->stream));
+  HIP_TRY(hipEventRecord(c->gdone, c->stream));
+  HIP_TRY(hipEventRecord(c->done, c->stream));
+  return REED_OK;
+}
+
+extern "C" int reed_comm_sync_gather(void* comm, void* compute_stream) {
+  ReedComm* c = (ReedComm*)comm;
+  REED_CHECK_ARG(c, "comm_sync_gather: null communicator");
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)compute_stream, c->gdone, 0));
+  return REED_OK;
+}
+
 extern "C" int reed_comm_broadcast(void* comm, float* buf, int64_t count, int root, void* compute_stream) {
   ReedComm* c = (ReedComm*)comm;
   REED_CHECK_ARG(c && buf && count > 0, "comm_broadcast: bad args");
@@ -95,6 +119,7 @@ extern "C" int reed_comm_destroy(void* comm) {
   ncclCommDestroy(c->comm);
   (void)hipEventDestroy(c->ready);
   (void)hipEventDestroy(c->done);
+  (void)hipEventDestroy(c->gdone);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return REED_OK;

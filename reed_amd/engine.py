@@ -342,15 +342,42 @@ class Engine:
         split_ada = self.reducer is not None if self.split_ada_wgrad is None else self.split_ada_wgrad
         gp = self.A.grad.data_ptr()
         dmp = dmod.data_ptr()
+        # Factor path (a reducer that is reducing THIS backward, no gradient accumulation in flight): the adaLN weight
+        # gradient contracts over the local batch only, so instead of all-reducing the [Nall, D] fp32 matrix (a third of
+        # the payload) the ranks all-gather the two bf16 factors — dmod rows of block i (pre-scaled by 1 / world: exact,
+        # power-of-two worlds only) right after block i's backward, silu(c) once — and every rank forms the global-batch
+        # product itself at the end of backward (K = world * b). At world = 1 this is the per-block GEMM on a copy.
+        red = self.reducer
+        fg = (red is not None and red.ada_gather and red.active() and not acc and self.split_ada_wgrad is None)
+        if fg:
+            split_ada = False
+            W = red.world
+            g_send, g_recv = red.gather_buffers("dmod", B * Nall, torch.bfloat16, dev)
+            s_send, s_all = red.gather_buffers("silu", B * D, torch.bfloat16, dev)
+            s_send.view(B, D).copy_(tp.silu_c)
+            red.gather(s_send, s_all)
+
+        def ada_rows(i):
+            return i * 6 * D, (6 * D if i < self.depth else 2 * D)
 
         def ada_wgrad(i):
-            c0 = i * 6 * D
-            rows = 6 * D if i < self.depth else 2 * D
+            c0, rows = ada_rows(i)
             ops.gemm(TN, EPI_F32, dmp + 2 * c0, tp.silu_c, rows, D, B, gp + 4 * (L.ada_w_off + c0 * D), Nall, D, D,
                      dbias=gp + 4 * (L.ada_b_off + c0), accumulate=acc)
 
-        if split_ada:
-            ada_wgrad(self.depth)
+        def ada_gather(i):   # block i's dmod rows are final: scale, pack [b, rows] contiguously, all-gather
+            c0, rows = ada_rows(i)
+            snd = g_send[B * c0:B * (c0 + rows)]
+            torch.mul(dmod[:, c0:c0 + rows], 1.0 / W, out=snd.view(B, rows))
+            red.gather(snd, g_recv[W * B * c0:W * B * (c0 + rows)])
+
+        def ada_after(i):
+            if fg:
+                ada_gather(i)
+            elif split_ada:
+                ada_wgrad(i)
+
+        ada_after(self.depth)
         if self.reducer is not None:
             self.reducer.ready("final")
             if split_ada:
@@ -413,8 +440,7 @@ class Engine:
                                   (p2, 2 * D, o6 + 3 * D), (p2 + 4 * D, 2 * D, o6 + 4 * D),
                                   (pg2.data_ptr(), D, o6 + 5 * D)], dmod, Nall, B, D, ch)
             tp.blocks[i] = None  # free this block's activations
-            if split_ada:
-                ada_wgrad(i)
+            ada_after(i)
             if self.reducer is not None:
                 if side is None:
                     self.reducer.ready(f"block{i}")
@@ -430,7 +456,13 @@ class Engine:
             self.reducer.ready("projectors")
         # -- adaLN (all blocks + final): dW = dmod^T silu(c); d silu(c) = dmod @ W   (one GEMM each)
         sp = self._shadow.data_ptr()
-        if not split_ada:
+        if fg:
+            red.gather_sync()
+            for i in reversed(range(self.depth + 1)):   # rank-major [world * b, rows] factors: K = the global batch
+                c0, rows = ada_rows(i)
+                ops.gemm(TN, EPI_F32, g_recv.data_ptr() + 2 * W * B * c0, s_all, rows, D, W * B,
+                         gp + 4 * (L.ada_w_off + c0 * D), rows, D, D, dbias=gp + 4 * (L.ada_b_off + c0), accumulate=False)
+        elif not split_ada:
             ops.gemm(TN, EPI_F32, dmod, tp.silu_c, Nall, D, B, gp + 4 * L.ada_w_off, Nall, D, D,
                      dbias=gp + 4 * L.ada_b_off, accumulate=acc)
         ksteps = Nall // 64
@@ -462,10 +494,14 @@ class Engine:
         ops.smallk_wgrad(dx, True, xb, wsf, self.G("x_embedder.proj.weight"), self.G("x_embedder.proj.bias"), None, M, D,
                          K, 0, acc)
         if self.reducer is not None:
-            if not split_ada:
-                for i in reversed(range(self.depth + 1)):
-                    self.reducer.ready(f"ada{i}")
-            self.reducer.ready("embed")
+            if fg:   # adaLN weights and biases are global-batch averages already: reduce only the embedders' part
+                eb, ee = self.reducer.buckets["embed"]
+                self.reducer.ready_range(L.ada_b_off + Nall, ee)
+            else:
+                if not split_ada:
+                    for i in reversed(range(self.depth + 1)):
+                        self.reducer.ready(f"ada{i}")
+                self.reducer.ready("embed")
         if side is not None:  # the optimiser / next micro-step (same stream as this backward) sees every weight gradient
             torch.cuda.current_stream().wait_stream(side)
         self.grad_live = True

@@ -48,8 +48,9 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
     assert lat.shape == (8, 4, 32, 32) and np.isfinite(lat).all()
 
 
+@pytest.mark.parametrize("ada_gather", ["1", "0"])
 @pytest.mark.parametrize("binding", ["native", "torch"])
-def test_rccl_reducer_world1(dev, binding):
+def test_rccl_reducer_world1(dev, binding, ada_gather):
     """Exercise every RCCL entry point (unique id, init, broadcast, bucketed all-reduce(avg) fired from backward on the
     side stream, sync, destroy) with a 1-rank communicator: averaging over one rank must leave gradients unchanged.
     binding="torch": the same bucket plan through torch.distributed's RCCL process group (REED_COMM=torch, the
@@ -67,6 +68,7 @@ def test_rccl_reducer_world1(dev, binding):
     from reed_amd.models.sit import SiT
     from reed_amd.parallel import GradReducer
     os.environ["REED_FORCE_REDUCER"] = "1"
+    os.environ["REED_ADA_GATHER"] = ada_gather   # "1": adaLN gradients through the factor all-gather (parallel.py:gather)
     try:
         def run(with_reducer):
             m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10,
@@ -76,7 +78,7 @@ def test_rccl_reducer_world1(dev, binding):
             m.force_drop_mask = torch.tensor([False, True, False, False])
             red = GradReducer(m, rank=0, world=1) if with_reducer else None
             if red:
-                assert red.binding == binding
+                assert red.binding == binding and red.ada_gather == (ada_gather == "1")
                 red.broadcast_params(0)
             lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
             x, n = detfill.normal((4, 4, 8, 8), 1).to(dev), detfill.normal((4, 4, 8, 8), 2)
@@ -94,6 +96,7 @@ def test_rccl_reducer_world1(dev, binding):
         assert torch.equal(g0, g1)
     finally:
         os.environ.pop("REED_FORCE_REDUCER", None)
+        os.environ.pop("REED_ADA_GATHER", None)
         os.environ.pop("REED_COMM", None)
         if binding == "torch" and dist.is_initialized():
             dist.destroy_process_group()

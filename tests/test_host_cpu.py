@@ -272,6 +272,77 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
         assert p.returncode == 0 and "OK" in o, o
 
 
+_GLOO_FACTOR_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from oracle import sit as osit
+from reed_amd.arena import ArenaLayout
+from reed_amd.parallel import TorchDistGradReducer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = osit.make_config("SiT-S/2", z_dims=[768])
+L = ArenaLayout(osit.param_shapes(cfg), cfg["depth"], 1)
+D, d, Nall, B = cfg["hidden_size"], cfg["depth"], L.ada_rows, 4
+torch.manual_seed(100 + rank)
+dmod = torch.randn(B, Nall).to(torch.bfloat16)          # this rank's factors (what Engine.backward holds)
+silu = torch.randn(B, D).to(torch.bfloat16)
+grad = torch.randn(L.n_train)
+# reference: the all-reduce path — local adaLN gradient, then all-reduce(avg) of every bucket
+ref = grad.clone()
+ref[L.ada_w_off:L.ada_w_off + Nall * D] = (dmod.float().t() @ silu.float()).reshape(-1)
+ref[L.ada_b_off:L.ada_b_off + Nall] = dmod.float().sum(0)
+dist.all_reduce(ref); ref /= world
+# factor path, in the engine's order: gather silu(c); per block (backward order) scale + pack + gather the dmod rows and
+# fire the block's bucket; at the end the global-batch products, then the embed bucket WITHOUT the adaLN biases
+red = TorchDistGradReducer(L, grad, world)
+def gather(x):
+    out = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(out, x.contiguous())
+    return torch.cat(out, 0)                           # rank-major [world * b, ...]
+s_all = gather(silu)
+recv = {}
+red.ready("final")
+for i in reversed(range(d + 1)):
+    c0, rows = i * 6 * D, (6 * D if i < d else 2 * D)
+    recv[i] = gather(dmod[:, c0:c0 + rows] * (1.0 / world))
+    if i < d:
+        red.ready(f"block{i}")
+        if i + 1 == cfg["encoder_depth"]: red.ready("projectors")
+for i in reversed(range(d + 1)):
+    c0, rows = i * 6 * D, (6 * D if i < d else 2 * D)
+    assert recv[i].dtype == torch.bfloat16 and recv[i].shape == (world * B, rows)
+    grad[L.ada_w_off + c0 * D:L.ada_w_off + (c0 + rows) * D] = (recv[i].float().t() @ s_all.float()).reshape(-1)
+    grad[L.ada_b_off + c0:L.ada_b_off + c0 + rows] = recv[i].float().sum(0)
+eb, ee = red.buckets["embed"]
+assert eb == L.ada_b_off
+dist.all_reduce(grad[L.ada_b_off + Nall:ee]); grad[L.ada_b_off + Nall:ee] /= world
+covered = torch.zeros(L.n_train, dtype=torch.bool)
+for b, e in red.buckets.values(): covered[b:e] = True
+# 1/world is a power of two: the scaled bf16 factors are exact, so the two paths differ by fp32 summation order only
+torch.testing.assert_close(grad[covered], ref[covered], rtol=1e-5, atol=1e-4)
+every = torch.cat([torch.empty_like(grad) for _ in range(world)]).view(world, -1)
+dist.all_gather(list(every.unbind(0)), grad)
+assert all(torch.equal(every[0][covered], every[r][covered]) for r in range(world)), "ranks disagree"
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_gloo_world2_adaln_factor_gather(tmp_path):
+    """The factor path of Engine.backward (reed_amd/parallel.py:GradReducer.gather): all-gathering the 1/world-scaled
+    bf16 dmod rows and silu(c) and forming the global-batch product on every rank == all-reduce(avg) of the per-rank
+    adaLN gradients (weights and biases), every other bucket reduced as before, identical results on every rank."""
+    script = tmp_path / "wf.py"
+    script.write_text(_GLOO_FACTOR_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o
+
+
 def test_update_chunks_cover_arena_in_forward_order():
     """ArenaLayout.update_chunks (overlapped optimiser): the chunks tile [0, n_total) exactly once, start with the
     embedders + the head of the adaLN matrix, visit the blocks in forward order with the adaLN tail behind the head
