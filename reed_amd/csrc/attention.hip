@@ -79,6 +79,47 @@ __device__ __forceinline__ void load_tile(char* lds, const bf16* src, long row_s
   }
 }
 
+// load_tile in two halves, so that a caller can have the loads of SEVERAL tiles in flight before the first wait (the
+// backward keeps four tiles resident and used to pay ~10 serial HBM round trips per workgroup for them).
+template <int HD>
+struct TileRegs {
+  static constexpr int PER = (256 * Cfg<HD>::NCH + 511) / 512;
+  uint4 v[PER];
+};
+template <int HD>
+__device__ __forceinline__ void tile_issue(TileRegs<HD>& r, const bf16* src, long row_stride, int rows_valid, int tid) {
+  constexpr int NCH = Cfg<HD>::NCH;
+  const int last = rows_valid - 1;
+#pragma unroll
+  for (int k = 0; k < TileRegs<HD>::PER; ++k) {
+    int idx = tid + k * 512;
+    int row = idx / NCH, c = idx - row * NCH;
+    int rc = min(row, last);
+    if (rc < 0) rc = 0;
+    int cc = idx < 256 * NCH ? c : 0;
+    r.v[k] = *(const uint4*)(src + (long)rc * row_stride + cc * 8);
+  }
+}
+template <int HD, int RB = ROWB>
+__device__ __forceinline__ void tile_commit(char* lds, const TileRegs<HD>& r, int rows_valid, int tid) {
+  constexpr int NCH = Cfg<HD>::NCH;
+#pragma unroll
+  for (int k = 0; k < TileRegs<HD>::PER; ++k) {
+    int idx = tid + k * 512;
+    int row = idx / NCH, c = idx - row * NCH;
+    if (idx < 256 * NCH) {
+      const unsigned msk = row < rows_valid ? 0xFFFFFFFFu : 0u;
+      uint4 w = r.v[k];
+      w.x &= msk; w.y &= msk; w.z &= msk; w.w &= msk;
+      *(uint4*)(lds + row * RB + c * 16) = w;
+    }
+  }
+  if (RB > HD * 2 + 8 && tid < 256) {
+#pragma unroll
+    for (int c = Cfg<HD>::NCH; c < RB / 16; ++c) *(uint4*)(lds + tid * RB + c * 16) = make_uint4(0, 0, 0, 0);
+  }
+}
+
 // lane (i = lane&15, g = lane>>4): X[row0 + i][ks*32 + 8g .. +7]
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
   return *(const bf16x8*)(tile + (row0 + (lane & 15)) * ROWB + (ks * 32 + 8 * (lane >> 4)) * 2);
@@ -255,7 +296,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
         }
     }
   }
+  // O leaves through LDS (the wave's own 32 rows of the K tile, free once every wave is past its last key tile): in the
+  // MFMA layout a wave-level store is sixteen 32-byte pieces; staged, it is whole 144-byte row pieces at 16 B per lane.
+  __syncthreads();
   if (!active) return;
+  char* stg = Kt + (wave * 32) * ROWF;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float lt = l[qt];
@@ -263,19 +308,26 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
     lt += __shfl_xor(lt, 32, 64);
     const float inv = 1.f / lt;
     const int q = q0 + 16 * qt + i;
-    if (q < T) {
-      bf16* orow = o + ((long)b * T + q) * D + h * HD;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        int d = 16 * dt + 4 * g;
-        if (d < HD) {
-          bf16x4 v;
+    for (int dt = 0; dt < DT; ++dt) {
+      int d = 16 * dt + 4 * g;
+      if (d < HD) {
+        bf16x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = f2bf(ot[qt][dt][r] * inv);
-          *(bf16x4*)(orow + d) = v;
-        }
+        for (int r = 0; r < 4; ++r) v[r] = f2bf(ot[qt][dt][r] * inv);
+        *(bf16x4*)(stg + (16 * qt + i) * ROWF + d * 2) = v;
       }
-      if (g == 0 && lse) lse[((long)b * H + h) * T + q] = m[qt] * LN2 + __logf(lt);
+    }
+    if (q < T && g == 0 && lse) lse[((long)b * H + h) * T + q] = m[qt] * LN2 + __logf(lt);
+  }
+  {
+    constexpr int NCH = Cfg<HD>::NCH, NQ = 32 * NCH;
+    bf16* obase = o + ((long)b * T + q0) * D + h * HD;
+#pragma unroll
+    for (int k = 0; k < (NQ + 63) / 64; ++k) {
+      const int qi = lane + 64 * k;
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      if (qi < NQ && q0 + rr < T) *(uint4*)(obase + (long)rr * D + c * 8) = *(const uint4*)(stg + rr * ROWF + c * 16);
     }
   }
 }
@@ -306,34 +358,73 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
 
-  if (dbg != 2) {
-  load_tile<HD>(Qt, base, tok, T, tid, 512);
-  load_tile<HD>(Kt, base + D, tok, T, tid, 512);
-  load_tile<HD>(Vt, base + 2 * D, tok, T, tid, 512);
-  load_tile<HD>(Gt, d_o + (long)b * T * D + h * HD, D, T, tid, 512);
-  }
   {
-    // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per row
+    // Every global load of the load phase is issued before the first wait: the four tiles (18 x 16 B per thread), the
+    // O / dO row halves of the delta sum and the log-sum-exp.  One workgroup per CU means nothing else hides HBM latency
+    // here, and as four load_tile calls + the delta loop this phase was ~10 dependent round trips = 60 % of the kernel.
+    TileRegs<HD> rq, rk, rv, rg;
+    constexpr int NH = (NCH + 1) / 2;
     const int row = tid >> 1, half = tid & 1;
-    float acc = 0.f;
-    if (row < T) {
-      const bf16* orow = o + ((long)b * T + row) * D + h * HD;
-      const bf16* grow = d_o + ((long)b * T + row) * D + h * HD;
-      for (int c = half; c < NCH; c += 2) {
-        bf16x8 a = *(const bf16x8*)(orow + c * 8), bb = *(const bf16x8*)(grow + c * 8);
+    const int rcl = min(row, T - 1);
+    bf16x8 ov[NH], gv[NH];
+    float lsev = 0.f;
+    if (dbg != 2) {
+      tile_issue<HD>(rq, base, tok, T, tid);
+      tile_issue<HD>(rk, base + D, tok, T, tid);
+      tile_issue<HD>(rv, base + 2 * D, tok, T, tid);
+      tile_issue<HD>(rg, d_o + (long)b * T * D + h * HD, D, T, tid);
+    }
+    {
+      const bf16* orow = o + ((long)b * T + rcl) * D + h * HD;
+      const bf16* grow = d_o + ((long)b * T + rcl) * D + h * HD;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(bb[j]);
+      for (int j = 0; j < NH; ++j) {
+        const int c = half + 2 * j;
+        const int cc = c < NCH ? c : 0;          // clamped, masked below
+        ov[j] = *(const bf16x8*)(orow + cc * 8);
+        gv[j] = *(const bf16x8*)(grow + cc * 8);
+      }
+      lsev = lse[((long)b * H + h) * T + rcl];
+    }
+    if (dbg != 2) {
+      tile_commit<HD>(Qt, rq, T, tid);
+      tile_commit<HD>(Kt, rk, T, tid);
+      tile_commit<HD>(Vt, rv, T, tid);
+      tile_commit<HD>(Gt, rg, T, tid);
+    }
+    // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per row (chunks half, half + 2, ... in the same order as before)
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      if (half + 2 * j < NCH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += bf2f(ov[j][e]) * bf2f(gv[j][e]);
       }
     }
     acc += __shfl_xor(acc, 1, 64);
     if (half == 0) {
       dlt[row] = row < T ? acc : 0.f;
-      lse2[row] = row < T ? lse[((long)b * H + h) * T + row] * LOG2E : INFINITY;
+      lse2[row] = row < T ? lsev * LOG2E : INFINITY;
     }
   }
   __syncthreads();
 
   const int r0 = wave * 32;  // this wave's 32 rows (queries in phase 1, keys in phase 2)
+  f32x4 dq[2][DT];
+  // A wave's 32 finished rows leave through LDS: the MFMA layout gives a lane 4 consecutive columns of one row, i.e. a
+  // wave-level store of sixteen 32-byte pieces — the pattern that cost the GEMM epilogues their HBM time.
+  // Staged in the wave's OWN 32 rows of the K / V tiles (dead once phase 2 has its key fragments in registers, see the
+  // barrier below) they go out as whole 144-byte row pieces, 16 bytes per lane.
+  auto store_rows = [&](const char* tile, bf16* gbase) {
+    constexpr int NQ = 32 * NCH;
+#pragma unroll
+    for (int k = 0; k < (NQ + 63) / 64; ++k) {
+      const int qi = lane + 64 * k;
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      if (qi < NQ && r0 + rr < T)
+        *(uint4*)(gbase + (long)(r0 + rr) * tok + c * 8) = *(const uint4*)(tile + (r0 + rr) * ROWB + c * 16);
+    }
+  };
   if (r0 < T) {
     // ---------------- phase 1: dQ for queries [r0, r0+32) ----------------
     bf16x8 qf[2][KS], gf[2][KS];
@@ -347,7 +438,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     float lq[2], dq_[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) { lq[qt] = lse2[r0 + 16 * qt + i]; dq_[qt] = dlt[r0 + 16 * qt + i]; }
-    f32x4 dq[2][DT];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -401,24 +491,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         dq[1][dt] = MFMA(ktf, dsb[1], dq[1][dt]);
       }
     }
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int q = r0 + 16 * qt + i;
-      if (q < T) {
-        bf16* row = dbase + (long)q * tok;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          int d = 16 * dt + 4 * g;
-          if (d < HD) {
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[qt][dt][r] * scale);
-            *(bf16x4*)(row + d) = v;
-          }
-        }
-      }
-    }
   }
+  __syncthreads();   // phase 1 (every wave reads all of K and V) is over: rows [r0, r0+32) of Kt / Vt are this wave's alone
   if (r0 < T) {
     // ---------------- phase 2: dK, dV for keys [r0, r0+32) ----------------
     bf16x8 kf[2][KS], vf[2][KS];
@@ -429,6 +503,20 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
         vf[ct][ks] = frag_rows_z<HD>(Vt, r0 + 16 * ct, ks, lane);
       }
+    // dQ of phase 1 leaves now, staged in the K rows whose fragments were just taken; its stores drain under phase 2
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        if (d < HD) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[qt][dt][r] * scale);
+          *(bf16x4*)(Kt + (r0 + 16 * qt + i) * ROWB + d * 2) = v;
+        }
+      }
+    store_rows(Kt, dbase);
     f32x4 dk[2][DT], dv[2][DT];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -484,24 +572,20 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
       }
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int kv = r0 + 16 * ct + i;
-      if (kv < T) {
-        bf16* krow = dbase + (long)kv * tok + D;
-        bf16* vrow = dbase + (long)kv * tok + 2 * D;
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          int d = 16 * dt + 4 * g;
-          if (d < HD) {
-            bf16x4 a, c;
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        if (d < HD) {
+          bf16x4 a, c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = f2bf(dk[ct][dt][r] * scale); c[r] = f2bf(dv[ct][dt][r]); }
-            *(bf16x4*)(krow + d) = a;
-            *(bf16x4*)(vrow + d) = c;
-          }
+          for (int r = 0; r < 4; ++r) { a[r] = f2bf(dk[ct][dt][r] * scale); c[r] = f2bf(dv[ct][dt][r]); }
+          *(bf16x4*)(Kt + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
+          *(bf16x4*)(Vt + (r0 + 16 * ct + i) * ROWB + d * 2) = c;
         }
       }
-    }
+    store_rows(Kt, dbase + D);
+    store_rows(Vt, dbase + 2 * D);
   }
 }
 
