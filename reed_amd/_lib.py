@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreed_hip.so")
+# REED_HIP_LIB: same-box A/B of two builds of the library (tools/); the product loads the in-tree one
+LIB_PATH = os.environ.get("REED_HIP_LIB") or os.path.join(_HERE, "libreed_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "reed_hip.h")
 
 _lib = None
