@@ -263,6 +263,49 @@ def test_full_size_properties(dev):
     assert torch.equal(g3, 2.0 * g1)
 
 
+def test_tile_choice_is_bit_invisible_at_small_local_batch(dev):
+    """The 8-GPU point (SiT-XL/2 + 1024-d projector, local batch 32): the step whose 1152-wide GEMMs run on the 256x144
+    tile (the heuristic's choice there, csrc/gemm144.hip) against the same step with every GEMM forced onto the 128^2
+    kernel — the kernels are bit-identical per GEMM, so loss and every gradient must be bit-identical too."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import random_fill
+    from reed_amd import ops
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT_models
+    torch.manual_seed(0)
+    m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8).to(dev).train()
+    random_fill(m, 4321)
+    B = 32
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(B, 4, 32, 32, device=dev, generator=g)
+    noise = torch.randn(B, 4, 32, 32, device=dev, generator=g)
+    t = torch.rand(B, device=dev, generator=g) * 0.9 + 0.05
+    y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    zs = [torch.randn(B, 256, 1024, device=dev, generator=g)]
+    m.force_drop_mask = torch.rand(B, device=dev, generator=g) < 0.1
+    lf = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
+
+    def step(tile):
+        ops.gemm_force_tile(tile)
+        try:
+            for p in m.parameters():
+                p.grad = None
+            m.engine().zero_grad()
+            out = lf(m, x, dict(y=y), zs=zs, time_input=t.cpu(), noises=noise)
+            loss = out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss.detach()), m._arena.grad.clone()
+        finally:
+            ops.gemm_force_tile(0)
+
+    l0, g0 = step(0)
+    l1, g1 = step(128)
+    assert np.isfinite(l0) and float(g0.abs().max()) > 0
+    assert l0 == l1 and torch.equal(g0, g1)
+
+
 def test_c4_xl2_two_encoders_vs_reference_bf16(dev):
     """C4 (BASELINE.json configs[3]): SiT-XL/2 with CLIP-L-shaped image tokens (1024-d, tap after block 8) and a pooled
     text / VLM vector (3584-d, tap after block 16), repa coefficients 1.0 / 0.5, B=4, 2 optimiser steps on injected
