@@ -22,6 +22,7 @@
 //   half 0:  wait reads(t, ks0) | issue reads(t, ks1) | MFMA(t, ks0)
 //   half 1:  wait DMA(t+1), reads(t, ks1) | barrier | issue DMA(t+3) into t's slot | issue reads(t+1, ks0) | MFMA(t, ks1)
 // NT / NN layouts, bf16-output epilogues (tile_epilogue's LDS-staged row-contiguous stores), no split-K.
+#include <math.h>
 #include <stdlib.h>
 
 #include "gemm_common.hpp"
@@ -115,8 +116,10 @@ __device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&
   }
 }
 
-template <int LAY, int EPI>
-__global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
+// LW (default; REED_GEMM144_LW=0 selects the 8-wave form): 4 extra LOADER waves (8..11, one per SIMD) issue every LDS-DMA of the workgroup;
+// the 8 compute waves then carry MFMAs and fragment reads only (no buffer_load ... lds issue cycles, no vmcnt waits).
+template <int LAY, int EPI, bool LW>
+__global__ __launch_bounds__(LW ? 768 : 512) void gemm144_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,6 +185,74 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(sb + A_BYTES + B_MAIN + wave * 1024), 16, vBp, kB + pieceB,
                                                0, 0);
   };
+
+  if constexpr (LW) {
+    if (wave >= 8) {
+      const int lw = wave - 8;
+      const bool ex = lw < 2;                    // loaders 0, 1 also take one of the two B-piece KiB: 13 DMAs per K-tile
+      const int rin = lane >> 3, cpl = lane & 7;
+      const int keyA = (4 * (lw & 1)) | (rin >> 1);   // ((8 q + rin) >> 1) & 7 with q = lw + 4 j
+      const int vLA = (int)(((long)rin * a.ldp + ((cpl ^ keyA) << 3)) * 2);
+      int vLB, vLP;
+      if constexpr (LAY == LAY_NT) {
+        vLB = (int)(((long)rin * a.ldq + ((cpl ^ keyA) << 3)) * 2);
+        vLP = vLB;
+      } else {
+        const int r4 = lane >> 4, chp = lane & 15;
+        vLB = (int)(((long)r4 * a.ldq + ((chp ^ ((r4 << 2) | lw)) << 3)) * 2);   // tr_sw(4 q + r4), q & 3 == lw
+        const int d = (lw & 1) * 64 + lane, rr = swap23(d >> 1);
+        vLP = (int)(((long)rr * a.ldq + 128 + (d & 1) * 8) * 2);
+      }
+      auto lissue = [&](int t, int slot) {
+        char* sb = smem + slot * STAGE4;
+        const int kA = t * (BK4 * 2), kB = t * kstepB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = lw + 4 * j;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)(sb + q * 1024), 16, vLA, kA + q * 8 * (int)a.ldp * 2, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = lw + 4 * j;
+          const int so = (LAY == LAY_NT) ? q * 8 * (int)a.ldq * 2 : q * 4 * (int)a.ldq * 2;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(sb + A_BYTES + q * 1024), 16, vLB, kB + so, 0, 0);
+        }
+        if (ex) {
+          const int so = (LAY == LAY_NT) ? (16 + lw) * 8 * (int)a.ldq * 2 : 0;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(sb + A_BYTES + B_MAIN + lw * 1024), 16, vLP, kB + so, 0, 0);
+        }
+      };
+      lissue(0, 0);
+      if (nt > 1) lissue(1, 1);
+      if (nt > 2) lissue(2, 2);
+      if (nt > 2) {
+        if (ex) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      } else if (nt > 1) {
+        if (ex) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      int slot = 0;
+      for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+          if (t + 2 < nt) {
+            if (ex) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();
+          if (t + 3 < nt) lissue(t + 3, slot);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      __syncthreads();
+      return;
+    }
+  }
 
   // ---- fragment addresses (LDS byte offsets inside a stage) ----
   const int li = lane & 15, lg = lane >> 4, lq = li >> 2, lp = li & 3;
@@ -255,6 +326,7 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
   u32x4 A0f[4], B0f[5], A1f[4], B1f[5];
 
   // prologue: K-tiles 0, 1, 2 in flight; wait for tile 0
+  if constexpr (!LW) {
   issue(0, 0);
   if (nt > 1) issue(1, 1);
   if (nt > 2) issue(2, 2);
@@ -266,6 +338,7 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   }
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
@@ -285,24 +358,28 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
     const int nslot = slot == 2 ? 0 : slot + 1;
     // ---- half 0 ----  (reads(t, ks0) landed: waited at the end of the previous iteration / the prologue)
     LOADF(1, so, A1f, B1f);
-    if (pend) { issue(pend_t, pend_slot); pend = false; }
+    if constexpr (!LW) { if (pend) { issue(pend_t, pend_slot); pend = false; } }
     __builtin_amdgcn_sched_barrier(0);
     MMA(A0f, B0f);
     __builtin_amdgcn_sched_barrier(0);
     // ---- half 1 ----
     if (t + 1 < nt) {
+      if constexpr (!LW) {
       if (t + 2 < nt) {              // K-tile t+1 landed; only t+2's DMAs may still be in flight
         if (extra) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      }
       LDS_WAIT0();                   // reads(t, ks1) landed: this wave is done with slot(t)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (!LW) {
       if (t + 3 < nt) {
         if (late) { pend = true; pend_t = t + 3; pend_slot = slot; }
         else issue(t + 3, slot);
+      }
       }
       LOADF(0, (unsigned)nslot * STAGE4, A0f, B0f);
     } else {
@@ -321,17 +398,35 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmArgs a) {
   if (wc == 0) strip_epilogue<EPI>(a, accx, m0 + wr * 64, n0 + 64, lane);   // columns 64 .. 79 of the tile
 }
 
+static bool use_loader_waves() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("REED_GEMM144_LW"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 template <int LAY, int EPI>
 int launch144(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
+  constexpr bool HAS_LW = EPI == EPI_BF16 || EPI == EPI_GATE_RES || EPI == EPI_GELU || EPI == EPI_DGELU;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm144_kernel<LAY, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm144_kernel<LAY, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        LDS4);
+    if constexpr (HAS_LW) {
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm144_kernel<LAY, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    }
     if (e != hipSuccess) { reed_set_error("gemm144: cannot reserve 150 KiB LDS: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM4) * (a.N / BN4), 1, 1);
-  REED_KLAUNCH((gemm144_kernel<LAY, EPI>), grid, dim3(512), LDS4, stream, a);
+  if constexpr (HAS_LW) {
+    if (use_loader_waves()) {
+      REED_KLAUNCH((gemm144_kernel<LAY, EPI, true>), grid, dim3(768), LDS4, stream, a);
+      REED_LAUNCH_CHECK();
+      return REED_OK;
+    }
+  }
+  REED_KLAUNCH((gemm144_kernel<LAY, EPI, false>), grid, dim3(512), LDS4, stream, a);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -365,22 +460,28 @@ bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits) {
 int reed_num_cus();   // gemm256.hip
 
 // Kernel selection against the 256^2 / 128^2 kernels, in gemm256.hip's units (one CU x one 128^2 tile; 256^2 tile = 4 /
-// 1.18).  A 256x144 tile is 0.5625 of a 256^2 tile; its main loop runs at the chip's dense-MFMA ceiling when all 256 CUs
-// are busy, but per round it exposes the same epilogue as the 256^2 kernel on 0.56 of the work, so over the block
-// shapes it is worth ~0.80 of the 256^2 kernel per flop (tools/tile_ab.py, b = 32 .. 256): cost = rounds x 2.25 / 0.80.
-// The 256^2 side is counted in WHOLE rounds here (ragged column tiles as workgroups): at 1.25 rounds (b = 64, N = 1152)
-// the second, quarter-full round costs a full tile time.  Outcome on SiT-XL/2: the five 1152-wide outputs (proj / fc2
-// forward, dgrads of qkv / proj / fc1) at b <= 64 per GPU (-14 .. -28 % at b = 32, -7 .. -17 % at b = 64); everything
-// else stays where it was.
+// 1.18).  A 256x144 tile is 0.5625 of a 256^2 tile; with the loader waves its main loop runs at the chip's dense-MFMA
+// ceiling when all 256 CUs are busy, but per round it exposes the same epilogue as the 256^2 kernel on 0.56 of the work,
+// so over the block shapes it is worth ~0.92 of the 256^2 kernel per flop (tools/tile_ab.py and, in-step,
+// tools/eta_sweep.sh, b = 32 .. 256): cost = rounds x 2.25 / 0.92.  The 256^2 side: below two rounds in WHOLE rounds
+// (ragged column tiles as workgroups: at 1.25 rounds — b = 64, N = 1152 — the second, quarter-full round costs a full
+// tile time), from two rounds on gemm256.hip's own half-round model.  Outcome on SiT-XL/2: the five 1152-wide outputs
+// (proj / fc2 forward, dgrads of qkv / proj / fc1) at b <= 64 per GPU and the two 4608-wide ones (fc1 forward, fc2
+// dgrad) at b = 32; everything else stays where it was.
 bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits) {
   if (!reed_gemm144_eligible(layout, epi, a, splits) || a.K < 256) return false;
   const int ncu = reed_num_cus();
+  static const double eta = getenv("REED_GEMM144_ETA") ? atof(getenv("REED_GEMM144_ETA")) : 0.92;   // experiments
+  const long tm = cdiv(a.M, 256), tn = cdiv(a.N, 256);
   const long t144 = (long)cdiv(a.M, BM4) * (a.N / BN4);
-  const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
   const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-  static const double eta = getenv("REED_GEMM144_ETA") ? atof(getenv("REED_GEMM144_ETA")) : 0.80;   // experiments
+  double r256 = (double)((tm * tn + ncu - 1) / ncu);
+  if ((a.N % 256) != 0 && (a.N % 256) <= 128) {
+    const double w = (double)tm * (tn - 1) + 0.6 * tm;
+    if (w >= 2.0 * ncu) r256 = ceil(2.0 * w / ncu) / 2.0;
+  }
   const double c144 = (double)((t144 + ncu - 1) / ncu) * 2.25 / eta;
-  const double c256 = (double)((t256 + ncu - 1) / ncu) * 4.0 / 1.18;
+  const double c256 = r256 * 4.0 / 1.18;
   const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
   return c144 < c256 && c144 < c128;
 }
