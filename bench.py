@@ -158,6 +158,30 @@ def cpu_baseline():
                       f"1 step after a B=2 warm-up, {dt:.1f}s"}
 
 
+def dp_consistency(reducer, opt, model, world, b):
+    """Data-parallel consistency after the timed steps: identical optimiser steps on all-reduced (and factor-gathered)
+    gradients must leave every rank with the same parameters bit for bit — two checksums per rank, compared on rank 0."""
+    import torch.distributed as dist
+    if hasattr(opt, "flush"):
+        opt.flush()
+    A = model._arena
+    cs = torch.stack([A.master[:A.layout.n_train].double().sum(), A.master[:A.layout.n_train].double().abs().sum()])
+    allcs = [torch.zeros_like(cs) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allcs, cs)
+    else:
+        allcs = [cs]
+    allcs = torch.stack(allcs).cpu()
+    L = A.layout
+    ada = L.ada_rows * args_D(model) if reducer.ada_gather else 0
+    dp = {"binding": reducer.binding, "adaln_factor_gather": bool(reducer.ada_gather),
+          "ranks_bit_identical_params": bool((allcs == allcs[0]).all()),
+          "param_checksum": float(allcs[0, 0]),
+          "allreduce_bytes_per_step": int(4 * (L.n_train - ada - (L.ada_rows if reducer.ada_gather else 0))),
+          "allgather_bytes_per_rank_per_step": int(2 * b * (L.ada_rows + args_D(model))) if reducer.ada_gather else 0}
+    return dp
+
+
 def args_D(model):
     return model.engine().D
 
@@ -227,25 +251,10 @@ def main():
     dt = float(tmax.item())
     loss_val = float(res["loss"])
     dp = None
-    if reducer is not None:
-        # data-parallel consistency: after K identical optimiser steps on all-reduced (and factor-gathered) gradients every
-        # rank must hold the same parameters bit for bit — two checksums per rank, compared on rank 0
-        opt.flush() if hasattr(opt, "flush") else None
-        A = model._arena
-        cs = torch.stack([A.master[:A.layout.n_train].double().sum(), A.master[:A.layout.n_train].double().abs().sum()])
-        allcs = [torch.zeros_like(cs) for _ in range(world)]
-        if world > 1:
-            dist.all_gather(allcs, cs)
-        else:
-            allcs = [cs]
-        allcs = torch.stack(allcs).cpu()
-        L = A.layout
-        ada = L.ada_rows * args_D(model) if reducer.ada_gather else 0
-        dp = {"binding": reducer.binding, "adaln_factor_gather": bool(reducer.ada_gather),
-              "ranks_bit_identical_params": bool((allcs == allcs[0]).all()),
-              "param_checksum": float(allcs[0, 0]),
-              "allreduce_bytes_per_step": int(4 * (L.n_train - ada - (L.ada_rows if reducer.ada_gather else 0))),
-              "allgather_bytes_per_rank_per_step": int(2 * b * (L.ada_rows + args_D(model))) if reducer.ada_gather else 0}
+    try:
+        dp = dp_consistency(reducer, opt, model, world, b) if reducer is not None else None
+    except Exception as e:   # a reported check, never a reason to lose the throughput line
+        dp = {"error": repr(e)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
