@@ -1,3 +1,6 @@
+"""gemm144.hip bring-up aid: identity / random operands on the smallest shapes (1, 2, 3 and 8 K-tiles, one and two column
+tiles, both layouts) with the positions of the first mismatches — the tool that located the element-wise re-pack of
+bf16 fragment vectors.  usage (GPU box): python tools/dbg144.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
