@@ -92,6 +92,10 @@ class GradReducer:
             if not dist.is_initialized():
                 raise RuntimeError("GradReducer: torch.distributed must be initialised for the torch RCCL binding")
             self._tstream = torch.cuda.Stream(device=model._arena.master.device, priority=-1)
+            # AVG and all_gather_into_tensor on device tensors are RCCL features; on any other backend (gloo: the
+            # two-ranks-on-one-GPU test of tests/test_cli_gpu.py) the same results come from SUM + scale / a SUM over a
+            # zero-padded buffer
+            self._rccl = dist.get_backend() == "nccl"
         model.engine().reducer = self
 
     def _init_native(self):
@@ -134,7 +138,14 @@ class GradReducer:
             return
         self._tstream.wait_stream(torch.cuda.current_stream())   # the bucket's gradients are written
         with torch.cuda.stream(self._tstream):
-            dist.all_reduce(g[b:e], op=dist.ReduceOp.AVG)           # stream-ordered: no host wait
+            self._t_allreduce_avg(g[b:e])                          # stream-ordered: no host wait
+
+    def _t_allreduce_avg(self, t):
+        if self._rccl:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(t)
+            t.mul_(1.0 / self.world)
 
     def active(self):
         """True when this backward's gradients are being reduced (not a no_sync micro-step, more than one rank)."""
@@ -151,7 +162,7 @@ class GradReducer:
             return
         self._tstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._tstream):
-            dist.all_reduce(g[b:e], op=dist.ReduceOp.AVG)
+            self._t_allreduce_avg(g[b:e])
 
     def gather_buffers(self, name, numel, dtype, device):
         """Persistent (send [numel], recv [world * numel]) pair: the collectives run on the communicator's stream, so
@@ -176,7 +187,14 @@ class GradReducer:
             return
         self._tstream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._tstream):
-            dist.all_gather_into_tensor(recv, send)
+            if self._rccl:
+                dist.all_gather_into_tensor(recv, send)
+            else:   # exact: every element is one rank's bit pattern plus zeros
+                ri, si = recv.view(torch.int32), send.view(torch.int32)   # (16-bit payloads: an even element count)
+                n = si.numel()
+                ri.zero_()
+                ri[self.rank * n:(self.rank + 1) * n].copy_(si)
+                dist.all_reduce(ri)
             self._gev = torch.cuda.Event()
             self._gev.record()
 

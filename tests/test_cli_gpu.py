@@ -3,12 +3,15 @@ checkpoint layout, resume, then generate.py counterpart sampling from the EMA ch
 import glob
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_train_checkpoint_resume_generate(dev, tmp_path):
@@ -100,6 +103,81 @@ def test_rccl_reducer_world1(dev, binding, ada_gather):
         os.environ.pop("REED_COMM", None)
         if binding == "torch" and dist.is_initialized():
             dist.destroy_process_group()
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from oracle import detfill
+from reed_amd.loss import SILoss
+from reed_amd.models.sit import SiT
+from reed_amd.parallel import GradReducer
+
+def make():
+    m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10, z_dims=[128],
+            projector_dim=128, encoder_depth=2)
+    detfill.fill_state_dict(m.state_dict(), base_seed=3)
+    return m.to(dev).train()
+
+def backward(m, r):   # rank r's local batch (B = 4) and draws
+    m.force_drop_mask = torch.tensor([False, True, False, False])
+    lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+    x, n = detfill.normal((4, 4, 8, 8), 10 + r).to(dev), detfill.normal((4, 4, 8, 8), 20 + r)
+    out = lf(m, x, dict(y=torch.tensor([1, 2, 3, 4], device=dev) + r), zs=[detfill.normal((4, 16, 128), 30 + r).to(dev)],
+             time_input=detfill.uniform((4,), 40 + r, 0.1, 0.9), noises=n)
+    (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+
+# reference on this rank: the two local gradients one after the other without a reducer, averaged
+ref = None
+for r in range(world):
+    m = make()
+    backward(m, r)
+    torch.cuda.synchronize()
+    g = m._arena.grad.clone()
+    ref = g if ref is None else ref + g
+ref /= world
+# the data-parallel step: this rank's batch, bucketed all-reduce(avg) + adaLN factor gather fired from backward
+m = make()
+red = GradReducer(m, rank=rank, world=world)
+assert red.binding == "torch" and red.ada_gather == (os.environ["REED_ADA_GATHER"] == "1")
+red.broadcast_params(0)
+backward(m, rank)
+red.sync()
+torch.cuda.synchronize()
+got = m._arena.grad.clone()
+L = m._layout
+covered = torch.zeros(L.n_train, dtype=torch.bool, device=dev)
+for b, e in red.buckets.values(): covered[b:e] = True
+torch.testing.assert_close(got[covered], ref[covered], rtol=2e-5, atol=2e-6)
+gc = got.cpu()
+allg = [torch.empty_like(gc) for _ in range(world)]
+dist.all_gather(allg, gc)
+assert all(torch.equal(allg[0][covered.cpu()], a[covered.cpu()]) for a in allg), "ranks disagree"
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+@pytest.mark.parametrize("ada_gather", ["1", "0"])
+def test_two_ranks_on_one_gpu(dev, tmp_path, ada_gather):
+    """The data-parallel ENGINE path with two real ranks (two processes sharing the one GPU of the box, collectives over
+    gloo through the torch binding of GradReducer): buckets fired from backward in completion order, the adaLN
+    factor gather with world = 2 (1/2-scaled factors, rank-major K = 2 b product, embed bucket cut short) or the adaLN
+    buckets — against the average of the two ranks' local gradients computed without a reducer, and both ranks equal."""
+    script = tmp_path / "w2.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29745", WORLD_SIZE="2", REED_COMM="torch",
+               REED_ADA_GATHER=ada_gather, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o[-3000:]
 
 
 def test_train_with_on_device_clip_encoder(dev, tmp_path, monkeypatch):
