@@ -180,6 +180,85 @@ def test_two_ranks_on_one_gpu(dev, tmp_path, ada_gather):
         assert p.returncode == 0 and "OK" in o, o[-3000:]
 
 
+_TWO_RANK_TRAIN_WORKER = r'''
+import copy, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from oracle import detfill
+from reed_amd.loss import SILoss
+from reed_amd.models.sit import SiT
+from reed_amd.optim import FusedAdamWEMA
+from reed_amd.parallel import GradReducer
+from reed_amd.trainer import TrainStep
+
+def make():
+    m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10, z_dims=[128],
+            projector_dim=128, encoder_depth=2)
+    detfill.fill_state_dict(m.state_dict(), base_seed=5)
+    m = m.to(dev).train()
+    ema = copy.deepcopy(m).requires_grad_(False).eval()
+    # eps far above the fp32 noise of a gradient: with 1e-8 Adam turns the last bits of a near-zero gradient (the two runs
+    # sum tokens in different orders) into a full +-lr step and the comparison below would be meaningless
+    opt = FusedAdamWEMA(m, ema, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-2, max_grad_norm=1.0)
+    return m, ema, opt
+
+def data(r, step):   # rank r's local batch of 4 at a step
+    s = 100 * step + 10 * r
+    return (detfill.normal((4, 4, 8, 8), s + 1).to(dev), torch.tensor([1, 2, 3, 4], device=dev) + r,
+            [detfill.normal((4, 16, 128), s + 2).to(dev)], detfill.uniform((4,), s + 3, 0.1, 0.9), detfill.normal((4, 4, 8, 8), s + 4))
+
+lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+# single process, global batch 8 = [rank 0's samples | rank 1's samples]
+m, ema, opt = make()
+step = TrainStep(m, lf, opt, None, proj_coeff=0.5, diffusion_warm_up_steps=0)
+for k in range(2):
+    parts = [data(r, k) for r in range(world)]
+    m.force_drop_mask = torch.tensor([False, True, False, False] * world)
+    step(torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), [torch.cat([p[2][0] for p in parts])],
+         time_input=torch.cat([p[3] for p in parts]), noises=torch.cat([p[4] for p in parts]))
+opt.flush(); torch.cuda.synchronize()
+ref, ref_ema = m._arena.master.clone(), ema._arena.master.clone()
+# two ranks, local batch 4 each
+m, ema, opt = make()
+red = GradReducer(m, rank=rank, world=world)
+red.broadcast_params(0)
+step = TrainStep(m, lf, opt, red, proj_coeff=0.5, diffusion_warm_up_steps=0)
+for k in range(2):
+    x, y, zs, t, n = data(rank, k)
+    m.force_drop_mask = torch.tensor([False, True, False, False])
+    step(x, y, zs, time_input=t, noises=n)
+opt.flush(); torch.cuda.synchronize()
+got, got_ema = m._arena.master.clone(), ema._arena.master.clone()
+nt = m._layout.n_train
+torch.testing.assert_close(got[:nt], ref[:nt], rtol=1e-4, atol=3e-6)
+torch.testing.assert_close(got_ema[:nt], ref_ema[:nt], rtol=1e-4, atol=3e-6)
+allg = [torch.empty(nt) for _ in range(world)]
+dist.all_gather(allg, got[:nt].cpu())
+assert all(torch.equal(allg[0], a) for a in allg), "parameters differ between the ranks after two steps"
+dist.barrier(); dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_two_ranks_train_steps_match_global_batch(dev, tmp_path):
+    """Two optimiser steps of TrainStep with two real ranks (local batch 4 each, gloo through the torch binding, adaLN
+    factor gather on) against the same two steps in one process on the global batch of 8: the reference's DDP contract
+    (train.py:263,293-295) — parameters and EMA equal to fp32 noise, bit-identical on both ranks."""
+    script = tmp_path / "w2t.py"
+    script.write_text(_TWO_RANK_TRAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747", WORLD_SIZE="2", REED_COMM="torch",
+               REED_ADA_GATHER="1", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in o, o[-3000:]
+
+
 def test_train_with_on_device_clip_encoder(dev, tmp_path, monkeypatch):
     """train.py counterpart on the reference's on-disk format (images/*.png + vae-sd/*.npy + dataset.json,
     image/dataset.py:18-85) with the frozen CLIP image encoder running on the GPU every step from a user-supplied
