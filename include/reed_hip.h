@@ -136,9 +136,11 @@ int reed_smallk_wgrad(const void* wide, int wide_is_f32, const void* small, floa
 /* TimestepEmbedder.positional_embedding (sit.py:45-64): out bf16 [B, dim] = [cos(t f) | sin(t f)] */
 int reed_timestep_sinusoid(const float* t, void* out, int B, int dim, float max_period, void* stream);
 /* LabelEmbedder (sit.py:84-99): labels_out = drop ? num_classes : labels; c_out f32 [B,D] = t_emb bf16 + table f32[label];
- * silu_c bf16 [B,D] = bf16(silu(c)) (input of every adaLN linear, sit.py:126-129) */
-int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, const float* table,
-                    const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int B, int D,
+ * silu_c bf16 [B,D] = bf16(silu(c)) (input of every adaLN linear, sit.py:126-129). table has table_rows rows; a label
+ * outside [0, table_rows) (nn.Embedding raises, sit.py:98) is replaced by row 0 and *err_flag (device int, may be NULL)
+ * is set to 1 — the caller reads it at its next synchronisation point. */
+int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, int table_rows, const float* table,
+                    const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int* err_flag, int B, int D,
                     void* stream);
 /* backward of the conditioning vector: dc f32 [B,D] -> dt_emb bf16, dtable f32 [rows,D] += (deterministic scatter;
  * dsilu_c is the f32 grad w.r.t. silu(c), bf16-rounded inside) */
@@ -212,6 +214,9 @@ int reed_sampler_input(const double* x, float* out, int64_t n_elems, int dup, vo
 int reed_comm_unique_id(void* out128);                       /* 128-byte ncclUniqueId */
 int reed_comm_init(const void* id128, int rank, int world, void** comm_out);
 int reed_comm_allreduce_avg(void* comm, float* buf, int64_t count, void* compute_stream); /* async on the comm stream, ordered after compute_stream */
+/* the same average issued as ncclReduceScatter + ncclAllGather, in place (the direct form of SURVEY.md §5; count % world
+ * tail elements through ncclAllReduce) */
+int reed_comm_allreduce_avg_rsag(void* comm, float* buf, int64_t count, void* compute_stream);
 int reed_comm_sync(void* comm, void* compute_stream);       /* compute_stream waits for all pending reductions */
 int reed_comm_broadcast(void* comm, float* buf, int64_t count, int root, void* compute_stream);
 /* all-gather of `bytes` bytes per rank (recv = world * bytes, rank-major), async on the comm stream, ordered after

@@ -43,20 +43,35 @@ extern "C" int reed_comm_unique_id(void* out128) {
   return REED_OK;
 }
 
-extern "C" int reed_comm_init(const void* id128, int rank, int world, void** comm_out) {
-  REED_CHECK_ARG(id128 && comm_out && world >= 1 && rank >= 0 && rank < world, "comm_init: bad args");
-  ReedComm* c = new ReedComm();
-  c->rank = rank;
-  c->world = world;
+static int comm_init_body(ReedComm* c, const void* id128) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
+  NCCL_TRY(ncclCommInitRank(&c->comm, c->world, id, c->rank));
   int lo, hi;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
   HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
   HIP_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->gdone, hipEventDisableTiming));
+  return REED_OK;
+}
+
+extern "C" int reed_comm_init(const void* id128, int rank, int world, void** comm_out) {
+  REED_CHECK_ARG(id128 && comm_out && world >= 1 && rank >= 0 && rank < world, "comm_init: bad args");
+  ReedComm* c = new ReedComm();
+  memset(c, 0, sizeof(*c));
+  c->rank = rank;
+  c->world = world;
+  int rc = comm_init_body(c, id128);
+  if (rc != REED_OK) {   // nothing half-built survives a failed init
+    if (c->gdone) (void)hipEventDestroy(c->gdone);
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->comm) (void)ncclCommAbort(c->comm);
+    delete c;
+    return rc;
+  }
   *comm_out = c;
   return REED_OK;
 }
@@ -67,6 +82,30 @@ extern "C" int reed_comm_allreduce_avg(void* comm, float* buf, int64_t count, vo
   HIP_TRY(hipEventRecord(c->ready, (hipStream_t)compute_stream));
   HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
   NCCL_TRY(ncclAllReduce(buf, buf, (size_t)count, ncclFloat32, ncclAvg, c->comm, c->stream));
+  HIP_TRY(hipEventRecord(c->done, c->stream));
+  return REED_OK;
+}
+
+// The same average as reduce-scatter + all-gather, both in place on the bucket: every rank reduces the 1 / world slice it
+// owns (ncclReduceScatter with recv = send + rank * chunk) and the slices are gathered back (ncclAllGather with
+// send = recv + rank * chunk). On a fully connected xGMI node each phase is one direct exchange with the 7 peers
+// (SURVEY.md §5); which of the two forms RCCL runs faster is for the 8-GPU node to say (REED_COMM_ALGO=rsag).
+// The count % world tail elements go through a plain all-reduce.
+extern "C" int reed_comm_allreduce_avg_rsag(void* comm, float* buf, int64_t count, void* compute_stream) {
+  ReedComm* c = (ReedComm*)comm;
+  REED_CHECK_ARG(c && buf && count > 0, "comm_allreduce_avg_rsag: bad args");
+  HIP_TRY(hipEventRecord(c->ready, (hipStream_t)compute_stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ready, 0));
+  const int64_t chunk = count / c->world, tail = count - chunk * c->world;
+  if (chunk > 0) {
+    float* mine = buf + chunk * c->rank;
+    NCCL_TRY(ncclReduceScatter(buf, mine, (size_t)chunk, ncclFloat32, ncclAvg, c->comm, c->stream));
+    NCCL_TRY(ncclAllGather(mine, buf, (size_t)chunk, ncclFloat32, c->comm, c->stream));
+  }
+  if (tail > 0) {
+    float* t = buf + chunk * c->world;
+    NCCL_TRY(ncclAllReduce(t, t, (size_t)tail, ncclFloat32, ncclAvg, c->comm, c->stream));
+  }
   HIP_TRY(hipEventRecord(c->done, c->stream));
   return REED_OK;
 }

@@ -185,13 +185,21 @@ __global__ void sinusoid_kernel(const float* __restrict__ t, bf16* __restrict__ 
 }
 
 // ---- label embedding + conditioning ----
+// A label outside [0, table_rows) (nn.Embedding raises there, sit.py:98) must not index past the table: the table lives
+// in the flat parameter arena, so the read would return other parameters and the backward scatter would add into their
+// gradients. Such a label is replaced by row 0 and reported through the sticky device flag `err` (read by the host at
+// its next synchronisation point: reed_amd/engine.py:Engine.check_errors).
 __global__ void label_cond_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ drop, int num_classes,
-                                  const float* __restrict__ table, const bf16* __restrict__ t_emb,
+                                  int table_rows, const float* __restrict__ table, const bf16* __restrict__ t_emb,
                                   int64_t* __restrict__ labels_out, float* __restrict__ c, bf16* __restrict__ silu_c,
-                                  int D) {
+                                  int* __restrict__ err, int D) {
   const int b = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
   int64_t lab = labels[b];
   if (drop && drop[b]) lab = num_classes;
+  if (lab < 0 || lab >= table_rows) {
+    if (d == 0 && err) *err = 1;
+    lab = 0;
+  }
   if (d == 0 && labels_out) labels_out[b] = lab;
   if (d >= D) return;
   float v = bf2f(t_emb[(long)b * D + d]) + table[lab * D + d];
@@ -375,12 +383,14 @@ extern "C" int reed_timestep_sinusoid(const float* t, void* out, int B, int dim,
   return REED_OK;
 }
 
-extern "C" int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, const float* table,
-                               const void* t_emb, int64_t* labels_out, float* c, void* silu_c, int B, int D,
-                               void* stream) {
+extern "C" int reed_label_cond(const int64_t* labels, const uint8_t* drop, int num_classes, int table_rows,
+                               const float* table, const void* t_emb, int64_t* labels_out, float* c, void* silu_c,
+                               int* err_flag, int B, int D, void* stream) {
   REED_CHECK_ARG(labels && table && t_emb && c && silu_c, "label_cond: null pointer");
+  REED_CHECK_ARG(table_rows >= 1 && (!drop || num_classes < table_rows),
+                 "label_cond: label dropout needs a null-class row (num_classes < table_rows)");
   REED_KLAUNCH(label_cond_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, (hipStream_t)stream, labels, drop,
-                     num_classes, table, (const bf16*)t_emb, labels_out, c, (bf16*)silu_c, D);
+                     num_classes, table_rows, table, (const bf16*)t_emb, labels_out, c, (bf16*)silu_c, err_flag, D);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -56,6 +56,19 @@ class Engine:
         self.wgrad_stream = {"0": False, "1": True}.get(os.environ.get("REED_WGRAD_STREAM", "auto"))
         self.wgrad_stream_max_tokens = int(os.environ.get("REED_WGRAD_STREAM_MAXTOK", "12288"))
         self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
+        self.table_rows = model.num_classes + (1 if model.class_dropout_prob > 0 else 0)
+        self._err = None         # sticky device flag: a label outside the embedding table was seen (see check_errors)
+
+    def check_errors(self):
+        """Raise if any forward since the last check saw a class label outside the embedding table (the reference's
+        nn.Embedding raises IndexError at that forward, sit.py:98; here the kernel substitutes row 0, sets a device flag
+        and the error surfaces at the caller's next synchronisation point: the trainer's logging sync, the samplers'
+        return, state_dict()). Costs one 4-byte D2H copy — call it where the host synchronises anyway."""
+        if self._err is not None and int(self._err.item()) != 0:
+            self._err.zero_()
+            raise IndexError(f"reed_amd.SiT: a class label outside [0, {self.table_rows}) was passed to the model "
+                             f"(num_classes={self.m.num_classes}, class_dropout_prob={self.m.class_dropout_prob}); "
+                             "the affected forwards used row 0 instead")
 
     # ---- pointers into the arenas -------------------------------------------------
     def W(self, name):
@@ -124,8 +137,10 @@ class Engine:
         labels_eff = torch.empty(B, dtype=torch.int64, device=dev)
         c = f32(B, D)
         silu_c = bf(B, D)
+        if self._err is None:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.label_cond(y, drop_u8, m.num_classes, self.Wf("y_embedder.embedding_table.weight"), temb, labels_eff, c,
-                       silu_c, B, D)
+                       silu_c, B, D, table_rows=self.table_rows, err=self._err)
         Nall = L.ada_rows
         mod = bf(B, Nall)
         sp = self._shadow.data_ptr()

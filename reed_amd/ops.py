@@ -244,9 +244,11 @@ def timestep_sinusoid(t, out, B, dim=256, max_period=10000.0):
     _call("reed_timestep_sinusoid", _p(t), _p(out), B, dim, max_period, _stream())
 
 
-def label_cond(labels, drop, num_classes, table, t_emb, labels_out, c, silu_c, B, D):
-    _call("reed_label_cond", _p(labels), _p(drop), num_classes, _p(table), _p(t_emb), _p(labels_out), _p(c),
-          _p(silu_c), B, D, _stream())
+def label_cond(labels, drop, num_classes, table, t_emb, labels_out, c, silu_c, B, D, table_rows=None, err=None):
+    if table_rows is None:
+        table_rows = num_classes + 1
+    _call("reed_label_cond", _p(labels), _p(drop), num_classes, table_rows, _p(table), _p(t_emb), _p(labels_out), _p(c),
+          _p(silu_c), _p(err), B, D, _stream())
 
 
 def label_cond_bwd(dsilu_c, c, labels_eff, dt_emb, dtable, B, D):

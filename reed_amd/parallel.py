@@ -57,13 +57,19 @@ def check_buckets(layout):
 
 
 class GradReducer:
-    """RCCL-backed reducer. Needs torch.distributed initialised (any backend) only to ship the 128-byte RCCL id.
+    """RCCL-backed reducer (torch.distributed must be initialised: it carries the 128-byte RCCL id of the native
+    communicator, the ranks' agreement on the binding, and the torch binding's collectives).
 
     Two bindings of the same collective (RCCL all-reduce(avg), fp32, in place, on a stream beside backward):
-      native   libreed_hip.so's own communicator + high-priority stream (csrc/comm.cpp) — the default;
-      torch    torch.distributed's NCCL(=RCCL) process group on a torch side stream — `REED_COMM=torch`, and the
-               automatic fall-back (with a warning) when the native communicator cannot be created, so that a
-               multi-GPU job still runs on RCCL rather than not at all."""
+      torch    torch.distributed's NCCL(=RCCL) process group on a torch side stream — the default: it is the one RCCL
+               instance every torch job on this image already runs, and no N > 1 run of the native binding exists yet;
+      native   libreed_hip.so's own communicator + high-priority stream (csrc/comm.cpp), `REED_COMM=native`. The ranks
+               AGREE on it: after the attempt every rank contributes an ok flag to a MIN all-reduce over the torch
+               process group, and if any rank failed, every rank destroys its native communicator and uses the torch
+               binding (a per-rank decision would leave the ranks issuing mismatched collectives: a hang, not an error).
+    Two forms of the reduction (`REED_COMM_ALGO`): `allreduce` (default) = one ncclAllReduce(avg) per bucket;
+    `rsag` = ncclReduceScatter(avg) + ncclAllGather on the bucket, the direct form SURVEY.md §5 derives for the fully
+    connected xGMI node. Same values either way (fp32 sums in RCCL's own order)."""
 
     def __init__(self, model, rank=None, world=None):
         self.rank = dist.get_rank() if rank is None else rank
@@ -79,15 +85,26 @@ class GradReducer:
         # (the 1 / world average is folded into the bf16 factor, exact for powers of two); REED_ADA_GATHER=0 turns it off
         self.ada_gather = os.environ.get("REED_ADA_GATHER", "1") != "0" and (self.world & (self.world - 1)) == 0
         self._gbuf = {}
-        mode = os.environ.get("REED_COMM", "native")
-        if mode != "torch":
+        mode = os.environ.get("REED_COMM", "torch")
+        self.algo = os.environ.get("REED_COMM_ALGO", "allreduce")
+        if self.algo not in ("allreduce", "rsag"):
+            raise ValueError(f"REED_COMM_ALGO={self.algo!r}: expected 'allreduce' or 'rsag'")
+        self.timing = None       # per-bucket event pairs when bench.py asks for the exposed-communication diagnosis
+        if mode == "native":
+            err = None
             try:
                 self._init_native()
             except RuntimeError as e:   # e.g. a second RCCL instance that cannot bootstrap next to torch's
+                err = e
+            if not self._agree(err is None):
+                if self.comm is not None:
+                    self._lib.reed_comm_destroy(self.comm)
+                    self.comm = None
                 import warnings
-                warnings.warn(f"reed_amd: native RCCL communicator unavailable ({e}); gradient all-reduce goes "
-                              "through torch.distributed's RCCL process group instead")
-                self.comm = None
+                warnings.warn(f"reed_amd: native RCCL communicator unavailable on at least one rank ({err}); every "
+                              "rank reduces through torch.distributed's RCCL process group instead")
+        elif mode != "torch":
+            raise ValueError(f"REED_COMM={mode!r}: expected 'torch' or 'native'")
         if self.comm is None:
             if not dist.is_initialized():
                 raise RuntimeError("GradReducer: torch.distributed must be initialised for the torch RCCL binding")
@@ -97,6 +114,15 @@ class GradReducer:
             # zero-padded buffer
             self._rccl = dist.get_backend() == "nccl"
         model.engine().reducer = self
+
+    def _agree(self, ok):
+        """True iff EVERY rank's `ok` is true (MIN all-reduce over the torch process group)."""
+        if self.world == 1 or not dist.is_initialized():
+            return ok
+        dev = self.model._arena.master.device if dist.get_backend() == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
 
     def _init_native(self):
         L = self._lib
@@ -131,18 +157,49 @@ class GradReducer:
         if not self.enabled or (self.world == 1 and not self.force):
             return
         b, e = self.buckets[name]
+        self._reduce(b, e, name)
+
+    def _reduce(self, b, e, name):
+        """All-reduce(avg) of grad[b:e) on the communicator's stream, ordered after the current stream."""
         g = self.model._arena.grad
         if self.comm is not None:
-            _lib.check(self._lib.reed_comm_allreduce_avg(self.comm, g.data_ptr() + 4 * b, e - b, self._stream()),
-                       "comm_allreduce_avg")
+            fn = self._lib.reed_comm_allreduce_avg_rsag if self.algo == "rsag" else self._lib.reed_comm_allreduce_avg
+            _lib.check(fn(self.comm, g.data_ptr() + 4 * b, e - b, self._stream()), "comm_allreduce_avg")
             return
         self._tstream.wait_stream(torch.cuda.current_stream())   # the bucket's gradients are written
         with torch.cuda.stream(self._tstream):
+            if self.timing is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             self._t_allreduce_avg(g[b:e])                          # stream-ordered: no host wait
+            if self.timing is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                self.timing.append((name, 4 * (e - b), ev0, ev1))
 
     def _t_allreduce_avg(self, t):
-        if self._rccl:
+        n = t.numel()
+        chunk = n // self.world
+        if self.algo == "rsag" and self._rccl and chunk > 0:
+            body = t[:chunk * self.world]
+            mine = body[self.rank * chunk:(self.rank + 1) * chunk]
+            dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.AVG)
+            dist.all_gather_into_tensor(body, mine)
+            if n > chunk * self.world:
+                dist.all_reduce(t[chunk * self.world:], op=dist.ReduceOp.AVG)
+        elif self._rccl:
             dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        elif self.algo == "rsag" and chunk > 0:   # gloo (tests): the same two-phase structure with SUM + scale
+            body = t[:chunk * self.world]
+            parts = list(body.view(self.world, chunk).unbind(0))
+            mine = torch.empty_like(parts[self.rank])
+            dist.reduce_scatter(mine, [p.contiguous() for p in parts])
+            mine.mul_(1.0 / self.world)
+            dist.all_gather(parts, mine)
+            if n > chunk * self.world:
+                tail = t[chunk * self.world:]
+                dist.all_reduce(tail)
+                tail.mul_(1.0 / self.world)
         else:
             dist.all_reduce(t)
             t.mul_(1.0 / self.world)
@@ -155,14 +212,7 @@ class GradReducer:
         """All-reduce(avg) of the gradient range [b, e) (a bucket cut short: see Engine.backward's factor path)."""
         if not self.active() or e <= b:
             return
-        g = self.model._arena.grad
-        if self.comm is not None:
-            _lib.check(self._lib.reed_comm_allreduce_avg(self.comm, g.data_ptr() + 4 * b, e - b, self._stream()),
-                       "comm_allreduce_avg")
-            return
-        self._tstream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._tstream):
-            self._t_allreduce_avg(g[b:e])
+        self._reduce(b, e, f"range[{b}:{e}]")
 
     def gather_buffers(self, name, numel, dtype, device):
         """Persistent (send [numel], recv [world * numel]) pair: the collectives run on the communicator's stream, so

@@ -15,6 +15,21 @@ def _check(latents):
                         "takes float32 inputs)")
 
 
+def _check_labels(model, y, cfg_scale):
+    """The reference's nn.Embedding raises on a label outside the table (sit.py:98) and the samplers hard-code the null
+    class id 1000 (samplers.py:59,120). One host check per sampler call (not per evaluation)."""
+    rows = getattr(getattr(model, "engine", lambda: None)(), "table_rows", None) if hasattr(model, "engine") else None
+    if rows is None:
+        return
+    lo, hi = int(y.min()), int(y.max())
+    if lo < 0 or hi >= rows:
+        raise IndexError(f"class labels in [{lo}, {hi}] but the model's embedding table has {rows} rows")
+    if cfg_scale > 1.0 and rows <= 1000:
+        raise IndexError(f"classifier-free guidance uses the null class id 1000 (samplers.py:59) but the model's "
+                         f"embedding table has only {rows} rows (num_classes={model.num_classes}, "
+                         f"class_dropout_prob={model.class_dropout_prob})")
+
+
 def _model_out(model, xin, rows, t_cur, y_cur):
     t_in = torch.full((rows,), float(t_cur), dtype=torch.float64, device=xin.device).to(torch.float32)
     out = model(xin, t_in, y=y_cur)[0]
@@ -24,6 +39,7 @@ def _model_out(model, xin, rows, t_cur, y_cur):
 def euler_sampler(model, latents, y, num_steps=20, heun=False, cfg_scale=1.0, guidance_low=0.0, guidance_high=1.0,
                   path_type="linear", **_ignored):
     _check(latents)
+    _check_labels(model, y, cfg_scale)
     n = y.size(0)
     if cfg_scale > 1.0:
         y_null = torch.tensor([1000] * n, device=y.device)  # hard-coded null id (samplers.py:59)
@@ -57,6 +73,7 @@ def euler_sampler(model, latents, y, num_steps=20, heun=False, cfg_scale=1.0, gu
 def euler_maruyama_sampler(model, latents, y, num_steps=20, heun=False, cfg_scale=1.0, guidance_low=0.0,
                            guidance_high=1.0, path_type="linear", noises=None, **_ignored):
     _check(latents)
+    _check_labels(model, y, cfg_scale)
     n = y.size(0)
     if cfg_scale > 1.0:
         y_null = torch.tensor([1000] * n, device=y.device)

@@ -262,8 +262,15 @@ def main(args):
     batch_sampler = torch.utils.data.BatchSampler(sampler, batch_size=local_batch_size, drop_last=True)
 
     class Shard(torch.utils.data.Sampler):
+        """Every rank yields exactly len(batch_sampler) // world batches per epoch (the tail that does not fill a whole
+        round of ranks is dropped), so the ranks stay on the same permutation and leave an epoch together — a rank with
+        one batch fewer would leave the others blocked in the bucket all-reduce."""
+
         def __iter__(self):
+            per_rank = len(batch_sampler) // world
             for k, batch in enumerate(batch_sampler):
+                if k >= per_rank * world:
+                    break
                 if k % world == rank:
                     yield batch
 
@@ -304,6 +311,8 @@ def main(args):
                 raw = _raw.to(device, non_blocking=True)
                 zs = [enc.encode_raw(raw) for enc in encoders]
             moments = moments.squeeze(dim=1).to(device, non_blocking=True)
+            if y.numel() and (int(y.min()) < 0 or int(y.max()) >= args.num_classes):   # on the host, before the copy
+                raise IndexError(f"dataset labels in [{int(y.min())}, {int(y.max())}] but --num-classes={args.num_classes}")
             y = y.to(device, non_blocking=True)
             if args.legacy:  # label dropping applied twice (train.py:338-343), kept for reproducibility
                 drop_ids = torch.rand(y.shape[0], device=device) < args.cfg_prob
@@ -334,6 +343,7 @@ def main(args):
                     dist.all_reduce(vals)
                     vals /= world
                 vals = vals.tolist()  # the only host sync of the step, and only every --log-every steps
+                model.engine().check_errors()
                 if is_main:
                     now = time.time()
                     ips = (global_step - n_last) * args.batch_size / max(now - t_last, 1e-9)

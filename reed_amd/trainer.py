@@ -92,5 +92,5 @@ class TrainStep:
             self.opt.step()          # clip + AdamW + EMA + bf16 re-cast, fused
             self.opt.zero_grad()
             self.global_step += 1
-            res["grad_norm"] = self.opt.grad_norm
+            res["grad_norm"] = self.opt.grad_norm.clone()   # opt.grad_norm is a view the next step overwrites
         return res

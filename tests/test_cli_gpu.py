@@ -51,17 +51,20 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
     assert lat.shape == (8, 4, 32, 32) and np.isfinite(lat).all()
 
 
+@pytest.mark.parametrize("algo", ["allreduce", "rsag"])
 @pytest.mark.parametrize("ada_gather", ["1", "0"])
 @pytest.mark.parametrize("binding", ["native", "torch"])
-def test_rccl_reducer_world1(dev, binding, ada_gather):
+def test_rccl_reducer_world1(dev, binding, ada_gather, algo):
     """Exercise every RCCL entry point (unique id, init, broadcast, bucketed all-reduce(avg) fired from backward on the
     side stream, sync, destroy) with a 1-rank communicator: averaging over one rank must leave gradients unchanged.
-    binding="torch": the same bucket plan through torch.distributed's RCCL process group (REED_COMM=torch, the
-    fall-back when the native communicator cannot be created)."""
+    binding="torch": the same bucket plan through torch.distributed's RCCL process group (the default binding, and what
+    every rank falls back to when the native communicator cannot be created on any of them). algo="rsag": each bucket as
+    ncclReduceScatter + ncclAllGather in place (REED_COMM_ALGO)."""
     import copy
     import torch.distributed as dist
+    os.environ["REED_COMM"] = binding
+    os.environ["REED_COMM_ALGO"] = algo
     if binding == "torch":
-        os.environ["REED_COMM"] = "torch"
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29741")
@@ -81,7 +84,7 @@ def test_rccl_reducer_world1(dev, binding, ada_gather):
             m.force_drop_mask = torch.tensor([False, True, False, False])
             red = GradReducer(m, rank=0, world=1) if with_reducer else None
             if red:
-                assert red.binding == binding and red.ada_gather == (ada_gather == "1")
+                assert red.binding == binding and red.ada_gather == (ada_gather == "1") and red.algo == algo
                 red.broadcast_params(0)
             lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
             x, n = detfill.normal((4, 4, 8, 8), 1).to(dev), detfill.normal((4, 4, 8, 8), 2)
@@ -101,6 +104,7 @@ def test_rccl_reducer_world1(dev, binding, ada_gather):
         os.environ.pop("REED_FORCE_REDUCER", None)
         os.environ.pop("REED_ADA_GATHER", None)
         os.environ.pop("REED_COMM", None)
+        os.environ.pop("REED_COMM_ALGO", None)
         if binding == "torch" and dist.is_initialized():
             dist.destroy_process_group()
 
@@ -163,16 +167,17 @@ print("OK", rank)
 '''
 
 
-@pytest.mark.parametrize("ada_gather", ["1", "0"])
-def test_two_ranks_on_one_gpu(dev, tmp_path, ada_gather):
+@pytest.mark.parametrize("ada_gather,algo", [("1", "allreduce"), ("0", "allreduce"), ("0", "rsag")])
+def test_two_ranks_on_one_gpu(dev, tmp_path, ada_gather, algo):
     """The data-parallel ENGINE path with two real ranks (two processes sharing the one GPU of the box, collectives over
     gloo through the torch binding of GradReducer): buckets fired from backward in completion order, the adaLN
     factor gather with world = 2 (1/2-scaled factors, rank-major K = 2 b product, embed bucket cut short) or the adaLN
-    buckets — against the average of the two ranks' local gradients computed without a reducer, and both ranks equal."""
+    buckets — against the average of the two ranks' local gradients computed without a reducer, and both ranks equal.
+    algo="rsag": every bucket as reduce-scatter + all-gather (REED_COMM_ALGO; over gloo the same two-phase structure)."""
     script = tmp_path / "w2.py"
     script.write_text(_TWO_RANK_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29745", WORLD_SIZE="2", REED_COMM="torch",
-               REED_ADA_GATHER=ada_gather, OMP_NUM_THREADS="2")
+               REED_ADA_GATHER=ada_gather, REED_COMM_ALGO=algo, OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]

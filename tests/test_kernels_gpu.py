@@ -143,9 +143,31 @@ def test_patch_embed_and_final_layer_index_maps_bit_exact(dev):
     ops.final_layer_fwd(xt, mod, mod[:, D:], 2 * D, wf.to(torch.bfloat16).to(dev), None, out, None, None, 1, T, D, C, P)
     hln = bfr(torch.nn.functional.layer_norm(xt, (D,), eps=1e-6))[:, :16].cpu()
     un = torch.from_numpy(gs["unpatchify_idx"]).flatten()    # out.flat[i] = lin.flat[un[i]]
-    torch.testing.assert_close(out.cpu().flatten(), hln.flatten()[un], atol=2e-2, rtol=0)
-    idx_exact = (out.cpu().flatten() - hln.flatten()[un]).abs().max()
-    assert idx_exact < 2e-2
+    torch.testing.assert_close(out.cpu().flatten(), hln.flatten()[un], atol=2e-2, rtol=0)   # values (LayerNorm in between)
+    # The index map itself, bit for bit and independent of any rounding: 12 passes, pass r carries bit r of the linear
+    # position (token * 16 + j) as the SIGN of element (token, j). Columns 16..31 hold the negated pattern, so every row
+    # sums to exactly 0, LayerNorm keeps each sign, and the one-hot W copies it through: decoding the signs of the output
+    # must give the reference's unpatchify map exactly (sit.py:256-269, golden `unpatchify_idx`).
+    pos_id = torch.arange(T * 16).reshape(T, 16)
+    decoded = torch.zeros(C * HW * HW, dtype=torch.long)
+    for r in range(12):
+        sgn = ((pos_id >> r) & 1).float() * 2 - 1
+        xs_ = torch.zeros(T, D)
+        xs_[:, :16], xs_[:, 16:32] = sgn, -sgn
+        ops.final_layer_fwd(xs_.to(dev), mod, mod[:, D:], 2 * D, wf.to(torch.bfloat16).to(dev), None, out, None, None, 1, T,
+                            D, C, P)
+        o = out.cpu().flatten()
+        assert (o.abs() > 1.0).all()
+        decoded |= (o > 0).long() << r
+    assert torch.equal(decoded, un)
+    # and the backward's patchify of the output gradient in the (pi, pj, c) order (reed_patchify_bf16 order 1) is its inverse
+    gi = torch.empty(T, 16, dtype=torch.bfloat16, device=dev)
+    for lo in range(0, 4096, 256):
+        img = torch.where((flat >= lo) & (flat < lo + 256), flat - lo + 1, torch.zeros_like(flat)).float()
+        ops.patchify_bf16(img.reshape(1, C, HW, HW).to(dev), gi, B, C, HW, P, 1)
+        exp = torch.zeros(T * 16)
+        exp[un] = img                                         # lin.flat[un[i]] = out.flat[i]
+        assert torch.equal(gi.float().cpu().flatten(), exp)
 
 
 def test_patch_embed_values_and_smallk_wgrad(dev):
@@ -253,6 +275,86 @@ def test_loss_kernels(dev):
     o = torch.empty_like(eps)
     ops.sample_posterior(mom, eps, o, B, 4 * 64, 0.18215, 0.0)
     torch.testing.assert_close(o, (mom[:, :4] + mom[:, 4:] * eps) * 0.18215, atol=1e-6, rtol=1e-6)
+
+
+def test_siloss_hip_vs_reference_units(dev):
+    """reed_amd.loss.SILoss (HIP interpolant / MSE / cosine kernels + the reference's time-weight broadcasting) on the
+    reference's own unit vectors (tools/gen_golden.py:g_loss_units): 6 time schedules x 2 path types with two encoders
+    (image tokens + pooled text), the zero-weight branch, single-encoder keying, and the lognormal t transform
+    (image/loss.py:118-151,160-168,204-237). fp32 arithmetic on both sides: 2e-6 relative."""
+    from reed_amd.loss import SILoss
+    g = load("loss_units")
+    from tests.test_oracle_golden import inputs
+    B = 6
+    x, noise, t, y, _, zs = inputs(B, 4, 8, 21, [(32, "i"), (16, "t")], 16, 10)
+    zt = [detfill.normal((B, 16, 32), 901).bfloat16().to(dev), detfill.normal((B, 16), 902).bfloat16().to(dev)]
+    vel = detfill.normal((B, 4, 8, 8), 903).to(dev)
+    zs_d = [z.to(dev) for z in zs]
+    worst = 0.0
+    for sched in ["constant", "linear", "cosine", "sigmoid", "loglinear", "cutoff"]:
+        for path in ["linear", "cosine"]:
+            lf = SILoss(path_type=path, enc_names=["clip", "text_embeds_qwenvl"],
+                        loss_weights={"clip": 1.0, "text_embeds_qwenvl": 0.5}, time_schedule=sched, cutoffs=[0.2, 0.8])
+            o = lf(lambda xx, tt, **k: (vel + 0.1 * xx, zt), x.to(dev), dict(y=y.to(dev)), zs=zs_d, time_input=t, noises=noise)
+            for k in ("denoising_loss", "proj_loss", "img_proj_loss", "text_proj_loss"):
+                got, ref = torch.as_tensor(o[k]).detach().cpu().numpy(), g[f"{sched}.{path}.{k}"]
+                worst = max(worst, float(np.max(np.abs(got - ref) / (np.abs(ref) + 1e-6))))
+                np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-7, err_msg=f"{sched}.{path}.{k}")
+    print("SILoss HIP vs reference units: worst relative deviation", worst)
+    lf = SILoss(enc_names=["text_embeds_qwenvl"], loss_weights={"text_embeds_qwenvl": 0.0}, time_schedule="linear")
+    o = lf(lambda xx, tt, **k: (vel, [zt[0]]), x.to(dev), dict(y=y.to(dev)), zs=[zs_d[0]], time_input=t, noises=noise)
+    np.testing.assert_allclose(float(o["proj_loss"]), g["zero_weight.proj_loss"], rtol=2e-6)
+    np.testing.assert_allclose(float(o["img_proj_loss"]), g["zero_weight.img_proj_loss"], rtol=2e-6)
+    assert o["text_proj_loss"] == 0.0
+    # lognormal weighting: t = sigma / (1 + sigma) or (2 / pi) atan(sigma), sigma = exp(N(0,1)) drawn on the CPU generator
+    rn = detfill.normal((B, 1, 1, 1), 77)
+    o_randn = torch.randn
+    for path in ["linear", "cosine"]:
+        cap = {}
+        torch.randn = lambda *s, **k: rn.clone()
+        try:
+            lf = SILoss(path_type=path, weighting="lognormal", enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+            lf(lambda xx, tt, **k: (cap.setdefault("t", tt), (vel, [zt[0]]))[1], x.to(dev), dict(y=y.to(dev)), zs=[zs_d[0]],
+               noises=noise)
+        finally:
+            torch.randn = o_randn
+        np.testing.assert_allclose(cap["t"].cpu().numpy(), g[f"lognormal.{path}.t"], rtol=1e-6)
+
+
+def test_label_out_of_range_is_reported(dev):
+    """A label outside the embedding table (nn.Embedding raises, sit.py:98) must neither read nor scatter outside the
+    table (it lives inside the flat parameter arena): the kernel uses row 0, sets the device flag, and
+    Engine.check_errors() / the samplers raise."""
+    from reed_amd import ops, samplers
+    from tests.test_model_gpu import build_hip_model
+    from tests.test_oracle_golden import tiny_cfg
+    B, D, NC = 4, 128, 10
+    table = torch.randn(NC + 1, D, generator=torch.Generator().manual_seed(1)).to(dev)
+    temb = torch.zeros(B, D, dtype=torch.bfloat16, device=dev)
+    labels = torch.tensor([0, 11, -3, 10], device=dev)
+    eff = torch.empty(B, dtype=torch.int64, device=dev)
+    c, sc = torch.empty(B, D, device=dev), torch.empty(B, D, dtype=torch.bfloat16, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.label_cond(labels, None, NC, table, temb, eff, c, sc, B, D, table_rows=NC + 1, err=err)
+    assert eff.tolist() == [0, 0, 0, 10] and int(err.item()) == 1
+    assert torch.equal(c[1], table[0]) and torch.equal(c[3], table[10])
+    err.zero_()
+    ops.label_cond(labels.clamp(0, 10), None, NC, table, temb, eff, c, sc, B, D, table_rows=NC + 1, err=err)
+    assert int(err.item()) == 0
+    m = build_hip_model(tiny_cfg(), dev, 3).eval()     # num_classes = 10 (+ null row)
+    x = torch.randn(2, 4, 8, 8, device=dev)
+    with torch.no_grad():
+        m(x, torch.full((2,), 0.5, device=dev), torch.tensor([3, 10], device=dev))
+    m.engine().check_errors()
+    with torch.no_grad():
+        m(x, torch.full((2,), 0.5, device=dev), torch.tensor([3, 11], device=dev))
+    with pytest.raises(IndexError):
+        m.engine().check_errors()
+    m.engine().check_errors()                           # the flag is cleared once reported
+    with pytest.raises(IndexError):                     # CFG's hard-coded null id 1000 on an 11-row table
+        samplers.euler_sampler(m, x, torch.tensor([1, 2], device=dev), num_steps=2, cfg_scale=1.5)
+    with pytest.raises(IndexError):
+        samplers.euler_sampler(m, x, torch.tensor([1, 12], device=dev), num_steps=2)
 
 
 def test_fused_optimizer_vs_reference_toy(dev):

@@ -30,6 +30,13 @@ def build_hip_model(cfg, dev, seed):
     return m.to(dev)
 
 
+# Per-tensor gradient bars against the SAME-PRECISION oracle (bf16 autocast on the CPU): (min cosine, max |norm ratio - 1|).
+# Set from the values the kernels deliver on MI355X (printed by the test); anything looser is listed with its reason.
+GRAD_BAR = (0.98, 0.08)
+GRAD_BAR_REF_COS = 0.98
+GRAD_BARS = {}
+
+
 def cos(a, b):
     return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
 
@@ -67,8 +74,9 @@ def test_tiny_vs_reference_and_oracle(dev, name):
     np.testing.assert_allclose(float(out["proj_loss"]), float(oo["proj_loss"]), rtol=2e-2, atol=2e-3)
     np.testing.assert_allclose(out["denoising_loss"].detach().cpu().numpy(), g[f"{name}.denoising_loss"], rtol=2e-2)
     np.testing.assert_allclose(float(total), float(g[f"{name}.total"]), rtol=2e-2)
-    # gradients: direction and size of every parameter's gradient vs the oracle
-    bad = []
+    # gradients: direction and size of every parameter's gradient vs the same-precision oracle, and the norm of every
+    # parameter's gradient vs the fp32 reference golden
+    bad, worst = [], [1.0, "", 0.0, "", 0.0, ""]
     for k, p in m.named_parameters():
         if not p.requires_grad:
             continue
@@ -77,15 +85,31 @@ def test_tiny_vs_reference_and_oracle(dev, name):
         if no < 5e-5:   # analytically zero gradients (e.g. k_norm.bias: softmax is invariant to a common key shift)
             assert nh < 5e-4, (k, nh, no)
             continue
-        cs = cos(gh, go)
-        if cs < 0.98 or abs(nh / no - 1) > 0.08:
-            bad.append((k, cs, nh, no))
+        cs, dn = cos(gh, go), abs(nh / no - 1)
+        dref = abs(nh / float(g[f"{name}.gnorm.{k}"]) - 1)
+        if cs < worst[0]:
+            worst[0:2] = [cs, k]
+        if dn > worst[2]:
+            worst[2:4] = [dn, k]
+        if dref > worst[4]:
+            worst[4:6] = [dref, k]
+        cmin, nmax = GRAD_BARS.get((name, k), GRAD_BARS.get(k.split(".")[-2] + "." + k.split(".")[-1], GRAD_BAR))
+        if cs < cmin or dn > nmax or dref > 3 * nmax:
+            bad.append((k, cs, dn, dref))
+    print(f"[{name}] worst cosine {worst[0]:.6f} ({worst[1]}), worst |norm ratio - 1| vs bf16 oracle {worst[2]:.5f} "
+          f"({worst[3]}), vs fp32 reference {worst[4]:.5f} ({worst[5]})")
     assert not bad, bad[:8]
-    # spot values vs the fp32 reference golden
-    for k in ("final_layer.linear.bias", "x_embedder.proj.bias", "projectors.0.4.bias"):
+    # element values vs the fp32 reference golden
+    worst_c = 1.0
+    for k in ("final_layer.linear.bias", "x_embedder.proj.bias", "projectors.0.4.bias", "final_layer.linear.weight",
+              "blocks.0.attn.qkv.bias", "x_embedder.proj.weight", "blocks.1.adaLN_modulation.1.bias",
+              "blocks.2.mlp.fc1.bias"):
         gh = dict(m.named_parameters())[k].grad.detach().cpu().numpy()
         ref = g[f"{name}.grad.{k}"]
-        assert cos(torch.from_numpy(gh), torch.from_numpy(ref)) > 0.98, k
+        cs = cos(torch.from_numpy(gh), torch.from_numpy(ref))
+        worst_c = min(worst_c, cs)
+        assert cs > GRAD_BAR_REF_COS, (k, cs)
+    print(f"[{name}] worst cosine vs fp32 reference elements {worst_c:.6f}")
     # eval-mode inference forward
     m.eval()
     m.force_drop_mask = None
@@ -112,7 +136,7 @@ def _hip_trainer(model_name, cfgkw, dev, enc, co, seed=0):
     return m, ema, opt, lf
 
 
-def _run_traj(m, opt, lf, dev, B, steps, zspec, align, proj_coeff=0.5):
+def _run_traj(m, opt, lf, dev, B, steps, zspec, align, proj_coeff=0.5, after_backward=None):
     rec = {"loss": [], "denoising_loss": [], "proj_loss": [], "grad_norm": []}
     for s in range(steps):
         x, noise, t, y, drop_u, zs = inputs(B, 4, 32, s, zspec, 256, 1000)
@@ -123,6 +147,8 @@ def _run_traj(m, opt, lf, dev, B, steps, zspec, align, proj_coeff=0.5):
         total = den + (proj * proj_coeff if align else 0.0)
         opt.zero_grad()
         total.backward()
+        if after_backward is not None:
+            after_backward(s)
         opt.step()
         rec["loss"].append(float(total)); rec["denoising_loss"].append(float(den))
         rec["proj_loss"].append(float(proj)); rec["grad_norm"].append(float(opt.grad_norm))
@@ -155,7 +181,17 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
     g = load("xl2_c2")
     kw = dict(z_dims=[1024], z_types=["i"], encoder_depth=8)
     m, ema, opt, lf = _hip_trainer("SiT-XL/2", kw, dev, ["dinov2"], [1.0])
-    rec = _run_traj(m, opt, lf, dev, 8, 5, [(1024, "i")], True)
+    probes = {}
+
+    def grab(step):   # step-1 gradients (unclipped: the clip coefficient is applied inside the fused update)
+        if step == 0:
+            torch.cuda.synchronize()
+            named = dict(m.named_parameters())
+            for k in [k[len("bf16.gnorm."):] for k in g.files if k.startswith("bf16.gnorm.")]:
+                f = named[k].grad.detach().flatten()
+                probes[k] = (f.double().norm().item(), f[:: max(1, f.numel() // 64)][:64].float().cpu().numpy())
+
+    rec = _run_traj(m, opt, lf, dev, 8, 5, [(1024, "i")], True, after_backward=grab)
     d_bf16 = np.abs(np.array(rec["loss"]) - g["bf16.loss"])
     d_fp32 = np.abs(np.array(rec["loss"]) - g["fp32.loss"])
     ref_gap = np.abs(g["bf16.loss"] - g["fp32.loss"])
@@ -167,6 +203,111 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
     assert (d_fp32 <= np.maximum(2e-3, 1.5 * ref_gap)).all(), (d_fp32, ref_gap)  # vs fp32: the reference's own bf16 gap
     np.testing.assert_allclose(rec["grad_norm"], g["bf16.grad_norm"], rtol=3e-2)
     np.testing.assert_allclose(rec["proj_loss"], g["bf16.proj_loss"], atol=2e-3)
+    # per-tensor gradients at XL/2 size, step 1, against the reference under bf16 autocast (and fp32): the norm of the
+    # whole tensor and 64 elements spread over it (tools/gen_golden.py:GRAD_PROBES_XL: qkv / proj / fc1 / fc2 of blocks
+    # 0, 8, 27, adaLN of blocks 8 and 27, projector layers, final layer, embedders)
+    assert len(probes) >= 20
+    rows = []
+    for k, (nh, sl) in probes.items():
+        nb, nf = float(g["bf16.gnorm." + k]), float(g["fp32.gnorm." + k])
+        rb, rf = g["bf16.gslice." + k], g["fp32.gslice." + k]
+        cb = cos(torch.from_numpy(sl), torch.from_numpy(rb))
+        cf = cos(torch.from_numpy(sl), torch.from_numpy(rf))
+        cref = cos(torch.from_numpy(rb), torch.from_numpy(rf))     # the reference's own bf16-vs-fp32 agreement
+        rows.append((k, nh / nb - 1, nh / nf - 1, nb / nf - 1, cb, cf, cref))
+    for r in rows:
+        print("  %-42s |g| vs bf16 %+.4f vs fp32 %+.4f (ref bf16 vs fp32 %+.4f)  slice cos vs bf16 %.5f vs fp32 %.5f (ref %.5f)" % r)
+    for k, dnb, dnf, dref, cb, cf, cref in rows:
+        assert abs(dnb) <= XL_GRAD_NORM_BAR + abs(dref), (k, dnb, dref)
+        assert cb >= min(XL_GRAD_COS_BAR, cref - (1 - XL_GRAD_COS_BAR)), (k, cb, cref)
+    # weights after the 5 AdamW steps (64 leading elements of three tensors) vs the reference's
+    sd = m.state_dict()
+    for k in ("blocks.0.attn.qkv.weight", "final_layer.linear.weight", "t_embedder.mlp.2.bias"):
+        w = sd[k].flatten()[:64].cpu().numpy()
+        # every step moves a weight by <= lr = 1e-4; a sign flip of a near-zero gradient element costs 2e-4 per step
+        np.testing.assert_allclose(w, g["bf16.w." + k], atol=3e-4)
+        frac_close = float(np.mean(np.abs(w - g["bf16.w." + k]) < 2e-5))
+        print(f"  weights after 5 steps {k}: {frac_close:.2f} of 64 elements within 2e-5 of the reference")
+        assert frac_close >= 0.7
+
+
+XL_GRAD_NORM_BAR = 0.05
+XL_GRAD_COS_BAR = 0.98
+
+
+def test_xl2_cfg_inference_vs_reference(dev):
+    """C5 at its real size: the CFG-doubled no-tap evaluation of SiT-XL/2 exactly as samplers.py:66-78 issues it
+    ([x; x], labels [y; 1000]) at two times, against the reference in fp32 and under bf16 autocast
+    (tools/gen_golden.py:g_xl_infer), plus 3 Heun steps with CFG 1.5 on top (5 evaluations, fp64 state)."""
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.samplers import euler_sampler
+    g = load("xl2_infer")
+    m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8, use_cfg=True)
+    detfill.fill_state_dict(m.state_dict(), base_seed=0)
+    m = m.to(dev).eval()
+    x, _, _, y, _, _ = inputs(2, 4, 32, 77, [], 256, 1000)
+    xx, yy = torch.cat([x, x]).to(dev), torch.cat([y, torch.tensor([1000, 1000])]).to(dev)
+    for tv in (0.9, 0.35):
+        with torch.no_grad():
+            o, z = m(xx, torch.full((4,), tv, device=dev), yy)
+        assert z is None
+        o = o.cpu()
+        rf, rb = torch.from_numpy(g[f"fp32.t{tv}"]), torch.from_numpy(g[f"bf16.t{tv}"])
+        sc = rf.abs().max().item()
+        e_b, e_f, e_ref = (o - rb).abs().max().item() / sc, (o - rf).abs().max().item() / sc, (rb - rf).abs().max().item() / sc
+        print(f"XL/2 CFG eval t={tv}: max|HIP-ref_bf16| {e_b:.2e}  max|HIP-ref_fp32| {e_f:.2e}  "
+              f"(reference's own bf16-vs-fp32 {e_ref:.2e}), all relative to max|v| = {sc:.3f}; "
+              f"cos vs fp32 {cos(o, rf):.6f}")
+        assert e_f <= 2.0 * e_ref + 1e-3 and cos(o, rf) > 0.9995
+    with torch.no_grad():
+        s = euler_sampler(m, x.to(dev), y.to(dev), num_steps=3, heun=True, cfg_scale=1.5).cpu()
+    ref = torch.from_numpy(g["heun3_cfg"])
+    err = (s - ref).abs().max().item()
+    print(f"XL/2 3-step Heun + CFG 1.5: max abs deviation from the fp32 reference {err:.3e} (latent scale {ref.abs().max().item():.2f})")
+    assert s.dtype == torch.float64 and err <= 2e-2 * ref.abs().max().item()
+
+
+def test_long_horizon_heun_cfg_drift_s2(dev):
+    """What the bf16 model costs over a long sampling horizon: SiT-S/2, n = 2, 50-step Heun with CFG 1.5 over the whole
+    interval (99 evaluations at batch 4), HIP (bf16 operands, fp64 state) against the reference with an fp32 model
+    (tools/gen_golden.py:g_samplers_long). The state fed to every 9th evaluation is compared: the printed curve is the
+    drift; the bound asserted is on its end point, relative to the latents' scale."""
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.samplers import euler_sampler
+    g = load("samplers_long")
+    m = SiT_models["SiT-S/2"](z_dims=[768], z_types=["i"], encoder_depth=8, use_cfg=True)
+    detfill.fill_state_dict(m.state_dict(), base_seed=3)
+    m = m.to(dev).eval()
+    z = detfill.normal((2, 4, 32, 32), 91).to(dev)
+    y = torch.tensor([17, 833], device=dev)
+    states = []
+
+    class Rec:
+        num_classes, class_dropout_prob = m.num_classes, m.class_dropout_prob
+
+        def engine(self):
+            return m.engine()
+
+        def __call__(self, xx, tt, **kw):
+            states.append(xx[:2].detach().cpu().clone())
+            return m(xx, tt, **kw)
+
+    with torch.no_grad():
+        out = euler_sampler(Rec(), z, y, num_steps=50, heun=True, cfg_scale=1.5).cpu()
+    assert len(states) == int(g["n_evals"]) == 99
+    ref_states = torch.from_numpy(g["states"])
+    curve = [(s - r).abs().max().item() for s, r in zip(states[::9], ref_states)]
+    ref = torch.from_numpy(g["final"])
+    scale = ref.abs().max().item()
+    end = (out - ref).abs().max().item()
+    print("drift of the bf16-operand sampler vs the fp32 reference, max abs, at evaluations 0, 9, ..., 90:",
+          " ".join(f"{c:.2e}" for c in curve), f"| final {end:.3e} (latent scale {scale:.2f}, rms "
+          f"{(out - ref).pow(2).mean().sqrt().item():.3e})")
+    assert curve[0] == 0.0
+    assert end <= LONG_DRIFT_BAR * scale
+
+
+LONG_DRIFT_BAR = 5e-2
 
 
 def test_wgrad_side_stream_bit_identical(dev):

@@ -122,7 +122,9 @@ def test_loss_units():
     g = load("loss_units")
     B = 6
     x, noise, t, y, _, zs = inputs(B, 4, 8, 21, [(32, "i"), (16, "t")], 16, 10)
-    zt = [detfill.normal((B, 16, 32), 901), detfill.normal((B, 16), 902)]
+    # the model's projector outputs are bf16 values (upcast by accelerate): keep the stand-in's bf16-representable, so the
+    # HIP SILoss (bf16 projector inputs, tests/test_kernels_gpu.py) sees exactly the values the reference saw
+    zt = [detfill.normal((B, 16, 32), 901).bfloat16().float(), detfill.normal((B, 16), 902).bfloat16().float()]
     vel = detfill.normal((B, 4, 8, 8), 903)
     for sched in ["constant", "linear", "cosine", "sigmoid", "loglinear", "cutoff"]:
         for path in ["linear", "cosine"]:

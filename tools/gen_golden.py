@@ -249,7 +249,9 @@ def g_loss_units(ref_sit, ref_loss, ref_samplers):
     """G-h: SILoss over time_schedule x path_type x weighting with a fixed stand-in model."""
     B = 6
     x, noise, t, y, _, zs = inputs(B, 4, 8, 21, [(32, "i"), (16, "t")], 16, 10)
-    zt = [detfill.normal((B, 16, 32), 901), detfill.normal((B, 16), 902)]
+    # the model's projector outputs are bf16 values (upcast by accelerate): keep the stand-in's bf16-representable, so the
+    # HIP SILoss (bf16 projector inputs, tests/test_kernels_gpu.py) sees exactly the values the reference saw
+    zt = [detfill.normal((B, 16, 32), 901).bfloat16().float(), detfill.normal((B, 16), 902).bfloat16().float()]
     vel = detfill.normal((B, 4, 8, 8), 903)
 
     def model(xx, tt, **k):
@@ -308,8 +310,20 @@ def g_samplers(ref_sit, ref_loss, ref_samplers):
     save("samplers", **out)
 
 
+GRAD_PROBES_XL = [f"blocks.{i}.{n}.weight" for i in (0, 8, 27) for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")] + [
+    "blocks.8.adaLN_modulation.1.weight", "blocks.27.adaLN_modulation.1.bias", "projectors.0.4.weight", "projectors.0.0.weight",
+    "final_layer.linear.weight", "final_layer.adaLN_modulation.1.weight", "x_embedder.proj.weight", "t_embedder.mlp.0.weight",
+    "y_embedder.embedding_table.weight", "blocks.13.attn.qkv.bias"]
+
+
+def grad_probe(g):
+    """(norm, 64 elements spread over the whole tensor) of one gradient — the per-tensor probes of the XL/2 goldens."""
+    f = g.detach().flatten()
+    return f.double().norm(), f[:: max(1, f.numel() // 64)][:64].clone()
+
+
 def ref_train_traj(ref_sit, ref_loss, model_name, kw, B, steps, zspec, enc_names, coeffs, autocast, proj_coeff=0.5,
-                   align=True, seed=0):
+                   align=True, seed=0, grad_probes=None):
     """Reference-equivalent optimisation steps (train.py:387-412): SILoss -> combine -> backward -> clip -> AdamW -> EMA."""
     m = build_ref_model(ref_sit, model_name, seed=seed, **kw)
     m.train()
@@ -336,6 +350,10 @@ def ref_train_traj(ref_sit, ref_loss, model_name, kw, B, steps, zspec, enc_names
         total = den * 1.0 + (proj * proj_coeff * 1.0 if align else 0.0)
         opt.zero_grad(set_to_none=True)
         total.backward()
+        if grad_probes is not None and s == 0:   # step-1 gradients, before clipping
+            named = dict(m.named_parameters())
+            for k in grad_probes[0]:
+                grad_probes[1]["gnorm." + k], grad_probes[1]["gslice." + k] = grad_probe(named[k].grad)
         gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
         opt.step()
         with torch.no_grad():
@@ -374,10 +392,53 @@ def g_xl(ref_sit, ref_loss, ref_samplers):
     out = {}
     for tag, ac in (("bf16", True), ("fp32", False)):
         print(f"  XL/2 {tag}")
-        rec, probe, _ = ref_train_traj(ref_sit, ref_loss, "SiT-XL/2", kw, 8, 5, [(1024, "i")], ["dinov2"], [1.0], ac)
+        gp = {}
+        rec, probe, _ = ref_train_traj(ref_sit, ref_loss, "SiT-XL/2", kw, 8, 5, [(1024, "i")], ["dinov2"], [1.0], ac,
+                                       grad_probes=(GRAD_PROBES_XL, gp))
         out.update({f"{tag}.{k}": np.array(v) for k, v in rec.items()})
         out.update({f"{tag}.w.{k}": v for k, v in probe.items()})
+        out.update({f"{tag}.{k}": v for k, v in gp.items()})
     save("xl2_c2", **out)
+
+
+def g_xl_infer(ref_sit, ref_loss, ref_samplers):
+    """C5 at its real size: one CFG-doubled evaluation of SiT-XL/2 in eval mode as samplers.py:66-78 issues it
+    ([x; x], labels [y; 1000]), n = 2, fp32 and bf16-autocast; plus 3 Heun steps with CFG 1.5 on the fp32 model
+    (5 evaluations at batch 4, fp64 state)."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[1024], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False,
+              use_cfg=True)
+    m = build_ref_model(ref_sit, "SiT-XL/2", seed=0, **kw).eval()
+    x, _, _, y, _, _ = inputs(2, 4, 32, 77, [], 256, 1000)
+    xx, yy = torch.cat([x, x]), torch.cat([y, torch.tensor([1000, 1000])])
+    out = {}
+    with torch.no_grad():
+        for tv in (0.9, 0.35):
+            tt = torch.full((4,), tv)
+            out[f"fp32.t{tv}"] = m(xx, tt, yy)[0]
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out[f"bf16.t{tv}"] = m(xx, tt, yy)[0].float()
+        out["heun3_cfg"] = ref_samplers.euler_sampler(m, x, y, num_steps=3, heun=True, cfg_scale=1.5)
+    save("xl2_infer", **out)
+
+
+def g_samplers_long(ref_sit, ref_loss, ref_samplers):
+    """Long-horizon drift pin: SiT-S/2 (fp32 reference model), n = 2, 50-step Heun with CFG 1.5 over the whole interval
+    (99 evaluations at batch 4). The state fed to every 9th evaluation and the final latents are recorded."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[768], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False,
+              use_cfg=True)
+    m = build_ref_model(ref_sit, "SiT-S/2", seed=3, **kw).eval()
+    z = detfill.normal((2, 4, 32, 32), 91)
+    y = torch.tensor([17, 833])
+    states = []
+
+    def model(xx, tt, **kw):
+        states.append(xx[:2].detach().clone())
+        return m(xx, tt, **kw)
+
+    out = {"final": ref_samplers.euler_sampler(model, z, y, num_steps=50, heun=True, cfg_scale=1.5)}
+    out["n_evals"] = np.array(len(states))
+    out["states"] = torch.stack(states[::9])
+    save("samplers_long", **out)
 
 
 def g_xl_c4(ref_sit, ref_loss, ref_samplers):
@@ -503,7 +564,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "clip": g_clip, "dataset": g_dataset}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "clip": g_clip, "dataset": g_dataset}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
