@@ -18,6 +18,8 @@
 // 32 key rows (dK, dV); Q, K, V, dO stay resident in LDS (147 KiB) for both.
 #include <stdlib.h>
 
+#include <utility>
+
 #include "../../include/reed_hip.h"
 #include "common.hpp"
 
@@ -185,9 +187,11 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward for any T (512^2 sampling: T = 1024; the CLIP tower: T = 257): 256-key tiles with online softmax, one
+// workgroup per (batch, head, 256-query block), register-staged tile loads.  T <= 256 runs attn_fwd256_kernel below.
 template <int HD>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                       float* __restrict__ lse, int B, int T, int H, int dbg) {
+                                                       float* __restrict__ lse, int B, int T, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -215,10 +219,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
   for (int kv0 = 0; kv0 < T; kv0 += 256) {
     __syncthreads();
     const int rows = min(256, T - kv0);
-    if (dbg != 2) {
     load_tile<HD, ROWF>(Kt, base + (long)kv0 * tok + D, tok, rows, tid, 512);
     load_tile<HD, ROWF>(Vt, base + (long)kv0 * tok + 2 * D, tok, rows, tid, 512);
-    }
     if (kv0 == 0) {  // Q fragments after the first tile loads: keeps the staging registers and Q from overlapping
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
     }
     __syncthreads();
     if (!active) continue;
-    const int nsub = dbg == 1 ? 0 : (rows + 63) >> 6;
+    const int nsub = (rows + 63) >> 6;
     for (int sub = 0; sub < nsub; ++sub) {
       const int kvs = sub * 64;
       f32x4 st[2][4];
@@ -333,10 +335,322 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// LDS-DMA tile staging (buffer_load_dwordx4 ... lds): a [256][RB / 16]-chunk tile image is 256 * RB / 1024 wave
+// instructions of 1 KiB; lane L of instruction I carries chunk c = 64 I + L = (row c / CPR, chunk c % CPR) from its own
+// source address to the lane-linear LDS address tile + 16 c.  Chunks behind the head's columns (the pad of a padded row
+// format) and rows >= rows_valid carry an offset outside the descriptor: the hardware range check writes zeros for them,
+// so the tiles need no zero-fill code and ragged T needs no masks on the load side.
+typedef void __attribute__((address_space(3))) * lds_ptr_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int DMA_OOB = 0x7FFFFFF0;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, long bytes) {
+  if (!base || bytes < 0) bytes = 0;
+  if (bytes > 0x7FFF0000l) bytes = 0x7FFF0000l;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (unsigned)bytes, 0x00020000);
+}
+template <int HD, int RB>
+__device__ __forceinline__ int dma_voff(int c, int stride_bytes) {
+  constexpr int CPR = RB / 16;
+  const int row = c / CPR, col = c - row * CPR;
+  return col < HD / 8 ? row * stride_bytes + col * 16 : DMA_OOB;
+}
+// bytes of a tile's source window: rows_valid rows of HD elements at stride_bytes
+template <int HD>
+__device__ __forceinline__ long tile_window(int rows_valid, int stride_bytes) {
+  return rows_valid > 0 ? (long)(rows_valid - 1) * stride_bytes + HD * 2 : 0;
+}
+// raw barrier: no compiler-inserted vmcnt(0) (the LDS-DMA of the next tiles stays in flight across it)
+#define ATTN_BARRIER()                                     \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    __builtin_amdgcn_s_barrier();                          \
+    asm volatile("" ::: "memory");                         \
+  } while (0)
+#define ATTN_LDS_WAIT()                                    \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+// ds_read_b64_tr_b16 through inline asm: with the builtin the compiler drains every pending LDS-DMA (s_waitcnt vmcnt(0))
+// before the read (GEMM); the caller orders it (ATTN_LDS_WAIT before the first consumer).  ONE per-lane base
+// address (tile + (4 g + q) RB + 8 p) and compile-time offsets in the DS immediate field: in a fully unrolled loop
+// per-read address registers are loop invariants that get hoisted and spilled
+template <int OFF>
+__device__ __forceinline__ bf16x4 tr16_asm_off(const char* p) {
+  bf16x4 r;
+  const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF));
+  return r;
+}
+template <int RB, int OFF>
+__device__ __forceinline__ bf16x8 frag_trT_off(const char* lane_base) {
+  bf16x4 lo = tr16_asm_off<OFF>(lane_base);
+  bf16x4 hi = tr16_asm_off<OFF + 16 * RB>(lane_base);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// O^T += V^T P^T over 32-key steps, software pipelined: the V^T fragments of step S + 1 are read (asm, unordered by the
+// compiler) before the MFMAs of step S issue, and waited for behind them
+template <int RB, int S, int NDT, int... DTS>
+__device__ __forceinline__ void pv_load(const char* vb, bf16x8 (&vf)[NDT], std::integer_sequence<int, DTS...>) {
+  ((vf[DTS] = frag_trT_off<RB, S * 32 * RB + DTS * 32>(vb)), ...);
+}
+template <int RB, int S, int NDT, int... DTS>
+__device__ __forceinline__ void pv_step(const char* vb, int ns, const bf16x8 (&pb)[2][8], f32x4 (&ot)[2][NDT],
+                                        bf16x8 (&cur)[NDT], bf16x8 (&nxt)[NDT], std::integer_sequence<int, DTS...> seq) {
+  if (S < ns) {
+    if constexpr (S + 1 < 8) {
+      if (S + 1 < ns) pv_load<RB, S + 1, NDT>(vb, nxt, seq);
+    }
+    ((ot[0][DTS] = MFMA(cur[DTS], pb[0][S], ot[0][DTS]), ot[1][DTS] = MFMA(cur[DTS], pb[1][S], ot[1][DTS])), ...);
+    ATTN_LDS_WAIT();
+  }
+}
+template <int RB, int NDT>
+__device__ __forceinline__ void pv_all(const char* vb, int ns, const bf16x8 (&pb)[2][8], f32x4 (&ot)[2][NDT]) {
+  constexpr auto seq = std::make_integer_sequence<int, NDT>{};
+  bf16x8 va[NDT], vb2[NDT];
+  pv_load<RB, 0, NDT>(vb, va, seq);
+  ATTN_LDS_WAIT();
+  pv_step<RB, 0, NDT>(vb, ns, pb, ot, va, vb2, seq);
+  pv_step<RB, 1, NDT>(vb, ns, pb, ot, vb2, va, seq);
+  pv_step<RB, 2, NDT>(vb, ns, pb, ot, va, vb2, seq);
+  pv_step<RB, 3, NDT>(vb, ns, pb, ot, vb2, va, seq);
+  pv_step<RB, 4, NDT>(vb, ns, pb, ot, va, vb2, seq);
+  pv_step<RB, 5, NDT>(vb, ns, pb, ot, vb2, va, seq);
+  pv_step<RB, 6, NDT>(vb, ns, pb, ot, va, vb2, seq);
+  pv_step<RB, 7, NDT>(vb, ns, pb, ot, vb2, va, seq);
+}
+__device__ __forceinline__ bf16x8 zero_frag() {
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+  return z;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward for T <= 256 (training and 256^2 sampling: the whole sequence is ONE key tile).
+//
+// The one-shot kernel below (attn_fwd_kernel: load K, V, Q -> compute -> store, two workgroups per CU) spent 182 of its
+// 249 us at b = 256 in loads and stores that nothing overlapped, and its online softmax carried a rescale of O per
+// 64-key block.  This kernel is persistent — one 8-wave workgroup per CU walks (batch, head) items — and splits an item
+// in three phases whose LDS buffers are refilled by LDS-DMA while the other phases run:
+//   S  = K Q^T for all 256 keys into registers (st[2][16]: a wave's 32 queries x 256 keys = 128 VGPRs; two waves per
+//        SIMD own 256 VGPRs each)                                        reads K, Q   -> then K(n+1), Q(n+1) are issued
+//   softmax, exact and single pass (row maximum over the registers, no running rescale)   registers only
+//   O^T = V^T P^T                                                         reads V     -> then V(n+1) is issued
+// so the K / Q stream of the next item flies under softmax + PV + the output stores and the V stream under the next S
+// phase.  Every vector-memory instruction a wave issues per item is counted (5 LDS-DMA per tile, 5 + 2 buffer stores),
+// and the two waits are counted s_waitcnt vmcnt(N) behind raw barriers: nothing drains the queue.
+// LDS: K | V | Q tiles of 160-byte rows + a 32-row output staging patch per wave = 4 x 40 KiB = all 160 KiB.
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                            float* __restrict__ lse, int T, int H, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const long tok = 3l * D;
+  const int tokb = (int)(tok * 2);
+  char* Kt = smem;
+  char* Vt = smem + TILE_F;
+  char* Qt = smem + 2 * TILE_F;
+  char* Ot = smem + 3 * TILE_F + wave * 32 * ROWF;
+  const int q0 = wave * 32;
+  const float sc2 = rsqrtf((float)HD) * LOG2E;
+  int voff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) voff[j] = dma_voff<HD, ROWF>((wave * 5 + j) * 64 + lane0, tokb);
+  const long win = tile_window<HD>(T, tokb);
+  auto issue = [&](char* tile, const bf16* base) {
+    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(base, win);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + (wave * 5 + j) * 1024), 16, voff[j], 0, 0, 0);
+  };
+  auto base_of = [&](int item) {
+    const int b = item / H, h = item - b * H;
+    return qkv + (long)b * T * tok + h * HD;
+  };
+  int it = xcd_contiguous(blockIdx.x, gridDim.x);   // the 16 heads of a sample run on one XCD at about the same time
+  {
+    const bf16* bs = base_of(it);
+    issue(Kt, bs + D);
+    issue(Qt, bs);
+    issue(Vt, bs + 2 * D);
+  }
+  bool first = true;
+  const int nsub = (T + 63) >> 6, ns = (T + 31) >> 5;
+  for (; it < nitems; it += gridDim.x) {
+    const int b = it / H, h = it - b * H;
+    const int nxt = it + gridDim.x;
+    // lane-derived values (fragment bases, store offsets) are re-derived per item from an opaque copy of the lane id:
+    // hoisted out of the item loop they are spilled around it, and a spill reload brings a compiler vmcnt(0) that
+    // drains the LDS-DMA queue in the middle of an item
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+    // K(n), Q(n) landed: younger in this wave's queue are V(n) [5] and, after the first item, the 7 stores of item n-1
+    if (first) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    ATTN_BARRIER();
+    // ---------------- S^T = K Q^T ----------------
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (HD % 32 != 0 && ks == KS - 1) {   // columns 64..95 of a 72-wide head: 64..79 exist (72..79 = zero pad)
+          qf[qt][ks] = frag_rows_f<true>(Qt, q0 + 16 * qt, ks, lane);
+          if (g >= 2) qf[qt][ks] = zero_frag();
+        } else {
+          qf[qt][ks] = frag_rows_f<false>(Qt, q0 + 16 * qt, ks, lane);
+        }
+      }
+    f32x4 st[2][16];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) st[qt][kt] = zero4();
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < nsub) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const int kt = sub * 4 + k4;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 kf = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Kt, 16 * kt, ks, lane)
+                                                       : frag_rows_f<false>(Kt, 16 * kt, ks, lane);
+            st[0][kt] = MFMA(kf, qf[0][ks], st[0][kt]);
+            st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // V(n) landed (younger: the stores of item n-1); every wave is past its K and Q reads
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    ATTN_BARRIER();
+    if (nxt < nitems) {
+      const bf16* bs = base_of(nxt);
+      issue(Kt, bs + D);
+      issue(Qt, bs);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the DMA issue stays in front of the softmax (the scheduler sinks it otherwise)
+    // ---------------- softmax over the 256 keys, in registers ----------------
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (64 * sub + 64 > T) {   // keys past T: a ragged or absent sub-block (wave-uniform)
+        int gg = g;
+        asm volatile("" : "+v"(gg));   // per-item value: keeps the 64 lane masks from being hoisted out of the item loop
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (64 * sub + 16 * k4 + 4 * gg + r >= T) st[qt][sub * 4 + k4][r] = -INFINITY;
+      }
+    }
+    float mrow[2], lrow[2];
+    bf16x8 pb[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mneg = mx * sc2;   // the scale is positive: max of the scaled scores
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sc2, -mneg));
+          st[qt][kt][r] = p;
+          sum += p;
+        }
+        if (kt & 1) pb[qt][kt >> 1] = pack2(st[qt][kt - 1], st[qt][kt]);
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      mrow[qt] = mneg;
+      lrow[qt] = sum;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- O^T = V^T P^T ----------------
+    f32x4 ot[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) ot[qt][dt] = zero4();
+    {
+      const char* vb = Vt + (4 * g + (i >> 2)) * ROWF + (i & 3) * 8;
+      pv_all<ROWF, DT>(vb, ns, pb, ot);
+    }
+    ATTN_BARRIER();   // every wave is past its V reads
+    if (nxt < nitems) issue(Vt, base_of(nxt) + 2 * D);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- output: staged in this wave's patch, whole 144-byte row pieces out ----------------
+    float lsev[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float inv = 1.f / lrow[qt];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        if (d < HD) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(ot[qt][dt][r] * inv);
+          *(bf16x4*)(Ot + (16 * qt + i) * ROWF + d * 2) = v;
+        }
+      }
+      lsev[qt] = mrow[qt] * LN2 + __logf(lrow[qt]);
+    }
+    {
+      // exactly 5 + 2 buffer stores per wave and item (counted by the waits above); rows >= T and the lanes past the
+      // 32 x NCH chunks fall outside the descriptors and are dropped by the range check
+      const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(o + (long)b * T * D + h * HD, tile_window<HD>(T, D * 2));
+      const __amdgpu_buffer_rsrc_t rsL = mk_rsrc(lse ? lse + ((long)b * H + h) * T : nullptr, (long)T * 4);
+      constexpr int NQ = 32 * NCH;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int qi = lane + 64 * k;
+        int rr = qi / NCH;
+        const int c = qi - rr * NCH;
+        const bool ok = qi < NQ;
+        rr = ok ? rr : 0;
+        const u32x4 v = *(const u32x4*)(Ot + rr * ROWF + c * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsO, ok ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
+                                              g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
+    }
+    first = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward, T <= 256: one workgroup per (batch, head), Q, K, V, dO resident (4 x 36 KiB), every operand read from HBM once.
+// Two forms that give up the single read were built in round 2, passed the tests and lost (attention):
+// four 80-KiB workgroups per item with 16-row waves, two per CU (dQ / dK,dV roles; each role re-reads all operands:
+// 2.7 GB per launch against 1.2 GB, 600 us), and this kernel with 16 waves of 16 rows at 128 VGPRs (every fragment read
+// feeds one MFMA instead of two: LDS traffic doubles, 630 us).  This form: 575 us at b = 256.
 template <int HD>
 __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                        const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                       bf16* __restrict__ dqkv, int B, int T, int H, int dbg) {
+                                                       bf16* __restrict__ dqkv, int B, int T, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -368,12 +682,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     const int rcl = min(row, T - 1);
     bf16x8 ov[NH], gv[NH];
     float lsev = 0.f;
-    if (dbg != 2) {
-      tile_issue<HD>(rq, base, tok, T, tid);
-      tile_issue<HD>(rk, base + D, tok, T, tid);
-      tile_issue<HD>(rv, base + 2 * D, tok, T, tid);
-      tile_issue<HD>(rg, d_o + (long)b * T * D + h * HD, D, T, tid);
-    }
+    tile_issue<HD>(rq, base, tok, T, tid);
+    tile_issue<HD>(rk, base + D, tok, T, tid);
+    tile_issue<HD>(rv, base + 2 * D, tok, T, tid);
+    tile_issue<HD>(rg, d_o + (long)b * T * D + h * HD, D, T, tid);
     {
       const bf16* orow = o + ((long)b * T + rcl) * D + h * HD;
       const bf16* grow = d_o + ((long)b * T + rcl) * D + h * HD;
@@ -386,12 +698,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
       }
       lsev = lse[((long)b * H + h) * T + rcl];
     }
-    if (dbg != 2) {
-      tile_commit<HD>(Qt, rq, T, tid);
-      tile_commit<HD>(Kt, rk, T, tid);
-      tile_commit<HD>(Vt, rv, T, tid);
-      tile_commit<HD>(Gt, rg, T, tid);
-    }
+    tile_commit<HD>(Qt, rq, T, tid);
+    tile_commit<HD>(Kt, rk, T, tid);
+    tile_commit<HD>(Vt, rv, T, tid);
+    tile_commit<HD>(Gt, rg, T, tid);
     // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per row (chunks half, half + 2, ... in the same order as before)
     float acc = 0.f;
 #pragma unroll
@@ -442,7 +752,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = zero4();
-    const int nblk = dbg == 1 ? 0 : (T + 31) >> 5;
+    const int nblk = (T + 31) >> 5;
     for (int kb = 0; kb < nblk; ++kb) {
       const int kv0 = kb * 32;
       f32x4 st[2][2], dp[2][2];
@@ -522,7 +832,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
-    const int nblk = dbg == 1 ? 0 : (T + 31) >> 5;
+    const int nblk = (T + 31) >> 5;
     for (int qb = 0; qb < nblk; ++qb) {
       const int qq0 = qb * 32;
       f32x4 st[2][2], dp[2][2];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
@@ -589,11 +899,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   }
 }
 
-// timing experiments only (tools/time_attn.py): REED_ATTN_DBG=1 skips the MFMA/softmax loops, =2 skips the global->LDS
-// tile loads; results are garbage in both.  Unset (0) in every product run.
-int attn_dbg() {
+int attn_fwd_oneshot() {   // REED_ATTN_FWD=oneshot: the round-1 forward also for T <= 256 (A/B)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("REED_ATTN_DBG"); v = e ? atoi(e) : 0; }
+  if (v < 0) { const char* e = getenv("REED_ATTN_FWD"); v = (e && e[0] == 'o') ? 1 : 0; }
   return v;
 }
 
@@ -604,6 +912,17 @@ int set_lds(K kernel, int bytes) {
   return 0;
 }
 
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 }  // namespace
 
 extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int hd,
@@ -611,18 +930,35 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
   REED_CHECK_ARG(qkv && o, "attention_fwd: null pointer");
   REED_CHECK_ARG(hd == 64 || hd == 72, "attention: head_dim %d unsupported (64 or 72)", hd);
   REED_CHECK_ARG(B > 0 && T > 0 && H > 0, "attention: bad dims B=%d T=%d H=%d", B, T, H);
+  if (T <= 256 && !attn_fwd_oneshot()) {
+    const int lds = 4 * TILE_F, nitems = B * H;
+    int ncu = num_cus();
+    ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
+    const dim3 grid(nitems < ncu ? nitems : ncu);
+    if (hd == 64) {
+      static int once = set_lds(attn_fwd256_kernel<64>, lds);
+      if (once) return once;
+      REED_KLAUNCH(attn_fwd256_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T, H,
+                   nitems);
+    } else {
+      static int once = set_lds(attn_fwd256_kernel<72>, lds);
+      if (once) return once;
+      REED_KLAUNCH(attn_fwd256_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T, H,
+                   nitems);
+    }
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
   const int lds = 2 * TILE_F;
   dim3 grid(B * H, (T + 255) / 256);
   if (hd == 64) {
     static int once = set_lds(attn_fwd_kernel<64>, lds);
     if (once) return once;
-    REED_KLAUNCH(attn_fwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (bf16*)o, lse, B, T, H, attn_dbg());
+    REED_KLAUNCH(attn_fwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, B, T, H);
   } else {
     static int once = set_lds(attn_fwd_kernel<72>, lds);
     if (once) return once;
-    REED_KLAUNCH(attn_fwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (bf16*)o, lse, B, T, H, attn_dbg());
+    REED_KLAUNCH(attn_fwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, B, T, H);
   }
   REED_LAUNCH_CHECK();
   return REED_OK;
@@ -638,13 +974,13 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
   if (hd == 64) {
     static int once = set_lds(attn_bwd_kernel<64>, lds);
     if (once) return once;
-    REED_KLAUNCH(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H, attn_dbg());
+    REED_KLAUNCH(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+                 (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   } else {
     static int once = set_lds(attn_bwd_kernel<72>, lds);
     if (once) return once;
-    REED_KLAUNCH(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
-                       (const bf16*)o, (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H, attn_dbg());
+    REED_KLAUNCH(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+                 (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   }
   REED_LAUNCH_CHECK();
   return REED_OK;

@@ -32,9 +32,11 @@ def build_hip_model(cfg, dev, seed):
 
 # Per-tensor gradient bars against the SAME-PRECISION oracle (bf16 autocast on the CPU): (min cosine, max |norm ratio - 1|).
 # Set from the values the kernels deliver on MI355X (printed by the test); anything looser is listed with its reason.
-GRAD_BAR = (0.98, 0.08)
-GRAD_BAR_REF_COS = 0.98
-GRAD_BARS = {}
+# Measured (round 2, every TINY case): worst cosine 0.99998, worst |norm ratio - 1| 0.0016 vs the bf16 oracle and 0.0059 vs
+# the fp32 reference (q_norm / k_norm affine and qkv biases: small tensors summed over every token in bf16).
+GRAD_BAR = (0.9999, 0.004)        # also bounds the fp32-reference norm ratio at 3 x 0.004
+GRAD_BAR_REF_COS = 0.9999         # element-wise cosine against the fp32 reference's gradient tensors (measured >= 0.99996)
+GRAD_BARS = {}                    # no exceptions needed
 
 
 def cos(a, b):
@@ -211,9 +213,13 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
     for k, (nh, sl) in probes.items():
         nb, nf = float(g["bf16.gnorm." + k]), float(g["fp32.gnorm." + k])
         rb, rf = g["bf16.gslice." + k], g["fp32.gslice." + k]
-        cb = cos(torch.from_numpy(sl), torch.from_numpy(rb))
-        cf = cos(torch.from_numpy(sl), torch.from_numpy(rf))
-        cref = cos(torch.from_numpy(rb), torch.from_numpy(rf))     # the reference's own bf16-vs-fp32 agreement
+        if not np.any(rb):     # label table: the 64 sampled elements lie in rows no label of the batch selects (exact zeros)
+            assert not np.any(sl), k
+            cb = cf = cref = 1.0
+        else:
+            cb = cos(torch.from_numpy(sl), torch.from_numpy(rb))
+            cf = cos(torch.from_numpy(sl), torch.from_numpy(rf))
+            cref = cos(torch.from_numpy(rb), torch.from_numpy(rf))     # the reference's own bf16-vs-fp32 agreement
         rows.append((k, nh / nb - 1, nh / nf - 1, nb / nf - 1, cb, cf, cref))
     for r in rows:
         print("  %-42s |g| vs bf16 %+.4f vs fp32 %+.4f (ref bf16 vs fp32 %+.4f)  slice cos vs bf16 %.5f vs fp32 %.5f (ref %.5f)" % r)
@@ -231,8 +237,9 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
         assert frac_close >= 0.7
 
 
-XL_GRAD_NORM_BAR = 0.05
-XL_GRAD_COS_BAR = 0.98
+# measured (round 2): every probe's norm within 1e-4 of the reference's bf16-autocast gradient, slice cosines >= 0.99998
+XL_GRAD_NORM_BAR = 0.002
+XL_GRAD_COS_BAR = 0.9999
 
 
 def test_xl2_cfg_inference_vs_reference(dev):
@@ -258,13 +265,13 @@ def test_xl2_cfg_inference_vs_reference(dev):
         print(f"XL/2 CFG eval t={tv}: max|HIP-ref_bf16| {e_b:.2e}  max|HIP-ref_fp32| {e_f:.2e}  "
               f"(reference's own bf16-vs-fp32 {e_ref:.2e}), all relative to max|v| = {sc:.3f}; "
               f"cos vs fp32 {cos(o, rf):.6f}")
-        assert e_f <= 2.0 * e_ref + 1e-3 and cos(o, rf) > 0.9995
+        assert e_f <= 1.3 * e_ref + 5e-4 and e_b <= e_ref and cos(o, rf) > 0.9999
     with torch.no_grad():
         s = euler_sampler(m, x.to(dev), y.to(dev), num_steps=3, heun=True, cfg_scale=1.5).cpu()
     ref = torch.from_numpy(g["heun3_cfg"])
     err = (s - ref).abs().max().item()
     print(f"XL/2 3-step Heun + CFG 1.5: max abs deviation from the fp32 reference {err:.3e} (latent scale {ref.abs().max().item():.2f})")
-    assert s.dtype == torch.float64 and err <= 2e-2 * ref.abs().max().item()
+    assert s.dtype == torch.float64 and err <= 4e-3 * ref.abs().max().item()     # measured 2.0e-3 of the scale
 
 
 def test_long_horizon_heun_cfg_drift_s2(dev):
@@ -307,7 +314,10 @@ def test_long_horizon_heun_cfg_drift_s2(dev):
     assert end <= LONG_DRIFT_BAR * scale
 
 
-LONG_DRIFT_BAR = 5e-2
+# measured (round 2): the drift grows linearly in t to 5.8e-3 abs = 1.4e-3 of the latents' scale (rms 3.7e-4 of it) at the
+# end of the trajectory; it is the integral of the bf16 evaluation error over the unit time interval, so a 250-step run
+# ends in the same place (sampling precision)
+LONG_DRIFT_BAR = 3e-3
 
 
 def test_wgrad_side_stream_bit_identical(dev):
