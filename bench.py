@@ -63,10 +63,17 @@ def random_fill(model, seed):
     A.shadow_version = -1
 
 
-TRAFFIC_B256 = 2.32e9   # bytes per launch of the dominant kernel, rocprofv3 --pmc (profiles/r1_pmc_gemm.txt, last section)
-TRAFFIC_NOTE = ("gemm256_kernel<NN, bf16> (the dgrads of fc1 / qkv / proj: 15.9 % of the step), fc1 dgrad launch: algorithmic "
-                "0.77 GB (da1 0.60 + W 0.01 + dx 0.15), measured 2.17 GB L2-miss reads (FETCH_SIZE x2, counts Infinity-Cache "
-                "hits: each 256-row slice of da1 is fetched by every XCD that holds one of its 5 column tiles) + 0.151 GB writes")
+# HBM-side bytes per launch of the dominant kernel's largest shape (fc1 dgrad, b = 256): NOT measured by this run — bench.py
+# cannot read PMC counters. The number is the committed rocprofv3 --pmc pass named in TRAFFIC_SOURCE (separate FETCH_SIZE /
+# WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), of the same kernel build.
+TRAFFIC_B256 = None
+TRAFFIC_SOURCE = None
+try:
+    with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as _f:
+        _t = json.load(_f)
+        TRAFFIC_B256, TRAFFIC_SOURCE = _t["fc1_dgrad_b256_bytes_per_launch"], _t["source"]
+except Exception:
+    pass
 
 
 def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
@@ -128,34 +135,44 @@ def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
 
 
 def cpu_baseline():
-    """The oracle (CPU restatement of the reference step, fp32, torch CPU ops) on this box's host cores:
-    SiT-XL/2 + 1024-d projector, B=8, 1 warm-up at B=2 then one timed step."""
+    """The oracle (CPU restatement of the reference step, fp32, torch CPU ops) on this box's host cores, BASELINE.md §4
+    protocol: SiT-XL/2 + 1024-d projector at B = 8 and SiT-S/2 + 768-d projector at B = 64; one warm-up step, then the
+    median of 3 timed steps; all host threads torch gives the process."""
     from oracle import sit as osit
     from oracle import train_step as otrain
     threads = torch.get_num_threads()
-    cfg = osit.make_config("SiT-XL/2", z_dims=[1024], z_types=["i"])
     g = torch.Generator().manual_seed(0)
-    P = osit.init_params(cfg)
-    for k, v in P.items():
-        if k == "pos_embed":
-            continue
-        fan = v[0].numel() if v.ndim > 1 else 1
-        v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * (0.5 * (3.0 / max(fan, 1)) ** 0.5 if v.ndim > 1 else 0.02))
-    tr = otrain.Trainer(P, cfg, ["dinov2"], [1.0], diffusion_warm_up_steps=0)
 
-    def batch(B):
-        return (torch.randn(B, 4, 32, 32, generator=g), torch.randint(0, 1000, (B,), generator=g),
-                [torch.randn(B, 256, 1024, generator=g)])
-    x, y, zs = batch(2)
-    tr.step(x, y, zs)
-    B = 8
-    x, y, zs = batch(B)
-    t0 = time.time()
-    tr.step(x, y, zs)
-    dt = time.time() - t0
-    return {"value": round(B / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle (CPU restatement of image/train.py step) SiT-XL/2 + 1024-d projector, fp32, B={B}, "
-                      f"1 step after a B=2 warm-up, {dt:.1f}s"}
+    def run(model, z, B, nrep):
+        cfg = osit.make_config(model, z_dims=[z], z_types=["i"])
+        P = osit.init_params(cfg)
+        for k, v in P.items():
+            if k == "pos_embed":
+                continue
+            fan = v[0].numel() if v.ndim > 1 else 1
+            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * (0.5 * (3.0 / max(fan, 1)) ** 0.5 if v.ndim > 1 else 0.02))
+        tr = otrain.Trainer(P, cfg, ["dinov2"], [1.0], diffusion_warm_up_steps=0)
+
+        def batch(n):
+            return (torch.randn(n, 4, 32, 32, generator=g), torch.randint(0, 1000, (n,), generator=g),
+                    [torch.randn(n, 256, z, generator=g)])
+        tr.step(*batch(2))                      # warm-up (allocator, thread pool)
+        ts = []
+        for _ in range(nrep):
+            x, y, zs = batch(B)
+            t0 = time.time()
+            tr.step(x, y, zs)
+            ts.append(time.time() - t0)
+        ts.sort()
+        return B / ts[len(ts) // 2], ts
+
+    ips_xl, ts_xl = run("SiT-XL/2", 1024, 8, 3)
+    ips_s, ts_s = run("SiT-S/2", 768, 64, 3)
+    return {"value": round(ips_xl, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle (CPU restatement of image/train.py step, fp32): SiT-XL/2 + 1024-d projector, B=8, median of 3 "
+                      f"steps after a B=2 warm-up ({', '.join(f'{t:.1f}' for t in ts_xl)} s); SiT-S/2 + 768-d projector, "
+                      f"B=64: {ips_s:.2f} images/sec ({', '.join(f'{t:.1f}' for t in ts_s)} s)",
+            "s2_b64_images_per_sec": round(ips_s, 3)}
 
 
 def dp_consistency(reducer, opt, model, world, b):
@@ -236,25 +253,76 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from reed_amd import ops
+    T_TOK = 256
+
+    def probe(layout, epi, M, N, K):
+        # the kernel with the largest share of the step (rocprofv3 --stats): the NN GEMM with the plain bf16 epilogue =
+        # the blocks' dgrads of fc1 / qkv / proj on the weight shadow (N = output width D, K = contraction)
+        if layout == ops.NN and epi == ops.EPI_BF16 and M == b * T_TOK and N == 1152 and K in (1152, 3456, 4608):
+            return K
+        return None
+
     for _ in range(args.warmup):
         res = step(None, labels, zs, moments=moments)
     barrier()
+    if rank == 0 and not args.no_kernel_table:
+        ops.gemm_probe = probe      # event pairs on the launch stream around every launch of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(None, labels, zs, moments=moments)
     t_enq = time.perf_counter() - t0    # host time to enqueue the K steps (the GPU runs behind; no sync inside a step)
     barrier()
     dt = time.perf_counter() - t0
+    ops.gemm_probe = None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(res["loss"])
-    dp = None
-    try:
-        dp = dp_consistency(reducer, opt, model, world, b) if reducer is not None else None
-    except Exception as e:   # a reported check, never a reason to lose the throughput line
-        dp = {"error": repr(e)}
+    model.engine().check_errors()
+    dom = {}
+    for key, e0, e1 in ops.gemm_probe_log:
+        dom.setdefault(key, []).append(e0.elapsed_time(e1))
+    ops.gemm_probe_log.clear()
+
+    # ---- data-parallel diagnosis (after the timed region): bucket plan, bytes, and with a reducer two extra steps with an
+    # event pair around every bucket reduction (comm stream) and around reducer.sync() (compute stream: what the step waits)
+    L = model._layout
+    bk = L.buckets()
+    dp = {"world": world, "buckets": len(bk), "gradient_bytes": int(4 * L.n_train),
+          "largest_bucket_bytes": int(4 * max(e - b0 for _, (b0, e) in bk)),
+          "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "NCCL_", "RCCL_"))}}
+    if reducer is not None:
+        try:
+            dp.update(dp_consistency(reducer, opt, model, world, b))
+            dp["algo"] = reducer.algo
+            reducer.timing = []
+            waits = []
+            orig_sync = reducer.sync
+
+            def timed_sync():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig_sync()
+                e1.record()
+                waits.append((e0, e1))
+            reducer.sync = timed_sync
+            for _ in range(2):
+                step(None, labels, zs, moments=moments)
+            barrier()
+            reducer.sync = orig_sync
+            tm, reducer.timing = reducer.timing, None
+            per = {}
+            for name, nbytes, e0, e1 in tm:
+                per.setdefault(name, []).append((nbytes, e0.elapsed_time(e1)))
+            rows = [{"bucket": n, "bytes": v[-1][0], "ms": round(v[-1][1], 4),
+                     "GBps": round(v[-1][0] / max(v[-1][1], 1e-6) / 1e6, 1)} for n, v in per.items()]
+            dp["bucket_reductions_last_step"] = rows if len(rows) <= 80 else rows[:80]
+            dp["sum_bucket_ms"] = round(sum(r["ms"] for r in rows), 3)
+            dp["exposed_wait_at_sync_ms"] = round(waits[-1][0].elapsed_time(waits[-1][1]), 4) if waits else None
+        except Exception as e:   # a reported diagnosis, never a reason to lose the throughput line
+            dp["error"] = repr(e)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -270,37 +338,36 @@ def main():
                        "global_batch": args.global_batch, "local_batch": b, "parallelism": f"dp{world}"},
             "final_loss": round(loss_val, 5),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+            # the whole step against the MFMA roofline: images/s/GPU x 724.97 GFLOP / 2.5 PFLOP/s (the headline efficiency)
             "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
+            "data_parallel": dp,
         }
-        if dp is not None:
-            out["data_parallel"] = dp
-        rows = None
         if not args.no_kernel_table:
+            # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region
+            M = b * T_TOK
+            n_l = sum(len(v) for v in dom.values())
+            tot_ms = sum(sum(v) for v in dom.values())
+            tot_fl = sum(2.0 * M * 1152 * K * len(v) for K, v in dom.items())
+            ach = tot_fl / max(tot_ms, 1e-9) / 1e9
+            shapes = {f"K={K}": {"launches": len(v), "avg_ms": round(sum(v) / len(v), 4),
+                                 "tflops": round(2.0 * M * 1152 * K / (sum(v) / len(v)) / 1e9, 1)} for K, v in sorted(dom.items())}
+            kname = ("gemm144_kernel<NN, bf16>" if b <= 64 else "gemm256_kernel<NN, bf16>")
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": round(ach * 1e12 / PEAK_BF16, 4),
+                "traffic": TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None,
+                "traffic_source": TRAFFIC_SOURCE if (b == 256 and args.model == "SiT-XL/2") else None,
+                "kernel": kname + " = the dgrads of fc1 (K=4608) / qkv (K=3456) / proj (K=1152) on the bf16 weight shadow, "
+                          "output [b*256, 1152]; algorithmic flop 2*M*1152*K per launch / event-timed duration of every such "
+                          "launch INSIDE the timed region (events on the launch stream)",
+                "launches_timed": n_l, "avg_ms_per_launch": round(tot_ms / max(n_l, 1), 4), "per_shape": shapes}
             rows = time_gemms(b)
-            # dominant kernel = the MFMA GEMM family; report its flop-weighted aggregate
-            tot_ms = sum(r["ms"] for r in rows)
-            agg = sum(r["tflops"] * r["ms"] for r in rows) / tot_ms
-            dom = max(rows, key=lambda r: r["ms"])
-            # the single kernel with the largest share of the step (rocprofv3 --stats: gemm256_kernel<1, 0>, ~16 %): the
-            # 256^2 NN kernel with the plain bf16 epilogue; its launches are the block's dgrads of fc1, proj and qkv
-            wg = [r for r in rows if r["kernel"] in ("dgrad fc1 NN", "dgrad proj NN", "dgrad qkv NN")]
-            wg_ms = sum(r["ms"] for r in wg)
-            wg_tf = sum(r["tflops"] * r["ms"] for r in wg) / wg_ms
-            # HBM-side traffic of the slowest GEMM launch, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            # (profiles/; FETCH_SIZE doubled per the gfx950 correction). Valid for the b=256 workload only.
-            traffic = TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None
-            out["roofline"] = {"bound": "mfma", "achieved": round(agg, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                               "frac": round(agg * 1e12 / PEAK_BF16, 4), "traffic": traffic,
-                               "kernel": "bf16 MFMA GEMM family gemm256_kernel<NT|NN> / gemm144_kernel<NT|NN> (1152-wide outputs at b <= 64) / "
-                                         "gemm_tn_kernel / gemm_kernel<TN> (time-"
-                                         "weighted over the block's 12 GEMM launches; flop per launch / event-timed duration)",
-                               "dominant": TRAFFIC_NOTE,
-                               "dominant_kernel": {"name": ("gemm144_kernel<NN, bf16>" if b <= 64 else "gemm256_kernel<NN, bf16>") +
-                                                           " (dgrads of fc1 / proj / qkv on the weight shadow)",
-                                                   "avg_ms_per_launch": round(wg_ms / len(wg), 4),
-                                                   "tflops": round(wg_tf, 1), "frac": round(wg_tf * 1e12 / PEAK_BF16, 4)},
-                               "slowest_shape": dom}
-            out["gemm_table"] = rows
+            tot = sum(r["ms"] for r in rows)
+            agg = sum(r["tflops"] * r["ms"] for r in rows) / tot
+            # the GEMM family launched in ISOLATION after the timed region (12 shapes of one block, time-weighted): an upper
+            # view of the kernels, not the step — the step's efficiency is step_mfma_frac
+            out["gemm_family_isolated"] = {"tflops": round(agg, 1), "frac": round(agg * 1e12 / PEAK_BF16, 4),
+                                           "ms_per_block": round(tot, 4), "table": rows}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

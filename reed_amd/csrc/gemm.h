@@ -38,6 +38,7 @@ struct GemmArgs {
   int accumulate;
   int ksplit_len;
   long slab_stride;
+  int tile_gm;   // gemm256: tile rows per XCD-local group of the workgroup -> tile map (set by launch256)
 };
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);

@@ -15,6 +15,7 @@
 // Each phase starts with s_waitcnt lgkmcnt(0) + s_barrier, which orders (WAR) the reads of a half-tile before the
 // DMA that overwrites it two K-tiles later, and (RAW, at p3) the landed K-tile t+1 before its first fragment read.
 #include <math.h>
+#include <stdlib.h>
 
 #include "gemm_common.hpp"
 
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
       int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
       bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    constexpr int GM = 4;
+    const int GM = a.tile_gm;
     const int per_group = GM * ntn;
     const int group = bid / per_group, first_m = group * GM;
     const int gs = min(ntm - first_m, GM);
@@ -325,6 +326,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     gemm256_body<LAY, EPI, false>(a, smem, tm, tn);
 }
 
+// Tile rows per group of the XCD-local tile walk (kernel: groups of GM tile rows x all tile columns, rows fastest).
+// REED_GEMM256_GM overrides (A/B timing).
+int tile_group_rows(const GemmArgs& a) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("REED_GEMM256_GM"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced;
+  return 4;
+}
+
 template <int LAY, int EPI>
 int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
   static bool attr_set = false;
@@ -335,7 +345,9 @@ int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM2) * cdiv(a.N, BN2), splits, 1);
-  REED_KLAUNCH((gemm256_kernel<LAY, EPI>), grid, dim3(512), LDS_BYTES, stream, a);
+  GemmArgs b = a;
+  b.tile_gm = tile_group_rows(a);
+  REED_KLAUNCH((gemm256_kernel<LAY, EPI>), grid, dim3(512), LDS_BYTES, stream, b);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -42,12 +42,26 @@ def require_cuda(t, name="tensor"):
 
 
 # ---------------- GEMM ----------------
+# Measurement hook (bench.py only): gemm_probe(layout, epi, M, N, K) -> key or None; for a key the launch is bracketed
+# by an event pair on the launch stream and (key, start, end) appended to gemm_probe_log. None (the default) costs one
+# attribute test per launch.
+gemm_probe = None
+gemm_probe_log = []
+
+
 def gemm(layout, epi, P, Q, M, N, K, C, ldp, ldq, ldc, C2=None, ldc2=0, R=None, ldr=0, bias=None,
          gate=None, ldgate=0, rows_per_gate=1, dbias=None, accumulate=False, split_k=1,
          slab_stride=0):
+    key = gemm_probe(layout, epi, M, N, K) if gemm_probe is not None else None
+    if key is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _call("reed_gemm", layout, epi, _p(P), ldp, _p(Q), ldq, M, N, K, _p(C), ldc, _p(C2), ldc2,
           _p(R), ldr, _p(bias), _p(gate), ldgate, rows_per_gate, _p(dbias), int(accumulate), split_k,
           slab_stride, _stream())
+    if key is not None:
+        e1.record()
+        gemm_probe_log.append((key, e0, e1))
 
 
 def linear_fwd(x, w, bias, out, epi=EPI_BF16, act_out=None, R=None, gate=None, ldgate=0,
