@@ -219,6 +219,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # this image exports NCCL_DEBUG=VERSION, which makes RCCL print its banner on STDOUT: keep stdout to the one JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/reed_rccl.%h.%p.log")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import copy

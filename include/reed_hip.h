@@ -33,7 +33,7 @@ int reed_version(void);
  *   layout 1 NN: C[M,N] = P[M,K] Q[K,N]       (dgrad    dx = dy W)
  *   layout 2 TN: C[M,N] = P[K,M]^T Q[K,N]     (wgrad    dW = dy^T x), optional dbias[M] = colsum(P)
  *   layout 3 / 4: TN on a 256x128 / 128x256 output tile (128x64 / 64x128 per wave; epilogue 6 only; 4 needs N%256==0)
- * epilogue codes: see reed_amd/csrc/gemm.h (0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
+ * epilogue codes: see reed_amd/csrc/gemm.h (11 = exact GELU(erf) with the layout of 9; 0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
  *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual).  N%128==0 (NT/NN with a
  *   bf16-output epilogue also N%144==0: the 256x144 tile of csrc/gemm144.hip); K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
@@ -243,6 +243,24 @@ int reed_clip_tokens(const void* patches, const float* cls, const float* pos, vo
 /* out bf16 = bf16(LayerNorm_fp32(float(x bf16 [M,D]); eps) * w + b)   (clip_vit.py:159-165) */
 int reed_ln_affine_bf16(const void* x, const float* w, const float* b, void* out, int M, int D, float eps,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The other frozen towers the reference can name (image/utils.py:73-82 mocov3, :133-147 mae, :149-160 jepa): plain pre-LN
+ * ViTs (image/models/jepa.py:173-218 Attention / Block, :376-466 VisionTransformer; image/models/mae_vit.py:20-48 and
+ * mocov3_vit.py:52-101 over timm's VisionTransformer) with an fp32 residual stream under autocast, LayerNorm(eps 1e-6,
+ * affine), exact GELU (reed_gemm epilogue 11) and head_dim 64 or 80 (reed_attention_fwd).  Row passes:
+ * ------------------------------------------------------------------------------------------- */
+/* out (bf16 or f32, row stride ldo) = LayerNorm_fp32(x f32 [M,D]; eps) * w + b */
+int reed_ln_affine_f32(const float* x, const float* w, const float* b, void* out, int out_is_f32, int M, int D,
+                       int64_t ldo, float eps, void* stream);
+/* out f32 [B,T,D]: row 0 = cls + pos[0] when cls != NULL (T = patches + 1), row t = float(patches bf16[b, t - ncls]) + pos[t] */
+int reed_vit_tokens(const void* patches, const float* cls, const float* pos, float* out, int B, int T, int D,
+                    void* stream);
+/* preprocess_raw_image (image/train.py:53-74): raw u8 [B,3,R,R] -> out f32 [B,3,S,S]; order 0: /255 -> bicubic -> normalise
+ * ('clip'), order 1: /255 -> normalise -> bicubic ('dinov2', 'jepa'); S == R: no resampling ('mocov3', 'mae').
+ * mean3 / std3 are HOST pointers to 3 floats.  Bicubic = F.interpolate(mode='bicubic', align_corners=False). */
+int reed_preprocess_image(const uint8_t* raw, float* out, int B, int R, int S, const float* mean3, const float* std3,
+                          int order, void* stream);
 
 #ifdef __cplusplus
 }

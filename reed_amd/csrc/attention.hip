@@ -928,24 +928,25 @@ int num_cus() {
 extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H, int hd,
                                   void* stream) {
   REED_CHECK_ARG(qkv && o, "attention_fwd: null pointer");
-  REED_CHECK_ARG(hd == 64 || hd == 72, "attention: head_dim %d unsupported (64 or 72)", hd);
+  REED_CHECK_ARG(hd == 64 || hd == 72 || hd == 80, "attention: head_dim %d unsupported (64, 72 or 80)", hd);
+  REED_CHECK_ARG(hd != 80 || T <= 256, "attention: head_dim 80 (the I-JEPA ViT-H tower) is built for T <= 256 only (T=%d)", T);
   REED_CHECK_ARG(B > 0 && T > 0 && H > 0, "attention: bad dims B=%d T=%d H=%d", B, T, H);
-  if (T <= 256 && !attn_fwd_oneshot()) {
+  if (T <= 256 && (hd == 80 || !attn_fwd_oneshot())) {
     const int lds = 4 * TILE_F, nitems = B * H;
     int ncu = num_cus();
     ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
     const dim3 grid(nitems < ncu ? nitems : ncu);
-    if (hd == 64) {
-      static int once = set_lds(attn_fwd256_kernel<64>, lds);
-      if (once) return once;
-      REED_KLAUNCH(attn_fwd256_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T, H,
-                   nitems);
-    } else {
-      static int once = set_lds(attn_fwd256_kernel<72>, lds);
-      if (once) return once;
-      REED_KLAUNCH(attn_fwd256_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T, H,
-                   nitems);
-    }
+#define LAUNCH_FWD256(HD)                                                                                              \
+    do {                                                                                                               \
+      static int once = set_lds(attn_fwd256_kernel<HD>, lds);                                                          \
+      if (once) return once;                                                                                           \
+      REED_KLAUNCH(attn_fwd256_kernel<HD>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T,  \
+                   H, nitems);                                                                                         \
+    } while (0)
+    if (hd == 64) LAUNCH_FWD256(64);
+    else if (hd == 72) LAUNCH_FWD256(72);
+    else LAUNCH_FWD256(80);
+#undef LAUNCH_FWD256
     REED_LAUNCH_CHECK();
     return REED_OK;
   }

@@ -70,6 +70,8 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   float xs = x * s;
   return fmaf(xs - xs * s, fmaf(d1, x * x, d0), s);
 }
+// nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2)) — the frozen ViT towers' Mlp activation (inference only)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
   float s = sigmoid_f(x);

@@ -16,7 +16,8 @@ enum {
   EPI_ATOMIC_F32 = 8, // atomicAdd(C f32, acc)   (split-K into a pre-zeroed / accumulating buffer)
   // inference-only epilogues of the frozen CLIP image encoder (bf16 residual stream):
   EPI_QGELU = 9,      // C2 bf16 = QuickGELU(pre) = bf16(pre * bf16(sigmoid(bf16(1.702 pre)))), pre = bf16(acc+bias) (C optional)
-  EPI_RES_BF16 = 10   // C bf16 = bf16(bf16(acc+bias) + R bf16)
+  EPI_RES_BF16 = 10,  // C bf16 = bf16(bf16(acc+bias) + R bf16)
+  EPI_GELU_ERF = 11   // ABI id only: exact GELU on the EPI_QGELU instantiation (GemmArgs::act_variant = 1); the ViT towers' Mlp
 };
 
 struct GemmArgs {
@@ -38,6 +39,7 @@ struct GemmArgs {
   int accumulate;
   int ksplit_len;
   long slab_stride;
+  int act_variant;   // EPI_QGELU: 0 = QuickGELU (CLIP), 1 = GELU(erf) (timm / I-JEPA Mlp, nn.GELU)
   int tile_gm;   // gemm256: tile rows per XCD-local group of the workgroup -> tile map (set by launch256)
 };
 

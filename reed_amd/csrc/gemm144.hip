@@ -84,7 +84,7 @@ __device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&
       for (int e = 0; e < 4; ++e) {
         pre[e] = f2bf(v[e]);
         const float x = bf2f(pre[e]);
-        if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+        if constexpr (EPI == EPI_QGELU) act[e] = a.act_variant ? f2bf(gelu_erf_f(x)) : f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
         else act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
       }
       if (a.C) *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = pre;

@@ -191,7 +191,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
             pre[e] = f2bf(v[h][e]);
             float x = bf2f(pre[e]);
             if constexpr (EPI == EPI_QGELU)   // x * sigmoid(1.702 x) with eager-mode bf16 roundings (clip_vit.py:168-170)
-              act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+              act[e] = a.act_variant ? f2bf(gelu_erf_f(x)) : f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
             else
               act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
           }

@@ -21,10 +21,34 @@ import torch
 from torch import nn
 
 from . import ops
-from .ops import EPI_BF16, EPI_QGELU, EPI_RES_BF16, NT
+from .ops import EPI_BF16, EPI_GATE_RES, EPI_GELU_ERF, EPI_QGELU, EPI_RES_BF16, NT
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # timm.data.IMAGENET_DEFAULT_MEAN / STD (image/train.py:28)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_raw_image(raw, enc_type):
+    """image/train.py:53-74, every branch, as ONE HIP pass (csrc/encoder.hip: preprocess_image_kernel): raw uint8
+    [B,3,R,R] on the GPU -> fp32 [B,3,S,S].  'clip': /255 -> bicubic to 224 (R // 256) -> CLIP mean/std; 'mocov3' / 'mae' /
+    'dinov1': /255 -> ImageNet mean/std, no resampling; 'dinov2' / 'jepa': /255 -> ImageNet mean/std -> bicubic."""
+    ops.require_cuda(raw, "raw images")
+    if raw.dtype != torch.uint8:
+        raise TypeError("preprocess_raw_image: raw images must be uint8 (the dataset's format, image/dataset.py:66-71)")
+    raw = raw.contiguous()
+    B, R = raw.shape[0], raw.shape[-1]
+    if "clip" in enc_type:
+        S, mean, std, order = 224 * (R // 256), CLIP_MEAN, CLIP_STD, 0
+    elif "mocov3" in enc_type or "mae" in enc_type or "dinov1" in enc_type:
+        S, mean, std, order = R, IMAGENET_MEAN, IMAGENET_STD, 1
+    elif "dinov2" in enc_type or "jepa" in enc_type:
+        S, mean, std, order = 224 * (R // 256), IMAGENET_MEAN, IMAGENET_STD, 1
+    else:
+        raise ValueError(f"preprocess_raw_image: unknown encoder type {enc_type!r}")
+    out = torch.empty(B, 3, S, S, dtype=torch.float32, device=raw.device)
+    ops.preprocess_image(raw, out, B, R, S, mean, std, order)
+    return out
 
 CLIP_CONFIGS = {   # openai/CLIP vision towers the reference can name (utils.py:127: f"ViT-{model_config}/14")
     "L": dict(width=1024, layers=24, heads=16, patch=14, image=224),
@@ -99,12 +123,7 @@ class ClipVisionEncoder(nn.Module):
     @staticmethod
     def preprocess(raw):
         """image/train.py:53-57, 'clip' branch: uint8 [B,3,R,R] -> /255 -> bicubic to 224·(R//256) -> CLIP mean/std."""
-        x = raw.float() / 255.0
-        res = x.shape[-1]
-        x = torch.nn.functional.interpolate(x, 224 * (res // 256), mode="bicubic")
-        mean = torch.tensor(CLIP_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-        std = torch.tensor(CLIP_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-        return (x - mean) / std
+        return preprocess_raw_image(raw, "clip")
 
     @torch.no_grad()
     def forward(self, x):
@@ -144,6 +163,170 @@ class ClipVisionEncoder(nn.Module):
 
     def encode_raw(self, raw_u8):
         return self.forward(self.preprocess(raw_u8))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other towers image/utils.py:load_encoders can name: plain pre-LN ViTs.
+VIT_TOWERS = {
+    # enc-type "jepa-vit-h": models.jepa.vit_huge(img_size=[224, 224], patch_size=14) (utils.py:149-160)
+    "jepa-vit-h": dict(embed=1280, depth=32, heads=16, patch=14, image=224, cls=False, final_norm=True),
+    # "mocov3-vit-{b,l}": mocov3_vit.vit_base / vit_large, img_size 256, patch 16 (utils.py:73-82; vit_small has head_dim 32)
+    "mocov3-vit-b": dict(embed=768, depth=12, heads=12, patch=16, image=256, cls=True, final_norm=True),
+    "mocov3-vit-l": dict(embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=True),
+    # "mae-vit-l": mae_vit.vit_large_patch16(img_size=256): forward_features WITHOUT the final norm (mae_vit.py:33-48)
+    "mae-vit-l": dict(embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=False),
+}
+
+
+class VitEncoder(nn.Module):
+    """Forward-only counterpart of the reference's I-JEPA / MAE / MoCo-v3 target encoders (image/models/jepa.py:376-466,
+    mae_vit.py:20-48, mocov3_vit.py:52-101 over timm's VisionTransformer): patch-embedding conv (im2col + GEMM with bias)
+    -> [class token |] patches + pos_embed in fp32 -> depth x {LayerNorm(eps 1e-6, affine) -> qkv GEMM -> attention (head_dim
+    64 or 80) -> proj GEMM + fp32 residual; LayerNorm -> fc1 GEMM + exact GELU -> fc2 GEMM + fp32 residual} -> [final
+    LayerNorm] -> patch tokens without the class token, fp32.  Numerics = the reference under accelerator.autocast() with
+    bf16 (train.py:351-357): bf16 GEMM operands and linear outputs, fp32 residual stream / LayerNorm, as SiT's.
+    Parameter names are the reference's / timm's (patch_embed.proj.*, cls_token, pos_embed, blocks.{i}.norm1.*,
+    attn.qkv.*, attn.proj.*, norm2.*, mlp.fc1.*, mlp.fc2.*, norm.*), so the checkpoints utils.py loads load here.  No
+    weights ship; no CPU path."""
+
+    def __init__(self, embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=True):
+        super().__init__()
+        hd = embed // heads
+        if embed % 128 or hd not in (64, 80) or heads * hd != embed:
+            raise ValueError(f"VitEncoder: embed={embed} / heads={heads}: need embed % 128 == 0 and head_dim 64 or 80")
+        self.embed_dim = self.embed = embed
+        self.depth, self.heads, self.hd, self.patch, self.image = depth, heads, hd, patch, image
+        self.has_cls, self.final_norm = bool(cls), bool(final_norm)
+        G = image // patch
+        self.npatch = G * G
+        self.tokens = self.npatch + (1 if cls else 0)
+        if hd == 80 and self.tokens > 256:
+            raise ValueError("VitEncoder: head_dim 80 is built for <= 256 tokens (I-JEPA ViT-H/14 at 224)")
+        self.kp = (3 * patch * patch + 63) // 64 * 64
+        self.patch_embed = nn.Module()
+        self.patch_embed.proj = nn.Conv2d(3, embed, patch, patch)
+        if cls:
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.tokens, embed), requires_grad=False)
+        blocks = []
+        for _ in range(depth):
+            b = nn.Module()
+            b.norm1, b.norm2 = nn.LayerNorm(embed, eps=1e-6), nn.LayerNorm(embed, eps=1e-6)
+            b.attn = nn.Module()
+            b.attn.qkv, b.attn.proj = nn.Linear(embed, 3 * embed), nn.Linear(embed, embed)
+            b.mlp = nn.Module()
+            b.mlp.fc1, b.mlp.fc2 = nn.Linear(embed, 4 * embed), nn.Linear(4 * embed, embed)
+            blocks.append(b)
+        self.blocks = nn.ModuleList(blocks)
+        self.norm = nn.LayerNorm(embed, eps=1e-6)
+        self.requires_grad_(False)
+        self._bf = None
+
+    def load_state_dict(self, sd, strict=False):
+        sd = {k: v for k, v in sd.items() if not k.startswith(("head.", "fc_norm."))}
+        r = super().load_state_dict(sd, strict=strict)
+        self._bf = None
+        return r
+
+    def _apply(self, fn, recurse=True):
+        self._bf = None
+        return super()._apply(fn, recurse)
+
+    def _operands(self):
+        if self._bf is None:
+            dev = self.pos_embed.device
+            E = self.embed
+            w = torch.zeros(E, self.kp, dtype=torch.bfloat16, device=dev)
+            w[:, :3 * self.patch * self.patch] = self.patch_embed.proj.weight.detach().reshape(E, -1).to(torch.bfloat16)
+            bf = lambda t: t.detach().to(torch.bfloat16).contiguous()  # noqa: E731
+            f32 = lambda t: t.detach().float().contiguous()            # noqa: E731
+            blocks = [dict(qkv_w=bf(b.attn.qkv.weight), qkv_b=bf(b.attn.qkv.bias), proj_w=bf(b.attn.proj.weight),
+                           proj_b=bf(b.attn.proj.bias), fc1_w=bf(b.mlp.fc1.weight), fc1_b=bf(b.mlp.fc1.bias),
+                           fc2_w=bf(b.mlp.fc2.weight), fc2_b=bf(b.mlp.fc2.bias),
+                           n1=(f32(b.norm1.weight), f32(b.norm1.bias)), n2=(f32(b.norm2.weight), f32(b.norm2.bias)))
+                      for b in self.blocks]
+            self._bf = dict(conv=w, conv_b=bf(self.patch_embed.proj.bias), pos=f32(self.pos_embed[0]),
+                            cls=f32(self.cls_token.reshape(-1)) if self.has_cls else None,
+                            norm=(f32(self.norm.weight), f32(self.norm.bias)), blocks=blocks,
+                            ones=torch.ones(E, dtype=torch.bfloat16, device=dev))
+        return self._bf
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: preprocessed images f32 [B,3,image,image] on the GPU -> f32 [B, patches, embed] (class token dropped)."""
+        ops.require_cuda(x, "images")
+        E, H, T, P = self.embed, self.heads, self.tokens, self.patch
+        if x.shape[1] != 3 or x.shape[-1] != self.image or x.shape[-2] != self.image:
+            raise ValueError(f"VitEncoder: input {tuple(x.shape)} is not (B,3,{self.image},{self.image})")
+        B = x.shape[0]
+        dev = x.device
+        w = self._operands()
+        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)   # noqa: E731
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)    # noqa: E731
+        x = x.contiguous().float()
+        Mp, M = B * self.npatch, B * T
+        cols = bf(Mp, self.kp)
+        ops.clip_im2col(x, cols, B, self.image, P, self.kp)
+        patches = bf(Mp, E)
+        ops.gemm(NT, EPI_BF16, cols, w["conv"], Mp, E, self.kp, patches, self.kp, self.kp, E, bias=w["conv_b"])
+        xa, xb = f32(M, E), f32(M, E)
+        ops.vit_tokens(patches, w["cls"], w["pos"], xa, B, T, E)
+        h, qkv, o, u = bf(M, E), bf(M, 3 * E), bf(M, E), bf(M, 4 * E)
+        one = w["ones"]
+        for blk in w["blocks"]:
+            ops.ln_affine_f32(xa, blk["n1"][0], blk["n1"][1], h, False, M, E)
+            ops.gemm(NT, EPI_BF16, h, blk["qkv_w"], M, 3 * E, E, qkv, E, E, 3 * E, bias=blk["qkv_b"])
+            ops.attention_fwd(qkv, o, None, B, T, H, self.hd)
+            # x + bf16(proj(o)) in fp32: the gate-residual epilogue with a gate of ones
+            ops.gemm(NT, EPI_GATE_RES, o, blk["proj_w"], M, E, E, xb, E, E, E, R=xa, ldr=E, bias=blk["proj_b"], gate=one,
+                     ldgate=0, rows_per_gate=T)
+            ops.ln_affine_f32(xb, blk["n2"][0], blk["n2"][1], h, False, M, E)
+            ops.gemm(NT, EPI_GELU_ERF, h, blk["fc1_w"], M, 4 * E, E, None, E, E, 4 * E, C2=u, ldc2=4 * E, bias=blk["fc1_b"])
+            ops.gemm(NT, EPI_GATE_RES, u, blk["fc2_w"], M, E, 4 * E, xa, 4 * E, 4 * E, E, R=xb, ldr=E, bias=blk["fc2_b"],
+                     gate=one, ldgate=0, rows_per_gate=T)
+        if self.final_norm:
+            ops.ln_affine_f32(xa, w["norm"][0], w["norm"][1], xb, True, M, E)
+            xa = xb
+        out = xa.view(B, T, E)
+        return out[:, 1:] if self.has_cls else out
+
+    def forward_features(self, x):
+        return self.forward(x)
+
+    enc_type = "jepa"   # set by load_vit_encoder: selects the preprocess_raw_image branch
+
+    def encode_raw(self, raw_u8):
+        return self.forward(preprocess_raw_image(raw_u8, self.enc_type))
+
+
+def load_vit_encoder(enc_type, ckpt_path, device):
+    """`jepa-vit-h`, `mocov3-vit-{b,l}`, `mae-vit-l` of image/utils.py:73-82,133-160 from the checkpoint files the reference
+    names (ckpts/ijepa_vith.pth: state_dict['encoder'] with a 'module.' prefix; ckpts/mocov3_vit{b,l}.pth: ['state_dict']
+    with 'module.base_encoder.' (fix_mocov3_state_dict, utils.py:27-52); ckpts/mae_vitl.pth: ['model']) or a plain state
+    dict.  A learned pos_embed of another grid must be resampled by the caller (utils.py:140-146 uses timm's helper)."""
+    cfg = VIT_TOWERS[enc_type]
+    enc = VitEncoder(**cfg)
+    sd = torch.load(ckpt_path, map_location="cpu")
+    for key in ("encoder", "state_dict", "model"):
+        if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+            sd = sd[key]
+            break
+    out = {}
+    for k, v in sd.items():
+        for pre in ("module.base_encoder.", "module."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+                break
+        out[k] = v.float() if torch.is_floating_point(v) else v
+    if "pos_embed" in out and out["pos_embed"].shape != enc.pos_embed.shape:
+        raise RuntimeError(f"{ckpt_path}: pos_embed {tuple(out['pos_embed'].shape)} != {tuple(enc.pos_embed.shape)}; resample it "
+                           "to the tower's grid first (image/utils.py:140-146)")
+    missing, unexpected = enc.load_state_dict(out, strict=False)
+    missing = [k for k in missing if not (k.startswith("norm.") and not enc.final_norm)]
+    if missing:
+        raise RuntimeError(f"checkpoint {ckpt_path} lacks {missing[:4]}...")
+    enc.enc_type = enc_type.split("-")[0]
+    return enc.to(device).eval()
 
 
 def load_clip_encoder(model_config, ckpt_path, device):

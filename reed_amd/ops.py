@@ -15,7 +15,7 @@ from . import _lib
 NT, NN, TN = 0, 1, 2
 TN_TALL, TN_WIDE = 3, 4   # TN on the 256x128 / 128x256 tile of csrc/gemm_tn.hip (weight gradients)
 (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32, EPI_QGELU,
- EPI_RES_BF16) = range(11)
+ EPI_RES_BF16, EPI_GELU_ERF) = range(12)
 
 
 def _p(t):
@@ -315,6 +315,24 @@ def cosine_fwd(zt, z, rowdot, loss, B, T, Z):
 
 def cosine_bwd(zt, z, gscale, dzt, B, T, Z):
     _call("reed_cosine_bwd", _p(zt), _p(z), _p(gscale), _p(dzt), B, T, Z, _stream())
+
+
+# ---------------- frozen ViT towers (encoders.py) ----------------
+def ln_affine_f32(x, w, b, out, out_is_f32, M, D, ldo=None, eps=1e-6):
+    _call("reed_ln_affine_f32", _p(x), _p(w), _p(b), _p(out), int(out_is_f32), M, D, D if ldo is None else ldo, eps, _stream())
+
+
+def vit_tokens(patches, cls, pos, out, B, T, D):
+    _call("reed_vit_tokens", _p(patches), _p(cls), _p(pos), _p(out), B, T, D, _stream())
+
+
+def preprocess_image(raw_u8, out, B, R, S, mean, std, order):
+    """image/train.py:53-74 on the device: uint8 [B,3,R,R] -> f32 [B,3,S,S]; order 0 = /255, bicubic, normalise (clip);
+    order 1 = /255, normalise, bicubic (dinov2 / jepa); S == R: no resampling (mocov3 / mae)."""
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    _call("reed_preprocess_image", _p(raw_u8), _p(out), B, R, S, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p),
+          order, _stream())
 
 
 # ---------------- optimiser ----------------

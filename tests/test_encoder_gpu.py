@@ -105,3 +105,92 @@ def test_vit_l14_shape_and_preprocess(dev):
     scale = o16.abs().max().item()
     assert (out - o16).abs().max().item() <= 3e-2 * scale
     assert torch.nn.functional.cosine_similarity(out.flatten(), o16.flatten(), dim=0).item() > 0.9995
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The other frozen towers (I-JEPA, MAE, MoCo-v3): reed_amd.encoders.VitEncoder vs the goldens of the reference's classes
+TOWER_CASES = {"jepa80": (dict(embed=640, depth=2, heads=8, patch=14, image=56, cls=False, final_norm=True), "jepa", 3),
+               "jepa64": (dict(embed=256, depth=3, heads=4, patch=14, image=56, cls=False, final_norm=True), "jepa", 3),
+               "mae": (dict(embed=256, depth=2, heads=4, patch=16, image=64, cls=True, final_norm=False), "learned", 2),
+               "moco": (dict(embed=256, depth=2, heads=4, patch=16, image=64, cls=True, final_norm=True), "moco", 2)}
+
+
+@pytest.mark.parametrize("tag", list(TOWER_CASES))
+def test_vit_tower_vs_reference(dev, tag):
+    """HIP tower (bf16 operands, fp32 residual) against the reference's output under bf16 autocast and in fp32
+    (tests/golden/towers.npz: the reference's own I-JEPA class; its MAE forward_features and MoCo-v3 constructor over the
+    timm stand-in) and against the same-precision oracle.  head_dim 80 (ViT-H) and 64; with / without class token and
+    final norm; T = 16 and 17 tokens."""
+    import numpy as np
+    from oracle import detfill
+    from oracle import vit_towers as ot
+    from reed_amd.encoders import VitEncoder
+    from tests.test_oracle_golden import load
+    g = load("towers")
+    kw, pos, B = TOWER_CASES[tag]
+    cfg = ot.make_config(pos=pos, **kw)
+    P = ot.fill_params(cfg, base_seed=9)
+    enc = VitEncoder(**kw)
+    enc.load_state_dict(P)
+    enc = enc.to(dev).eval()
+    x = detfill.normal((B, 3, kw["image"], kw["image"]), 55)
+    out = enc(x.to(dev)).float().cpu()
+    ref32, ref16 = torch.from_numpy(g[tag + ".fp32"]), torch.from_numpy(g[tag + ".bf16"])
+    assert out.shape == ref32.shape
+    sc = ref32.abs().max().item()
+    e16, e32, eref = (out - ref16).abs().max().item() / sc, (out - ref32).abs().max().item() / sc, (ref16 - ref32).abs().max().item() / sc
+    c32 = torch.nn.functional.cosine_similarity(out.flatten(), ref32.flatten(), dim=0).item()
+    print(f"tower {tag}: max|HIP - ref_bf16| {e16:.2e}, max|HIP - ref_fp32| {e32:.2e} (reference's own bf16-vs-fp32 {eref:.2e}) of the "
+          f"output range; cosine vs fp32 {c32:.6f}")
+    assert e32 <= 2.0 * eref + 2e-3 and c32 > 0.9998
+
+
+def test_preprocess_raw_image_branches(dev):
+    """preprocess_raw_image (image/train.py:53-74) as one HIP pass: every branch against the torch restatement
+    (F.interpolate bicubic + Normalize) on random uint8 images and against the reference-generated ramp samples."""
+    import numpy as np
+    from oracle import vit_towers as ot
+    from reed_amd.encoders import preprocess_raw_image
+    from tests.test_oracle_golden import load
+    g = load("towers")
+    gc = load("clip")
+    raw = torch.randint(0, 256, (3, 3, 256, 256), generator=torch.Generator().manual_seed(4), dtype=torch.uint8)
+    for enc in ("clip", "mocov3", "mae", "dinov2", "jepa"):
+        got = preprocess_raw_image(raw.to(dev), enc).cpu()
+        ref = ot.preprocess(raw, enc)
+        assert got.shape == ref.shape, enc
+        err = (got - ref).abs().max().item()
+        print(f"preprocess {enc}: max abs deviation from torch {err:.2e}")
+        assert err <= 2e-5, (enc, err)       # fp32 bicubic taps summed in a different order
+    ramp = (torch.arange(2 * 3 * 256 * 256) % 251).reshape(2, 3, 256, 256).to(torch.uint8).to(dev)
+    np.testing.assert_allclose(preprocess_raw_image(ramp, "jepa")[:, :, ::37, ::41].cpu().numpy(), g["pre.jepa.sample"], atol=2e-5)
+    np.testing.assert_allclose(preprocess_raw_image(ramp, "mae")[:, :, ::37, ::41].cpu().numpy(), g["pre.mae.sample"], atol=2e-6)
+    mean = torch.tensor(ot.CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ot.CLIP_STD).view(1, 3, 1, 1)
+    got = preprocess_raw_image(ramp, "clip")[:, :, ::37, ::41].cpu()
+    np.testing.assert_allclose((got * std + mean).numpy(), gc["pre.sample"], atol=2e-5)   # golden = before Normalize
+    big = torch.randint(0, 256, (1, 3, 512, 512), generator=torch.Generator().manual_seed(5), dtype=torch.uint8)
+    assert preprocess_raw_image(big.to(dev), "dinov2").shape == (1, 3, 448, 448)
+    assert (preprocess_raw_image(big.to(dev), "jepa").cpu() - ot.preprocess(big, "jepa")).abs().max().item() <= 2e-5
+
+
+def test_vit_h_tower_shape_and_head_dim_80_attention(dev):
+    """I-JEPA ViT-H/14 geometry (embed 1280, 16 heads of 80, 256 tokens) through 2 blocks: shape / finiteness, and the
+    head_dim-80 attention kernel against fp32 softmax attention at T = 256 with more (batch, head) items than CUs."""
+    from reed_amd import ops
+    from reed_amd.encoders import VitEncoder
+    from tests.test_attention_gpu import _ref
+    B, T, H, hd = 20, 256, 16, 80
+    qkv = (torch.randn(B, T, 3, H, hd, generator=torch.Generator().manual_seed(8)) * 1.2).to(torch.bfloat16).to(dev)
+    o = torch.full((B, T, H * hd), float("nan"), dtype=torch.bfloat16, device=dev)
+    lse = torch.full((B, H, T), float("nan"), device=dev)
+    ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+    ro, rl = _ref(qkv, B, T, H, hd)
+    torch.testing.assert_close(lse, rl, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(o.float(), ro, atol=2e-2, rtol=2e-2)
+    enc = VitEncoder(embed=1280, depth=2, heads=16, patch=14, image=224, cls=False, final_norm=True).to(dev).eval()
+    for p in enc.parameters():
+        if p.ndim > 1:
+            torch.nn.init.normal_(p, std=0.02)
+    out = enc(torch.randn(2, 3, 224, 224, device=dev))
+    assert out.shape == (2, 256, 1280) and out.dtype == torch.float32 and bool(torch.isfinite(out).all())

@@ -286,3 +286,34 @@ def test_clip_encoder_oracle_vs_reference():
     std = torch.tensor(oclip.CLIP_STD).view(1, 3, 1, 1)
     assert pre.shape == (2, 3, 224, 224)
     torch.testing.assert_close((pre * std + mean)[:, :, ::37, ::41], torch.from_numpy(g["pre.sample"]), atol=1e-5, rtol=1e-5)
+
+
+def test_vit_towers():
+    """oracle/vit_towers.py against the reference's own JEPA class, its MAE forward_features and MoCo-v3 constructor /
+    pos-embed (tools/gen_golden.py:g_towers): fp32 to 2e-5, bf16-autocast to bf16 noise; pos-embed tables of the real
+    grids and the preprocess geometry of both resample orders exactly / to 1e-6."""
+    from oracle import vit_towers as ot
+    g = load("towers")
+    cases = {"jepa80": (ot.make_config(640, 2, 8, 14, 56, False, True, "jepa"), 3),
+             "jepa64": (ot.make_config(256, 3, 4, 14, 56, False, True, "jepa"), 3),
+             "mae": (ot.make_config(256, 2, 4, 16, 64, True, False, "learned"), 2),
+             "moco": (ot.make_config(256, 2, 4, 16, 64, True, True, "moco"), 2)}
+    for tag, (cfg, B) in cases.items():
+        P = ot.fill_params(cfg, base_seed=9)
+        x = detfill.normal((B, 3, cfg["image"], cfg["image"]), 55)
+        with torch.no_grad():
+            o32 = ot.forward(P, cfg, x).numpy()
+            o16 = ot.forward(P, cfg, x, autocast_bf16=True).float().numpy()
+        assert o32.shape == g[tag + ".fp32"].shape
+        np.testing.assert_allclose(o32, g[tag + ".fp32"], rtol=2e-5, atol=2e-5)
+        sc = np.abs(g[tag + ".fp32"]).max()
+        assert np.abs(o16 - g[tag + ".bf16"]).max() <= 2e-2 * sc, tag
+    pe = ot.jepa_pos_embed(1280, 16)[0]
+    assert np.array_equal(pe[::17].numpy(), g["jepa_pos_1280_rows"])
+    assert np.array_equal(pe.double().sum(0).numpy(), g["jepa_pos_1280_sum"])
+    pm = ot.moco_pos_embed(768, 16, 16)[0]
+    assert np.array_equal(pm[::17].numpy(), g["moco_pos_768_rows"])
+    raw = (torch.arange(2 * 3 * 256 * 256) % 251).reshape(2, 3, 256, 256).to(torch.uint8)
+    np.testing.assert_allclose(ot.preprocess(raw, "jepa")[:, :, ::37, ::41].numpy(), g["pre.jepa.sample"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ot.preprocess(raw, "mae")[:, :, ::37, ::41].numpy(), g["pre.mae.sample"], rtol=1e-6, atol=1e-6)
+    assert ot.preprocess(raw, "mocov3").shape == (2, 3, 256, 256) and ot.preprocess(raw, "dinov2").shape == (2, 3, 224, 224)

@@ -67,6 +67,45 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, in_features)
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
+# --- the container image/models/mae_vit.py and mocov3_vit.py subclass (timm >= 0.9 semantics, inference subset) ---
+def _cfg(**kw):
+    return dict(kw)
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4.0, qkv_bias=True, norm_layer=None, embed_layer=PatchEmbed, **kw):
+        super().__init__()
+        norm_layer = norm_layer or nn.LayerNorm
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        self.patch_embed.img_size = (img_size, img_size)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + 1, embed_dim) * .02)
+        self.pos_drop = nn.Identity()
+        self.patch_drop = nn.Identity()
+        self.norm_pre = nn.Identity()
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+    def _pos_embed(self, x):
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
+        return self.pos_drop(x + self.pos_embed)
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = self._pos_embed(x)
+        x = self.patch_drop(x)
+        x = self.norm_pre(x)
+        x = self.blocks(x)
+        return self.norm(x)
 '''
 
 
@@ -77,6 +116,10 @@ def import_reference():
     open(os.path.join(d, "timm", "models", "__init__.py"), "w").close()
     with open(os.path.join(d, "timm", "models", "vision_transformer.py"), "w") as f:
         f.write(TIMM_STANDIN)
+    os.makedirs(os.path.join(d, "timm", "layers"))
+    open(os.path.join(d, "timm", "layers", "__init__.py"), "w").close()
+    with open(os.path.join(d, "timm", "layers", "helpers.py"), "w") as f:
+        f.write("def to_2tuple(x):\n    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)\n")
     sys.path.insert(0, d)
     sys.path.insert(0, REF)
     import loss as ref_loss  # noqa
@@ -485,6 +528,64 @@ def g_clip(ref_sit, ref_loss, ref_samplers):
     save("clip", **out)
 
 
+def g_towers(ref_sit, ref_loss, ref_samplers):
+    """Frozen ViT towers other than CLIP.  JEPA: the reference's own VisionTransformer
+    (image/models/jepa.py, self-contained), head_dim 80 and 64.  MAE: the reference's own forward_features
+    (mae_vit.py:33-48) and MoCo-v3: its own sin-cos pos-embed builder and constructor (mocov3_vit.py:52-101), both over the
+    stand-in for timm's VisionTransformer container / Block above.  fp32 and bf16-autocast outputs; pos-embed tables of the
+    real ViT-H/14 and ViT-B/16 grids; preprocess_raw_image (train.py:53-74 cannot be imported: its torch calls are
+    restated in oracle.vit_towers.preprocess) pinned on a fixed ramp for both orders of normalise / resample."""
+    from functools import partial
+    from models import jepa as ref_jepa
+    from models import mae_vit as ref_mae
+    from models import mocov3_vit as ref_moco
+    from oracle import vit_towers as ot
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    out = {}
+
+    def run(tag, model, cfg, fwd, B):
+        P = ot.fill_params(cfg, base_seed=9)
+        sd = model.state_dict()
+        keep = {k: v for k, v in P.items() if k in sd and not (k == "pos_embed" and cfg["pos"] != "learned")}
+        assert torch.equal(sd["pos_embed"].float(), P["pos_embed"]) or cfg["pos"] == "learned", tag   # the reference's own table
+        missing = model.load_state_dict(keep, strict=False)
+        assert not [k for k in missing.missing_keys if k not in ("pos_embed", "head.weight", "head.bias")], missing
+        model.eval()
+        x = detfill.normal((B, 3, cfg["image"], cfg["image"]), 55)
+        with torch.no_grad():
+            out[tag + ".fp32"] = fwd(x).numpy()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out[tag + ".bf16"] = fwd(x).float().numpy()
+
+    for tag, E, H, depth in (("jepa80", 640, 8, 2), ("jepa64", 256, 4, 3)):
+        cfg = ot.make_config(E, depth, H, 14, 56, False, True, "jepa")
+        m = ref_jepa.VisionTransformer(img_size=[56], patch_size=14, embed_dim=E, depth=depth, num_heads=H, mlp_ratio=4,
+                                       qkv_bias=True, norm_layer=ln)
+        run(tag, m, cfg, m.forward, 3)
+    cfg = ot.make_config(256, 2, 4, 16, 64, True, False, "learned")
+    m = ref_mae.VisionTransformer(num_classes=0, img_size=64, patch_size=16, embed_dim=256, depth=2, num_heads=4, mlp_ratio=4,
+                                  qkv_bias=True, norm_layer=ln)
+    run("mae", m, cfg, m.forward_features, 2)
+    cfg = ot.make_config(256, 2, 4, 16, 64, True, True, "moco")
+    m = ref_moco.VisionTransformerMoCo(img_size=64, patch_size=16, embed_dim=256, depth=2, num_heads=4, mlp_ratio=4,
+                                       qkv_bias=True, norm_layer=ln)
+    run("moco", m, cfg, lambda x: m.forward_features(x)[:, 1:], 2)
+    # the real grids' tables
+    pe = torch.from_numpy(ref_jepa.get_2d_sincos_pos_embed(1280, 16, cls_token=False)).float()
+    out["jepa_pos_1280_rows"], out["jepa_pos_1280_sum"] = pe[::17].numpy(), pe.double().sum(0).numpy()
+    mb = ref_moco.vit_base()
+    out["moco_pos_768_rows"], out["moco_pos_768_sum"] = mb.pos_embed[0, ::17].detach().numpy(), mb.pos_embed[0].double().sum(0).detach().numpy()
+    # preprocess geometry: /255 -> normalise -> bicubic (dinov2 / jepa order) on a fixed ramp, and the no-resample branch
+    raw = (torch.arange(2 * 3 * 256 * 256) % 251).reshape(2, 3, 256, 256).to(torch.uint8)
+    xr = raw.float() / 255.
+    mean = torch.tensor(ot.IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(ot.IMAGENET_STD).view(1, 3, 1, 1)
+    xn = (xr - mean) / std
+    out["pre.jepa.sample"] = torch.nn.functional.interpolate(xn, 224, mode="bicubic")[:, :, ::37, ::41].numpy()
+    out["pre.mae.sample"] = xn[:, :, ::37, ::41].numpy()
+    save("towers", **out)
+
+
 def make_tiny_dataset(root, n=6, text_dim=16):
     """Deterministic tiny dataset in the reference's on-disk format (image/dataset.py:18-85; written by
     preprocessing/dataset_tools.py): images/XXXXX/imgNNNNNNNN.png, vae-sd/XXXXX/img-mean-std-NNNNNNNN.npy,
@@ -564,7 +665,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "clip": g_clip, "dataset": g_dataset}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "clip": g_clip, "dataset": g_dataset, "towers": g_towers}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
