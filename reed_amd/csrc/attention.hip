@@ -643,6 +643,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(const bf16* __restr
 
 // ------------------------------------------------------------------------------------------
 // Backward, T <= 256: one workgroup per (batch, head), Q, K, V, dO resident (4 x 36 KiB), every operand read from HBM once.
+// Three other forms were built in round 2, passed every test and lost on the same box (attention;
+// profiles/r2_pmc_attention.txt): (a) four 80-KiB workgroups per item (dQ / dK,dV roles x halves, two per CU): 2.7 GB of
+// requests per launch instead of 1.2 GB, 600 us; (b) this kernel with 16 waves of 16 rows at 128 VGPRs: every fragment
+// read feeds one MFMA instead of two, LDS traffic doubles, 630 us; (c) a persistent key-stationary kernel (4 waves x 64
+// keys with the 512-register file, Q / dO / O streamed through an LDS-DMA ring across items, S and dP computed once, dQ
+// by an fp32 exchange): 631 us — 224 v_accvgpr_read per chunk and one wave per SIMD with nothing to hide its waits.
 // Two forms that give up the single read were built in round 2, passed the tests and lost (attention):
 // four 80-KiB workgroups per item with 16-row waves, two per CU (dQ / dK,dV roles; each role re-reads all operands:
 // 2.7 GB per launch against 1.2 GB, 600 us), and this kernel with 16 waves of 16 rows at 128 VGPRs (every fragment read

@@ -310,3 +310,43 @@ def test_train_with_on_device_clip_encoder(dev, tmp_path, monkeypatch):
     logs2 = [json.loads(l) for l in open(os.path.join(d2, "metrics.jsonl"))]
     assert len(logs2) == 3 and all(np.isfinite(r["proj_loss"]) for r in logs2)
     torch.set_grad_enabled(True)
+
+
+def test_train_with_on_device_jepa_and_mae_towers(dev, tmp_path, monkeypatch):
+    """train.py counterpart with TWO frozen image encoders running on the GPU every step (--enc-type jepa-vit-h,mae-vit-l
+    --encoder-ckpts a b; image/train.py:182-186,351-357 with the jepa / mae branches of preprocess_raw_image and
+    load_encoders): 1-block towers of the real widths stand in; checkpoints in the reference's file layouts
+    ({'encoder': {'module.*'}} for I-JEPA, utils.py:153-158; {'model': ...} for MAE, utils.py:137-145)."""
+    import PIL.Image
+    from oracle import vit_towers as ot
+    from reed_amd import encoders, train
+    data = tmp_path / "data"
+    (data / "images" / "00000").mkdir(parents=True)
+    (data / "vae-sd" / "00000").mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    labels = []
+    for i in range(8):
+        PIL.Image.fromarray(rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)).save(data / "images" / "00000" / f"img{i:08d}.png")
+        mom = np.concatenate([rng.standard_normal((4, 32, 32)) * 5.0, np.full((4, 32, 32), 0.5)]).astype(np.float32)
+        np.save(data / "vae-sd" / "00000" / f"img-mean-std-{i:08d}.npy", mom)
+        labels.append([f"00000/img-mean-std-{i:08d}.npy", int(i % 5)])
+    json.dump({"labels": labels}, open(data / "vae-sd" / "dataset.json", "w"))
+    cks = []
+    for key, wrap in (("jepa-vit-h", lambda sd: {"encoder": {"module." + k: v for k, v in sd.items()}}),
+                      ("mae-vit-l", lambda sd: {"model": sd})):
+        kw = dict(encoders.VIT_TOWERS[key], depth=1)
+        monkeypatch.setitem(encoders.VIT_TOWERS, key, kw)
+        P = ot.fill_params(ot.make_config(pos="jepa" if "jepa" in key else "learned", **kw), base_seed=2)
+        path = str(tmp_path / (key + ".pth"))
+        torch.save(wrap(P), path)
+        cks.append(path)
+    a = train.parse_args(["--exp-name", "towers", "--model", "SiT-S/2", "--output-dir", str(tmp_path / "exps"),
+                          "--data-dir", str(data), "--enc-type", "jepa-vit-h,mae-vit-l", "--encoder-ckpts", cks[0], cks[1],
+                          "--repa-coeff", "1.0", "0.5", "--mixed-precision", "bf16", "--batch-size", "4", "--num-workers", "0",
+                          "--diffusion-warm-up-steps", "0", "--report-to", "none", "--max-train-steps", "2",
+                          "--num-classes", "5", "--checkpointing-steps", "100"])
+    d = train.main(a)
+    logs = [json.loads(l) for l in open(os.path.join(d, "metrics.jsonl"))]
+    assert len(logs) == 2 and all(np.isfinite(r["proj_loss"]) and np.isfinite(r["training_denoising_loss"]) for r in logs)
+    assert logs[0]["img_proj_loss"] != 0.0
+    torch.set_grad_enabled(True)
