@@ -294,7 +294,7 @@ def main():
     bk = L.buckets()
     dp = {"world": world, "buckets": len(bk), "gradient_bytes": int(4 * L.n_train),
           "largest_bucket_bytes": int(4 * max(e - b0 for _, (b0, e) in bk)),
-          "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "NCCL_", "RCCL_"))}}
+          "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}
     if reducer is not None:
         try:
             dp.update(dp_consistency(reducer, opt, model, world, b))

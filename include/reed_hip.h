@@ -25,6 +25,9 @@ extern "C" {
 
 const char* reed_last_error(void);
 int reed_version(void);
+/* 0: this library was built with bfloat16 operands (libreed_hip.so: the training path); 1: IEEE half operands
+ * (libreed_hip_f16.so, the same sources with -DREED_FP16: the sampling path at the mantissa of the reference's TF32) */
+int reed_half_kind(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense contractions (every nn.Linear on the path: sit.py:17-24 projector, :38-42 t-MLP,

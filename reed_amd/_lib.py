@@ -9,9 +9,12 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # REED_HIP_LIB: same-box A/B of two builds of the library (tools/); the product loads the in-tree one
 LIB_PATH = os.environ.get("REED_HIP_LIB") or os.path.join(_HERE, "libreed_hip.so")
+# the same sources built with IEEE-half operands (csrc/common.hpp, -DREED_FP16): the sampling path
+LIB_PATH_F16 = os.environ.get("REED_HIP_LIB_F16") or os.path.join(_HERE, "libreed_hip_f16.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "reed_hip.h")
 
 _lib = None
+_libs = {}
 
 _CT = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
@@ -40,19 +43,21 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
-def load():
+def load(precision="bf16"):
+    """precision "bf16": libreed_hip.so (training and everything else); "fp16": libreed_hip_f16.so (sampling)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if precision in _libs:
+        return _libs[precision]
+    path = {"bf16": LIB_PATH, "fp16": LIB_PATH_F16}[precision]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"reed_amd: {LIB_PATH} not found. Build it with `python -m reed_amd.build` "
+            f"reed_amd: {path} not found. Build it with `python -m reed_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
     # PyTorch-ROCm wheels bundle their own libamdhip64 / librccl. Import torch FIRST so that our NEEDED entries
     # resolve (by SONAME) to the runtime torch already loaded: one HIP runtime and one RCCL per process. Loading
     # /opt/rocm's copies first makes torch fail later with "no ROCm-capable device is detected".
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     missing = []
     for name, (restype, args) in parse_header().items():
         try:
@@ -63,11 +68,15 @@ def load():
         fn.restype = restype
         fn.argtypes = [t for t, _ in args]
     lib._reed_missing = missing  # tests assert this is empty; calling a missing symbol raises
-    _lib = lib
+    if not missing and lib.reed_half_kind() != {"bf16": 0, "fp16": 1}[precision]:
+        raise RuntimeError(f"reed_amd: {path} was not built for {precision} operands")
+    _libs[precision] = lib
+    if precision == "bf16":
+        _lib = lib
     return lib
 
 
-def check(rc, what=""):
+def check(rc, what="", lib=None):
     if rc != 0:
-        msg = load().reed_last_error()
+        msg = (lib or load()).reed_last_error()
         raise RuntimeError(f"reed_hip {what} failed (code {rc}): {msg.decode() if msg else ''}")

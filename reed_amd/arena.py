@@ -163,16 +163,22 @@ class ParamArena:
             self.grad = torch.zeros(self.layout.n_train, dtype=torch.float32, device=self.device)
         return self.grad
 
-    def ensure_shadow(self):
-        """bf16 copy of the master weights (GEMM operands). Refreshed when the master changed through torch
-        (version counter) — the fused optimiser rewrites it itself and calls mark_shadow_fresh()."""
+    def ensure_shadow(self, precision="bf16"):
+        """16-bit copy of the master weights (GEMM operands; bf16, or IEEE half for a model sampling at
+        precision="fp16"). Refreshed when the master changed through torch (version counter) — the fused optimiser
+        rewrites the bf16 one itself and calls mark_shadow_fresh()."""
         from . import ops
-        if self.shadow is None:
-            self.shadow = torch.empty(self.layout.n_total, dtype=torch.bfloat16, device=self.device)
+        dt = ops.half_dtype(precision)
+        if self.shadow is None or self.shadow.dtype != dt:
+            self.shadow = torch.empty(self.layout.n_total, dtype=dt, device=self.device)
             self.shadow_version = -1
         if self.shadow_version != self.master._version:
             self.wait_all()   # an overlapped optimiser step may still be rewriting the master
-            ops.cast_bf16(self.master, self.shadow, self.layout.n_total)
+            prev = ops.use(precision)
+            try:
+                ops.cast_bf16(self.master, self.shadow, self.layout.n_total)
+            finally:
+                ops.use(prev)
             self.shadow_version = self.master._version
         return self.shadow
 

@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libreed_hip.so")
+# the same sources with IEEE-half operands (-DREED_FP16, csrc/common.hpp): the sampling path at TF32's mantissa
+LIB_F16 = os.path.join(HERE, "libreed_hip_f16.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result",
@@ -25,12 +27,13 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src + ".o")
+def _compile(job):
+    src, f16 = job
+    obj = os.path.join(OBJ, src + (".f16.o" if f16 else ".o"))
     srcp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + CFLAGS + ["-x", "hip", "-c", srcp, "-o", obj]
+    cmd = [HIPCC] + CFLAGS + (["-DREED_FP16"] if f16 else []) + ["-x", "hip", "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -40,19 +43,21 @@ def _compile(src):
 def build(verbose=True, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     srcs = _sources()
-    jobs = jobs or min(8, len(srcs))
+    jobs = jobs or 8
     with ThreadPoolExecutor(jobs) as ex:
-        res = list(ex.map(_compile, srcs))
-    objs = [o for o, _ in res]
-    rebuilt = any(c for _, c in res)
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + \
-              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    if verbose:
-        print(f"[reed_amd.build] {LIB} ({'rebuilt' if rebuilt else 'up to date'}; {len(srcs)} sources)")
+        res = list(ex.map(_compile, [(s, f) for f in (False, True) for s in srcs]))
+    n = len(srcs)
+    for lib, part in ((LIB, res[:n]), (LIB_F16, res[n:])):
+        objs = [o for o, _ in part]
+        rebuilt = any(c for _, c in part)
+        if rebuilt or not os.path.exists(lib):
+            cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + \
+                  ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-Bsymbolic"]   # both libraries export
+            r = subprocess.run(cmd, capture_output=True, text=True)                            # the same names
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[reed_amd.build] {lib} ({'rebuilt' if rebuilt else 'up to date'}; {n} sources)")
     return LIB
 
 

@@ -18,6 +18,7 @@ extern "C" void reed_set_error(const char* fmt, ...) {
 
 extern "C" const char* reed_last_error(void) { return g_err; }
 extern "C" int reed_version(void) { return 100; }
+extern "C" int reed_half_kind(void) { return REED_HALF_KIND; }   // 0: bfloat16 operands (libreed_hip.so), 1: IEEE half (libreed_hip_f16.so)
 
 extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* Q,
                          int64_t ldq, int M, int N, int K, void* C, int64_t ldc, void* C2,

@@ -136,8 +136,8 @@ __device__ __forceinline__ bf16x8 frag_rows_f(const char* tile, int row0, int ks
 __device__ __forceinline__ bf16x8 frag_trT_f(const char* tile, int rbase, int d0, int lane) {
   int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
   const char* a0 = tile + (rbase + 4 * g + q) * ROWF + (d0 + 4 * p) * 2;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 16 * ROWF));
+  bf16x4 lo = REED_DS_READ_TR16_B64((bf16x4 __attribute__((address_space(3)))*)a0);
+  bf16x4 hi = REED_DS_READ_TR16_B64((bf16x4 __attribute__((address_space(3)))*)(a0 + 16 * ROWF));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // lane (i, g): X[rbase + 16*(j>>2) + 4g + (j&3)][d0 + i], j = 0..7 — the k-slot order in which an
@@ -145,8 +145,8 @@ __device__ __forceinline__ bf16x8 frag_trT_f(const char* tile, int rbase, int d0
 __device__ __forceinline__ bf16x8 frag_trT(const char* tile, int rbase, int d0, int lane) {
   int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
   const char* a0 = tile + (rbase + 4 * g + q) * ROWB + (d0 + 4 * p) * 2;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a0);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0 + 16 * ROWB));
+  bf16x4 lo = REED_DS_READ_TR16_B64((bf16x4 __attribute__((address_space(3)))*)a0);
+  bf16x4 hi = REED_DS_READ_TR16_B64((bf16x4 __attribute__((address_space(3)))*)(a0 + 16 * ROWB));
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 template <int HD>
@@ -175,7 +175,7 @@ __device__ __forceinline__ bf16x8 pack2(f32x4 a, f32x4 b) {
   return r;
 }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA(a, b, c) REED_MFMA_16x16x32((a), (b), (c))
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  One (batch, head) reads 144-byte (hd 72) or
 // 128-byte pieces of every token row of qkv, so the cache lines it touches are shared with the neighbouring heads of

@@ -3,10 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit operand type of every kernel.  The product library (libreed_hip.so) is built with bfloat16 — the reference's
+// training precision under accelerate bf16 autocast.  The SAME sources build a second library (libreed_hip_f16.so,
+// -DREED_FP16) with IEEE half operands for the sampling path: the reference samples with an fp32 model under TF32
+// (image/generate.py:41,183), whose 10-bit mantissa is half's, at the same MFMA rate as bf16 (v_mfma_f32_16x16x32_f16).
+// The type keeps its name `bf16` in the sources ("the 16-bit operand"); only this block knows which one it is.
+#ifdef REED_FP16
+typedef _Float16 bf16;
+#define REED_HALF_KIND 1
+#define REED_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
 typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define REED_HALF_KIND 0
+#define REED_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define REED_DS_READ_TR16_B64(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p)
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
+#ifdef REED_FP16   // the typed builtin of the transposing LDS read wants clang's __fp16 vector
+typedef __fp16 reed_tr16_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define REED_DS_READ_TR16_B64(p) \
+  __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((reed_tr16_t __attribute__((address_space(3)))*)(p)))
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 

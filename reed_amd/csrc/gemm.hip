@@ -150,12 +150,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks][j], pf[ks][i], acc[i][j], 0, 0, 0);
+          acc[i][j] = REED_MFMA_16x16x32(qf[ks][j], pf[ks][i], acc[i][j]);
       if constexpr (LAY == LAY_TN) {
         if (do_dbias) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[ks][i], accb[i], 0, 0, 0);
+            accb[i] = REED_MFMA_16x16x32(ones, pf[ks][i], accb[i]);
         }
       }
     }

@@ -311,12 +311,12 @@ __global__ __launch_bounds__(LW ? 768 : 512) void gemm144_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(1);                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
-      accm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Bf[j]),                \
-                                                           __builtin_bit_cast(bf16x8, Af[i]), accm[i][j], 0, 0, 0); \
+      accm[i][j] = REED_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Bf[j]),                \
+                                                           __builtin_bit_cast(bf16x8, Af[i]), accm[i][j]); \
     if (wc == 0) {                                                                                           \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-        accx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Bf[4]),                 \
-                                                          __builtin_bit_cast(bf16x8, Af[i]), accx[i], 0, 0, 0); \
+        accx[i] = REED_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Bf[4]),                 \
+                                                          __builtin_bit_cast(bf16x8, Af[i]), accx[i]); \
     }                                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)

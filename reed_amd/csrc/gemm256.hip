@@ -193,7 +193,7 @@ __device__ __forceinline__ void gemm256_body(const GemmArgs& a, char* smem, cons
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
       acc[(MH) * 4 + i][(NH) * 2 + j] =                                                           \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ks], AF[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+          REED_MFMA_16x16x32(BF[j][ks], AF[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 
@@ -373,12 +373,20 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
+// CUs the tile heuristics plan for.  REED_GEMM_CUS overrides the device's count: while a gradient bucket is in flight RCCL's
+// channels hold CUs, and a grid planned as exactly one round of 256 workgroups (the 256x144 tile at b = 32 per GPU) turns
+// into two rounds on what is left — set e.g. REED_GEMM_CUS=240 for the data-parallel run if the 8-GPU trace shows that
+// (bench.py reports the value under data_parallel.env).
 int reed_num_cus() {
   static int n = 0;
   if (!n) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    const char* e = getenv("REED_GEMM_CUS");
+    if (e && atoi(e) > 0) n = atoi(e);
+    if (!n) {
+      int dev = 0;
+      hipDeviceProp_t p;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    }
     if (n <= 0) n = 256;
   }
   return n;

@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TNN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = REED_MFMA_16x16x32(qf[j], pf[i], acc[i][j]);
     if (do_dbias) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], accb[i], 0, 0, 0);
+      for (int i = 0; i < TM; ++i) accb[i] = REED_MFMA_16x16x32(ones, pf[i], accb[i]);
     }
     __syncthreads();
   }

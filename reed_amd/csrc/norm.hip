@@ -262,15 +262,13 @@ struct HalfRow {
   __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const {   // bf16 -> f32
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-      u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] * 2, soff, 0);
-      v[4 * k + 0] = __builtin_bit_cast(float, t[0] << 16);
-      v[4 * k + 1] = __builtin_bit_cast(float, t[0] & 0xFFFF0000u);
-      v[4 * k + 2] = __builtin_bit_cast(float, t[1] << 16);
-      v[4 * k + 3] = __builtin_bit_cast(float, t[1] & 0xFFFF0000u);
+      const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] * 2, soff, 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * k + j] = bf2f(t[j]);
     }
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      v[4 * NF + t] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, vo[NF + t] * 2, soff, 0) << 16);
+      v[4 * NF + t] = bf2f(__builtin_bit_cast(bf16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo[NF + t] * 2, soff, 0)));
   }
   __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const {
 #pragma unroll

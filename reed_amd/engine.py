@@ -93,6 +93,16 @@ class Engine:
 
     # ---- forward -------------------------------------------------------------------
     def forward(self, x, t, y, inference, need_grad, drop):
+        prec = getattr(self.m, "precision", "bf16")
+        if prec != "bf16" and need_grad:
+            raise RuntimeError("reed_amd.SiT: precision='fp16' is the sampling path (inference only); training runs in bf16")
+        prev = ops.use(prec)
+        try:
+            return self._forward(x, t, y, inference, need_grad, drop, prec)
+        finally:
+            ops.use(prev)
+
+    def _forward(self, x, t, y, inference, need_grad, drop, prec):
         m, L = self.m, self.L
         ops.require_cuda(x, "x")
         dev = x.device
@@ -101,7 +111,8 @@ class Engine:
         if C != self.C or HW != m.input_size or x.shape[-2] != HW:
             raise ValueError(f"input {tuple(x.shape)} does not match (N,{self.C},{m.input_size},{m.input_size})")
         M = B * T
-        self._shadow = self.A.ensure_shadow()
+        self._shadow = self.A.ensure_shadow(prec)
+        hdt = ops.half_dtype(prec)
         pend = self.A.pending   # parameter buckets an overlapped optimiser step is still rewriting (optim.py)
         if "all" in pend:
             self.A.wait_all()
@@ -112,7 +123,7 @@ class Engine:
         y = y.contiguous().long()
 
         def bf(*s):
-            return torch.empty(s, dtype=torch.bfloat16, device=dev)
+            return torch.empty(s, dtype=hdt, device=dev)
 
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
@@ -244,7 +255,8 @@ class Engine:
         img = m.z_types[j] == "i"
         self.A.wait("projectors")
         R = B * T if img else B
-        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)  # noqa: E731
+        hdt = ops.half_dtype()   # the build Engine.forward selected
+        bf = lambda *s: torch.empty(s, dtype=hdt, device=dev)  # noqa: E731
         xin = bf(R, D)
         if img:
             ops.ln_modulate_fwd(x, None, None, 0, xin, None, None, R, D, T)  # f32 -> bf16 cast (autocast input cast)

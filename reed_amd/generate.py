@@ -62,7 +62,11 @@ def build_parser():
     from .models.sit import SiT_models
     parser = argparse.ArgumentParser()
     parser.add_argument("--global-seed", type=int, default=0)
-    parser.add_argument("--tf32", action=argparse.BooleanOptionalAction, default=True)  # accepted, no effect on gfx950
+    # The reference samples with an fp32 model and, with --tf32 (its default), TF32 matmuls (generate.py:41,183: 10-bit
+    # mantissa operands, fp32 accumulation).  The MFMA equivalent at full rate is IEEE-half operands with fp32 accumulation:
+    # --tf32 selects the fp16 build of the kernels for the model evaluations (libreed_hip_f16.so), --no-tf32 too (there is no
+    # fp32-operand path: the flag is accepted for compatibility).  --sample-precision bf16 evaluates in the training precision.
+    parser.add_argument("--tf32", action=argparse.BooleanOptionalAction, default=True)
     parser.add_argument("--ckpt", type=str, default=None, help="Optional path to a SiT checkpoint.")
     parser.add_argument("--sample-dir", type=str, default="samples")
     parser.add_argument("--model", type=str, choices=list(SiT_models.keys()), default="SiT-XL/2")
@@ -86,6 +90,9 @@ def build_parser():
     parser.add_argument("--prediction", type=str, default="v", choices=["v"])
     # additive
     parser.add_argument("--save-latents", action="store_true", help="write latents .npz instead of decoding to PNG")
+    parser.add_argument("--sample-precision", type=str, choices=["fp16", "bf16"], default="fp16",
+                        help="16-bit operand type of the model evaluations: fp16 = 10-bit mantissa (the reference's TF32), "
+                             "bf16 = the training precision")
     return parser
 
 
@@ -122,6 +129,7 @@ def main(args):
             state_dict.pop(k)
     model.load_state_dict(state_dict, strict=False)
     model.eval()
+    model.precision = args.sample_precision
     assert args.cfg_scale >= 1.0, "In almost all cases, cfg_scale be >= 1.0"
     if args.cfg_scale > 1.0:
         assert args.num_classes == 1000, "the samplers hard-code the null class id 1000 (samplers.py:59)"

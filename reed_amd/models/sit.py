@@ -92,6 +92,9 @@ class SiT(nn.Module):
         self._build_tree(shapes)
         self.initialize_weights()
         self.force_drop_mask = None  # tests: bool [N] replacing LabelEmbedder's torch.rand draw
+        # 16-bit operand type of the kernels: "bf16" (training; the reference under accelerate bf16) or "fp16" (inference only:
+        # the sampling path at the mantissa of the reference's TF32, generate.py --sample-precision; csrc/common.hpp REED_FP16)
+        self.precision = "bf16"
 
     # ------------------------------------------------------------------ structure
     def _param_shapes(self):

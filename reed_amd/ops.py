@@ -30,9 +30,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Which build of the library the calls go to: "bf16" (libreed_hip.so) or "fp16" (libreed_hip_f16.so, the same sources with
+# IEEE-half operands: the sampling path).  The engine selects it per forward from the model's `precision`; torch tensors
+# handed to the kernels must then be torch.float16 where the bf16 build takes torch.bfloat16 (half_dtype()).
+_PRECISION = "bf16"
+
+
+def use(precision):
+    """Select the library build for the following calls; returns the previous selection."""
+    global _PRECISION
+    if precision not in ("bf16", "fp16"):
+        raise ValueError(f"precision {precision!r}: 'bf16' or 'fp16'")
+    prev, _PRECISION = _PRECISION, precision
+    return prev
+
+
+def half_dtype(precision=None):
+    return torch.float16 if (precision or _PRECISION) == "fp16" else torch.bfloat16
+
+
 def _call(name, *args):
-    L = _lib.load()
-    _lib.check(getattr(L, name)(*args), name)
+    L = _lib.load(_PRECISION)
+    _lib.check(getattr(L, name)(*args), name, L)
 
 
 def require_cuda(t, name="tensor"):

@@ -20,11 +20,12 @@ def test_library_exports_every_header_symbol():
     from reed_amd import _lib
     protos = _lib.parse_header()
     assert len(protos) >= 40
-    lib = _lib.load()
-    assert lib._reed_missing == [], lib._reed_missing
-    assert lib.reed_version() == 100
-    for name in protos:
-        assert hasattr(lib, name)
+    for prec, kind in (("bf16", 0), ("fp16", 1)):   # the product library and its IEEE-half build (the sampling path)
+        lib = _lib.load(prec)
+        assert lib._reed_missing == [], lib._reed_missing
+        assert lib.reed_version() == 100 and lib.reed_half_kind() == kind
+        for name in protos:
+            assert hasattr(lib, name)
 
 
 def test_arg_errors_do_not_need_a_gpu():

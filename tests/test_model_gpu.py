@@ -238,20 +238,25 @@ def test_c2_xl2_trajectory_vs_reference_bf16(dev):
 
 
 # measured (round 2): every probe's norm within 1e-4 of the reference's bf16-autocast gradient, slice cosines >= 0.99998
+FP16_EVAL_BAR = 1.2e-3
 XL_GRAD_NORM_BAR = 0.002
 XL_GRAD_COS_BAR = 0.9999
 
 
-def test_xl2_cfg_inference_vs_reference(dev):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_xl2_cfg_inference_vs_reference(dev, precision):
     """C5 at its real size: the CFG-doubled no-tap evaluation of SiT-XL/2 exactly as samplers.py:66-78 issues it
     ([x; x], labels [y; 1000]) at two times, against the reference in fp32 and under bf16 autocast
-    (tools/gen_golden.py:g_xl_infer), plus 3 Heun steps with CFG 1.5 on top (5 evaluations, fp64 state)."""
+    (tools/gen_golden.py:g_xl_infer), plus 3 Heun steps with CFG 1.5 on top (5 evaluations, fp64 state).
+    precision="fp16": the sampling build (IEEE-half operands, generate.py's default: the mantissa of the reference's TF32
+    evaluations) — its deviation from the fp32 reference must be several times below the bf16 path's."""
     from reed_amd.models.sit import SiT_models
     from reed_amd.samplers import euler_sampler
     g = load("xl2_infer")
     m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8, use_cfg=True)
     detfill.fill_state_dict(m.state_dict(), base_seed=0)
     m = m.to(dev).eval()
+    m.precision = precision
     x, _, _, y, _, _ = inputs(2, 4, 32, 77, [], 256, 1000)
     xx, yy = torch.cat([x, x]).to(dev), torch.cat([y, torch.tensor([1000, 1000])]).to(dev)
     for tv in (0.9, 0.35):
@@ -262,22 +267,27 @@ def test_xl2_cfg_inference_vs_reference(dev):
         rf, rb = torch.from_numpy(g[f"fp32.t{tv}"]), torch.from_numpy(g[f"bf16.t{tv}"])
         sc = rf.abs().max().item()
         e_b, e_f, e_ref = (o - rb).abs().max().item() / sc, (o - rf).abs().max().item() / sc, (rb - rf).abs().max().item() / sc
-        print(f"XL/2 CFG eval t={tv}: max|HIP-ref_bf16| {e_b:.2e}  max|HIP-ref_fp32| {e_f:.2e}  "
+        print(f"XL/2 CFG eval [{precision}] t={tv}: max|HIP-ref_bf16| {e_b:.2e}  max|HIP-ref_fp32| {e_f:.2e}  "
               f"(reference's own bf16-vs-fp32 {e_ref:.2e}), all relative to max|v| = {sc:.3f}; "
               f"cos vs fp32 {cos(o, rf):.6f}")
         # max-abs over 16 K elements is the tail of the bf16 noise of BOTH sides (measured e_b 3.4e-3 .. 6.8e-3 across two
         # forward kernels with the same cosine); the cosine is the stable statistic
-        assert e_f <= 1.3 * e_ref + 5e-4 and e_b <= 2.0 * e_ref and cos(o, rf) > 0.9999 and cos(o, rb) > 0.9999
+        if precision == "bf16":
+            assert e_f <= 1.3 * e_ref + 5e-4 and e_b <= 2.0 * e_ref and cos(o, rf) > 0.9999 and cos(o, rb) > 0.9999
+        else:   # 3 more mantissa bits: measured 6.6e-4 of the scale (bf16: 4.8e-3), cosine 0.9999998
+            assert e_f <= FP16_EVAL_BAR and cos(o, rf) > 0.999999
     with torch.no_grad():
         s = euler_sampler(m, x.to(dev), y.to(dev), num_steps=3, heun=True, cfg_scale=1.5).cpu()
     ref = torch.from_numpy(g["heun3_cfg"])
     err = (s - ref).abs().max().item()
-    print(f"XL/2 3-step Heun + CFG 1.5: max abs deviation from the fp32 reference {err:.3e} (latent scale {ref.abs().max().item():.2f})")
-    assert s.dtype == torch.float64 and err <= 4e-3 * ref.abs().max().item()     # measured 2.0e-3 of the scale
+    print(f"XL/2 3-step Heun + CFG 1.5 [{precision}]: max abs deviation from the fp32 reference {err:.3e} (latent scale {ref.abs().max().item():.2f})")
+    assert s.dtype == torch.float64
+    assert err <= (4e-3 if precision == "bf16" else 6e-4) * ref.abs().max().item()     # measured 2.0e-3 / see print
 
 
-def test_long_horizon_heun_cfg_drift_s2(dev):
-    """What the bf16 model costs over a long sampling horizon: SiT-S/2, n = 2, 50-step Heun with CFG 1.5 over the whole
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_long_horizon_heun_cfg_drift_s2(dev, precision):
+    """What the 16-bit model evaluations cost over a long sampling horizon: SiT-S/2, n = 2, 50-step Heun with CFG 1.5 over the whole
     interval (99 evaluations at batch 4), HIP (bf16 operands, fp64 state) against the reference with an fp32 model
     (tools/gen_golden.py:g_samplers_long). The state fed to every 9th evaluation is compared: the printed curve is the
     drift; the bound asserted is on its end point, relative to the latents' scale."""
@@ -287,6 +297,7 @@ def test_long_horizon_heun_cfg_drift_s2(dev):
     m = SiT_models["SiT-S/2"](z_dims=[768], z_types=["i"], encoder_depth=8, use_cfg=True)
     detfill.fill_state_dict(m.state_dict(), base_seed=3)
     m = m.to(dev).eval()
+    m.precision = precision
     z = detfill.normal((2, 4, 32, 32), 91).to(dev)
     y = torch.tensor([17, 833], device=dev)
     states = []
@@ -309,17 +320,18 @@ def test_long_horizon_heun_cfg_drift_s2(dev):
     ref = torch.from_numpy(g["final"])
     scale = ref.abs().max().item()
     end = (out - ref).abs().max().item()
-    print("drift of the bf16-operand sampler vs the fp32 reference, max abs, at evaluations 0, 9, ..., 90:",
+    print(f"drift of the {precision}-operand sampler vs the fp32 reference, max abs, at evaluations 0, 9, ..., 90:",
           " ".join(f"{c:.2e}" for c in curve), f"| final {end:.3e} (latent scale {scale:.2f}, rms "
           f"{(out - ref).pow(2).mean().sqrt().item():.3e})")
     assert curve[0] == 0.0
-    assert end <= LONG_DRIFT_BAR * scale
+    assert end <= (LONG_DRIFT_BAR if precision == "bf16" else LONG_DRIFT_BAR_FP16) * scale
 
 
 # measured (round 2): the drift grows linearly in t to 5.8e-3 abs = 1.4e-3 of the latents' scale (rms 3.7e-4 of it) at the
 # end of the trajectory; it is the integral of the bf16 evaluation error over the unit time interval, so a 250-step run
 # ends in the same place (sampling precision)
 LONG_DRIFT_BAR = 3e-3
+LONG_DRIFT_BAR_FP16 = 5e-4
 
 
 def test_wgrad_side_stream_bit_identical(dev):
@@ -559,3 +571,44 @@ def test_gradient_accumulation_matches_full_batch(dev):
     dw = (out[1][1][:nt] - out[2][1][:nt])[big]
     assert (dw.abs() > 1e-6).float().mean().item() < 0.02
     torch.testing.assert_close(out[2][2], out[1][2], atol=1e-6, rtol=0)
+
+
+def test_fp16_is_inference_only_and_switch_restores(dev):
+    """precision='fp16' (the sampling build) refuses a training forward, and the library selection is restored after every
+    forward: a bf16 training step right after an fp16 evaluation of another model is bit-identical to one without it."""
+    from reed_amd import ops
+    from reed_amd.loss import SILoss
+    c = TINY_CASES["hd64"]
+    cfg = c["cfg"]
+    T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 13, c["zspec"], T, cfg["num_classes"])
+    lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
+
+    def step(m):
+        m.train()
+        m.force_drop_mask = drop_u < 0.1
+        for p in m.parameters():
+            p.grad = None
+        m.engine().zero_grad()
+        out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+        (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+        torch.cuda.synchronize()
+        return m._arena.grad.clone()
+
+    m = build_hip_model(cfg, dev, 13)
+    g0 = step(m)
+    s = build_hip_model(cfg, dev, 14).eval()
+    s.precision = "fp16"
+    with torch.no_grad():
+        o16, _ = s(x.to(dev), t.to(dev), y.to(dev))
+    s.precision = "bf16"
+    with torch.no_grad():
+        ob, _ = s(x.to(dev), t.to(dev), y.to(dev))
+    assert ops._PRECISION == "bf16"
+    assert torch.isfinite(o16).all() and 0 < (o16 - ob).abs().max().item() < 0.1 * ob.abs().max().item()
+    assert torch.equal(step(m), g0)
+    s.precision = "fp16"
+    s.train()
+    with pytest.raises(RuntimeError):
+        lf(s, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+    assert ops._PRECISION == "bf16"
