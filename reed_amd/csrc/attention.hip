@@ -390,6 +390,15 @@ __device__ __forceinline__ bf16x8 frag_trT_off(const char* lane_base) {
   bf16x4 hi = tr16_asm_off<OFF + 16 * RB>(lane_base);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// lane (i, g): X[rbase + 16 (j >> 2) + 4 g + (j & 3)][d0 + i], j = 0..7 (frag_trT through the asm read, any row stride)
+template <int RB>
+__device__ __forceinline__ bf16x8 frag_trT_a(const char* tile, int rbase, int d0, int lane) {
+  const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+  const char* a0 = tile + (rbase + 4 * g + q) * RB + (d0 + 4 * p) * 2;
+  bf16x4 lo = tr16_asm_off<0>(a0);
+  bf16x4 hi = tr16_asm_off<16 * RB>(a0);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 // O^T += V^T P^T over 32-key steps, software pipelined: the V^T fragments of step S + 1 are read (asm, unordered by the
 // compiler) before the MFMAs of step S issue, and waited for behind them
 template <int RB, int S, int NDT, int... DTS>
@@ -678,54 +687,52 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
 
-  {
-    // Every global load of the load phase is issued before the first wait: the four tiles (18 x 16 B per thread), the
-    // O / dO row halves of the delta sum and the log-sum-exp.  One workgroup per CU means nothing else hides HBM latency
-    // here, and as four load_tile calls + the delta loop this phase was ~10 dependent round trips = 60 % of the kernel.
-    TileRegs<HD> rq, rk, rv, rg;
-    constexpr int NH = (NCH + 1) / 2;
-    const int row = tid >> 1, half = tid & 1;
-    const int rcl = min(row, T - 1);
-    bf16x8 ov[NH], gv[NH];
-    float lsev = 0.f;
-    tile_issue<HD>(rq, base, tok, T, tid);
-    tile_issue<HD>(rk, base + D, tok, T, tid);
-    tile_issue<HD>(rv, base + 2 * D, tok, T, tid);
-    tile_issue<HD>(rg, d_o + (long)b * T * D + h * HD, D, T, tid);
-    {
-      const bf16* orow = o + ((long)b * T + rcl) * D + h * HD;
-      const bf16* grow = d_o + ((long)b * T + rcl) * D + h * HD;
+  // Load phase, round 2: the four tiles arrive by LDS-DMA (nothing staged in registers) in two pairs, 9 pieces per wave
+  // and pair: K, V first — phase 1 (dQ) reads them — then this wave's own query rows straight into registers (Q and dO
+  // fragments, the O rows of its delta = rowsum(dO * O), the log-sum-exp), then Q, dO, which only phase 2 needs: they
+  // land while phase 1 computes.  The wait before phase 1 is counted (the Q / dO pieces stay in flight).
+  const int r0 = wave * 32;  // this wave's 32 rows (queries in phase 1, keys in phase 2)
+  const bf16* gbase = d_o + (long)b * T * D + h * HD;
+  auto issue_pair = [&](char* t0, const bf16* s0, int sb0, char* t1, const bf16* s1, int sb1) {
+    const __amdgpu_buffer_rsrc_t rs0 = mk_rsrc(s0, tile_window<HD>(T, sb0)), rs1 = mk_rsrc(s1, tile_window<HD>(T, sb1));
 #pragma unroll
-      for (int j = 0; j < NH; ++j) {
-        const int c = half + 2 * j;
-        const int cc = c < NCH ? c : 0;          // clamped, masked below
-        ov[j] = *(const bf16x8*)(orow + cc * 8);
-        gv[j] = *(const bf16x8*)(grow + cc * 8);
-      }
-      lsev = lse[((long)b * H + h) * T + rcl];
+    for (int j = 0; j < 9; ++j) {
+      const int pp = 9 * wave + j;              // 72 pieces of 1 KiB: 36 per tile (256 rows x 9 chunks / 64 lanes)
+      const bool second = pp >= 36;
+      const int I = second ? pp - 36 : pp;
+      const int vo = dma_voff<HD, ROWB>(I * 64 + lane, second ? sb1 : sb0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, 0);
     }
-    tile_commit<HD>(Qt, rq, T, tid);
-    tile_commit<HD>(Kt, rk, T, tid);
-    tile_commit<HD>(Vt, rv, T, tid);
-    tile_commit<HD>(Gt, rg, T, tid);
-    // delta[q] = sum_d dO[q,d] * O[q,d]; two threads per row (chunks half, half + 2, ... in the same order as before)
+  };
+  issue_pair(Kt, base + D, (int)(tok * 2), Vt, base + 2 * D, (int)(tok * 2));
+  bf16x8 qf[2][KS], gf[2][KS];
+  float lq[2], dq_[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int row = r0 + 16 * qt + i;
+    const bool ok = row < T;
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      if (half + 2 * j < NCH) {
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[qt][ks] = load_frag_global<HD>(base + (long)row * tok, ok, ks, lane);
+      gf[qt][ks] = load_frag_global<HD>(gbase + (long)row * D, ok, ks, lane);
+      const bf16x8 of = load_frag_global<HD>(o + ((long)b * T + row) * D + h * HD, ok, ks, lane);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += bf2f(ov[j][e]) * bf2f(gv[j][e]);
-      }
+      for (int e = 0; e < 8; ++e) acc += bf2f(gf[qt][ks][e]) * bf2f(of[e]);
     }
-    acc += __shfl_xor(acc, 1, 64);
-    if (half == 0) {
-      dlt[row] = row < T ? acc : 0.f;
-      lse2[row] = row < T ? lsev * LOG2E : INFINITY;
-    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    dq_[qt] = acc;
+    lq[qt] = ok ? lse[((long)b * H + h) * T + row] * LOG2E : INFINITY;
   }
-  __syncthreads();
+  issue_pair(Qt, base, (int)(tok * 2), Gt, gbase, D * 2);
+  if (g == 0) {   // phase 2 reads the 256 deltas and log-sum-exps from LDS: every wave contributes its 32 rows
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) { dlt[r0 + 16 * qt + i] = dq_[qt]; lse2[r0 + 16 * qt + i] = lq[qt]; }
+  }
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // K, V (and the register loads) landed; younger: the 9 Q / dO pieces
+  ATTN_BARRIER();
 
-  const int r0 = wave * 32;  // this wave's 32 rows (queries in phase 1, keys in phase 2)
   f32x4 dq[2][DT];
   // A wave's 32 finished rows leave through LDS: the MFMA layout gives a lane 4 consecutive columns of one row, i.e. a
   // wave-level store of sixteen 32-byte pieces — the pattern that cost the GEMM epilogues their HBM time.
@@ -743,17 +750,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   };
   if (r0 < T) {
     // ---------------- phase 1: dQ for queries [r0, r0+32) ----------------
-    bf16x8 qf[2][KS], gf[2][KS];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        qf[qt][ks] = frag_rows_z<HD>(Qt, r0 + 16 * qt, ks, lane);
-        gf[qt][ks] = frag_rows_z<HD>(Gt, r0 + 16 * qt, ks, lane);
-      }
-    float lq[2], dq_[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) { lq[qt] = lse2[r0 + 16 * qt + i]; dq_[qt] = dlt[r0 + 16 * qt + i]; }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -800,14 +796,21 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
       }
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) dsb[qt] = pack2(st[qt][0], st[qt][1]);
+      {
+        // (asm reads: with the builtin the compiler would drain the Q / dO pieces still in flight before every read)
+        bf16x8 ktf[DT];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        bf16x8 ktf = frag_trT(Kt, kv0, 16 * dt, lane);
-        dq[0][dt] = MFMA(ktf, dsb[0], dq[0][dt]);
-        dq[1][dt] = MFMA(ktf, dsb[1], dq[1][dt]);
+        for (int dt = 0; dt < DT; ++dt) ktf[dt] = frag_trT_a<ROWB>(Kt, kv0, 16 * dt, lane);
+        ATTN_LDS_WAIT();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          dq[0][dt] = MFMA(ktf[dt], dsb[0], dq[0][dt]);
+          dq[1][dt] = MFMA(ktf[dt], dsb[1], dq[1][dt]);
+        }
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q / dO tiles have landed
   __syncthreads();   // phase 1 (every wave reads all of K and V) is over: rows [r0, r0+32) of Kt / Vt are this wave's alone
   if (r0 < T) {
     // ---------------- phase 2: dK, dV for keys [r0, r0+32) ----------------
