@@ -81,47 +81,6 @@ __device__ __forceinline__ void load_tile(char* lds, const bf16* src, long row_s
   }
 }
 
-// load_tile in two halves, so that a caller can have the loads of SEVERAL tiles in flight before the first wait (the
-// backward keeps four tiles resident and used to pay ~10 serial HBM round trips per workgroup for them).
-template <int HD>
-struct TileRegs {
-  static constexpr int PER = (256 * Cfg<HD>::NCH + 511) / 512;
-  uint4 v[PER];
-};
-template <int HD>
-__device__ __forceinline__ void tile_issue(TileRegs<HD>& r, const bf16* src, long row_stride, int rows_valid, int tid) {
-  constexpr int NCH = Cfg<HD>::NCH;
-  const int last = rows_valid - 1;
-#pragma unroll
-  for (int k = 0; k < TileRegs<HD>::PER; ++k) {
-    int idx = tid + k * 512;
-    int row = idx / NCH, c = idx - row * NCH;
-    int rc = min(row, last);
-    if (rc < 0) rc = 0;
-    int cc = idx < 256 * NCH ? c : 0;
-    r.v[k] = *(const uint4*)(src + (long)rc * row_stride + cc * 8);
-  }
-}
-template <int HD, int RB = ROWB>
-__device__ __forceinline__ void tile_commit(char* lds, const TileRegs<HD>& r, int rows_valid, int tid) {
-  constexpr int NCH = Cfg<HD>::NCH;
-#pragma unroll
-  for (int k = 0; k < TileRegs<HD>::PER; ++k) {
-    int idx = tid + k * 512;
-    int row = idx / NCH, c = idx - row * NCH;
-    if (idx < 256 * NCH) {
-      const unsigned msk = row < rows_valid ? 0xFFFFFFFFu : 0u;
-      uint4 w = r.v[k];
-      w.x &= msk; w.y &= msk; w.z &= msk; w.w &= msk;
-      *(uint4*)(lds + row * RB + c * 16) = w;
-    }
-  }
-  if (RB > HD * 2 + 8 && tid < 256) {
-#pragma unroll
-    for (int c = Cfg<HD>::NCH; c < RB / 16; ++c) *(uint4*)(lds + tid * RB + c * 16) = make_uint4(0, 0, 0, 0);
-  }
-}
-
 // lane (i = lane&15, g = lane>>4): X[row0 + i][ks*32 + 8g .. +7]
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int ks, int lane) {
   return *(const bf16x8*)(tile + (row0 + (lane & 15)) * ROWB + (ks * 32 + 8 * (lane >> 4)) * 2);
@@ -705,27 +664,35 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     }
   };
   issue_pair(Kt, base + D, (int)(tok * 2), Vt, base + 2 * D, (int)(tok * 2));
-  bf16x8 qf[2][KS], gf[2][KS];
+  bf16x8 qf[2][KS], gf[2][KS], of[2][KS];
   float lq[2], dq_[2];
+  // every register load of the wave's own rows is issued before anything consumes one, and the Q / dO pieces behind them:
+  // the compiler's wait for the fragments is then a counted vmcnt(9), not a drain per use
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int row = r0 + 16 * qt + i;
     const bool ok = row < T;
-    float acc = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       qf[qt][ks] = load_frag_global<HD>(base + (long)row * tok, ok, ks, lane);
       gf[qt][ks] = load_frag_global<HD>(gbase + (long)row * D, ok, ks, lane);
-      const bf16x8 of = load_frag_global<HD>(o + ((long)b * T + row) * D + h * HD, ok, ks, lane);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += bf2f(gf[qt][ks][e]) * bf2f(of[e]);
+      of[qt][ks] = load_frag_global<HD>(o + ((long)b * T + row) * D + h * HD, ok, ks, lane);
     }
+    lq[qt] = lse[((long)b * H + h) * T + min(row, T - 1)];
+  }
+  issue_pair(Qt, base, (int)(tok * 2), Gt, gbase, D * 2);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float acc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += bf2f(gf[qt][ks][e]) * bf2f(of[qt][ks][e]);
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
     dq_[qt] = acc;
-    lq[qt] = ok ? lse[((long)b * H + h) * T + row] * LOG2E : INFINITY;
+    lq[qt] = (r0 + 16 * qt + i < T) ? lq[qt] * LOG2E : INFINITY;
   }
-  issue_pair(Qt, base, (int)(tok * 2), Gt, gbase, D * 2);
   if (g == 0) {   // phase 2 reads the 256 deltas and log-sum-exps from LDS: every wave contributes its 32 rows
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) { dlt[r0 + 16 * qt + i] = dq_[qt]; lse2[r0 + 16 * qt + i] = lq[qt]; }
