@@ -189,10 +189,18 @@ int reed_cosine_bwd(const void* zt, const float* z, const float* gscale, void* d
 /* partial[i] = sum of squares of chunk i (nblocks partials); finalize: norm_clip[0]=||g||, [1]=min(1,max_norm/(||g||+1e-6)) */
 int reed_grad_sqnorm(const float* g, int64_t n, float* partial, int nblocks, void* stream);
 int reed_clip_finalize(const float* partial, int nblocks, float max_norm, float* norm_clip, void* stream);
-/* fused clip * AdamW + EMA + bf16 shadow over a flat arena; norm_clip may be NULL (no clipping) */
+/* the same with dynamic loss scaling on the device (fp16 training; torch.amp.GradScaler as accelerate drives it,
+ * image/train.py:401-409): scaler_state f32[4] = [scale, growth_tracker, found_inf, steps_taken]; the arena holds scale x the
+ * gradients; norm_clip[0] = the true norm (inf / nan on overflow), [1] = clip coefficient / scale, 0 on overflow; the state is
+ * updated as GradScaler.update() does (x backoff on overflow; x growth after growth_interval clean steps) */
+int reed_clip_finalize_scaled(const float* partial, int nblocks, float max_norm, float* norm_clip, float* scaler_state,
+                              float growth_factor, float backoff_factor, float growth_interval, void* stream);
+/* fused clip * AdamW + EMA + 16-bit shadow over a flat arena; norm_clip may be NULL (no clipping); scaler_state (may be
+ * NULL): an overflowed step leaves p, m, v untouched (EMA and shadow still run) and the bias corrections count the steps
+ * actually taken (bc1 / bc2 are then ignored) */
 int reed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow,
-                   int64_t n_train, int64_t n_total, const float* norm_clip, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, float bc1, float bc2, float ema_decay,
+                   int64_t n_train, int64_t n_total, const float* norm_clip, const float* scaler_state, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2, float ema_decay,
                    void* stream);
 int reed_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 

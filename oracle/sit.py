@@ -202,16 +202,20 @@ def sit_forward(P, cfg, x, t, y, inference=True, training=False, drop_mask=None)
 
 class OracleModel:
     """Callable with the reference's model signature, for SILoss / the samplers. `autocast_bf16=True` mirrors
-    accelerate's mixed_precision='bf16' wrapping (autocast forward + outputs converted to fp32)."""
+    accelerate's mixed_precision='bf16' wrapping (autocast forward + outputs converted to fp32); `autocast_dtype`
+    (torch.float16: the reference's default --mixed-precision, train.py:458) picks the autocast type."""
 
-    def __init__(self, P, cfg, autocast_bf16=False, training=False):
+    def __init__(self, P, cfg, autocast_bf16=False, training=False, autocast_dtype=None):
+        if autocast_dtype is not None:
+            autocast_bf16 = True
+        self.autocast_dtype = autocast_dtype or torch.bfloat16
         self.P, self.cfg, self.autocast_bf16, self.training = P, cfg, autocast_bf16, training
         self.drop_mask = None
         self.in_channels = cfg["in_channels"]
 
     def __call__(self, x, t, y, inference=True):
         if self.autocast_bf16:
-            with torch.autocast("cpu", dtype=torch.bfloat16):
+            with torch.autocast("cpu", dtype=self.autocast_dtype):
                 out, zs = sit_forward(self.P, self.cfg, x, t, y, inference, self.training, self.drop_mask)
             out = out.float()
             zs = None if zs is None else [z.float() for z in zs]

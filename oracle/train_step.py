@@ -49,13 +49,18 @@ class Trainer:
                  max_grad_norm=1.0, proj_coeff=0.5, path_type="linear", weighting="uniform",
                  time_schedule="constant", cutoffs=(0.0, 1.0), autocast_bf16=False, ema_decay=0.9999,
                  repa_decay="constant", repa_steps=400000, start_diffusion_steps=0, diffusion_warm_up_steps=50000,
-                 diffusion_decay="constant", max_train_steps=400000):
+                 diffusion_decay="constant", max_train_steps=400000, autocast_dtype=None, init_scale=None):
         self.cfg = cfg
         self.P = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in P.items()}
         self.ema = {k: v.detach().clone() for k, v in P.items()}
         self.opt = torch.optim.AdamW([v for k, v in self.P.items() if k != "pos_embed"], lr=lr, betas=betas,
                                      weight_decay=weight_decay, eps=eps)
-        self.model = osit.OracleModel(self.P, cfg, autocast_bf16=autocast_bf16, training=True)
+        self.model = osit.OracleModel(self.P, cfg, autocast_bf16=autocast_bf16, training=True,
+                                      autocast_dtype=autocast_dtype)
+        # --mixed-precision fp16: accelerate wraps backward / clip / step in torch's GradScaler at its defaults
+        # (accelerator.backward -> scaler.scale(loss).backward(); clip_grad_norm_ -> unscale_; optimizer.step ->
+        # scaler.step + update), train.py:401-408
+        self.scaler = None if init_scale is None else torch.amp.GradScaler("cpu", init_scale=init_scale)
         self.enc_names = list(enc_names)
         self.loss_weights = {n: repa_coeff[i] for i, n in enumerate(enc_names)}
         self.k = dict(path_type=path_type, weighting=weighting, time_schedule=time_schedule, cutoffs=cutoffs)
@@ -81,13 +86,22 @@ class Trainer:
         proj_mean = proj.mean() if torch.is_tensor(proj) else torch.tensor(float(proj))
         total = den * w_diff + proj_mean * self.proj_coeff * w_repa
         self.opt.zero_grad(set_to_none=True)
-        total.backward()
+        if self.scaler is not None:
+            self.scaler.scale(total).backward()
+            self.scaler.unscale_(self.opt)
+        else:
+            total.backward()
         gn = torch.nn.utils.clip_grad_norm_([v for k, v in self.P.items() if k != "pos_embed"], self.max_grad_norm)
-        self.opt.step()
+        if self.scaler is not None:
+            self.scaler.step(self.opt)   # skipped when unscale_ saw inf / nan
+            self.scaler.update()
+        else:
+            self.opt.step()
         with torch.no_grad():
             for k, v in self.P.items():
                 self.ema[k].mul_(self.ema_decay).add_(v.detach(), alpha=1 - self.ema_decay)
         self.step_idx += 1
         return {"loss": float(total), "denoising_loss": float(den), "proj_loss": float(proj_mean),
-                "grad_norm": float(gn), "img_proj_loss": float(out["img_proj_loss"]),
+                "grad_norm": float(gn), "scale": self.scaler.get_scale() if self.scaler is not None else 1.0,
+                "img_proj_loss": float(out["img_proj_loss"]),
                 "text_proj_loss": float(out["text_proj_loss"])}

@@ -40,6 +40,41 @@ __global__ __launch_bounds__(256) void clip_finalize_kernel(const float* __restr
   }
 }
 
+// Dynamic loss scaling for fp16 training (torch.amp.GradScaler as accelerate drives it: scale(loss).backward(), unscale_
+// before clip_grad_norm_, step skipped on inf / nan, update(); image/train.py:401-409 under --mixed-precision fp16), on the
+// device: state = [scale, growth_tracker, found_inf (this step), good_steps (optimiser steps actually taken)].
+// The gradients in the arena are scale x the true ones; out[0] = the true norm (inf / nan on overflow, as the reference
+// logs it), out[1] = clip coefficient / scale (unscale and clip in the one multiply the update applies), 0 on overflow.
+__global__ __launch_bounds__(256) void clip_finalize_scaled_kernel(const float* __restrict__ partial, int nb, float max_norm,
+                                                                   float* __restrict__ out, float* __restrict__ st,
+                                                                   float growth, float backoff, float interval) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += (double)partial[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float scale = st[0];
+    const float norm_s = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+    const bool bad = !(norm_s <= 3.0e38f);          // inf or nan anywhere in the scaled gradients
+    const float norm = norm_s / scale;
+    out[0] = norm;
+    out[1] = bad ? 0.f : (max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f) / scale;
+    if (bad) {
+      st[0] = scale * backoff;
+      st[1] = 0.f;
+      st[2] = 1.f;
+    } else {
+      float tr = st[1] + 1.f;
+      if (tr >= interval) { st[0] = scale * growth; tr = 0.f; }
+      st[1] = tr;
+      st[2] = 0.f;
+      st[3] += 1.f;
+    }
+  }
+}
+
 struct AdamArgs {
   float lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay;
 };
@@ -48,13 +83,18 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         float* __restrict__ ema, bf16* __restrict__ shadow, long n4_train,
                                                         long n4_total, const float* __restrict__ norm_clip,
-                                                        AdamArgs a) {
+                                                        const float* __restrict__ scaler, AdamArgs a) {
   const float clip = norm_clip ? norm_clip[1] : 1.f;
-  const float step_size = a.lr / a.bc1;
-  const float bc2s = sqrtf(a.bc2);
+  // with a loss scaler: an overflowed step leaves p, m, v untouched (GradScaler.step skips optimizer.step; the EMA update
+  // and the shadow still run, train.py:411-412), and the bias corrections count the steps actually taken
+  const bool skip = scaler && scaler[2] != 0.f;
+  const float bc1 = scaler ? 1.f - powf(a.beta1, scaler[3]) : a.bc1;
+  const float bc2 = scaler ? 1.f - powf(a.beta2, scaler[3]) : a.bc2;
+  const float step_size = a.lr / bc1;
+  const float bc2s = sqrtf(bc2);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4_total; i += (long)gridDim.x * 256) {
     f32x4 pv = *(const f32x4*)(p + i * 4);
-    if (i < n4_train) {
+    if (i < n4_train && !skip) {
       f32x4 gv = *(const f32x4*)(g + i * 4);
       f32x4 mv = *(const f32x4*)(m + i * 4);
       f32x4 vv = *(const f32x4*)(v + i * 4);
@@ -106,10 +146,20 @@ extern "C" int reed_clip_finalize(const float* partial, int nblocks, float max_n
   return REED_OK;
 }
 
+extern "C" int reed_clip_finalize_scaled(const float* partial, int nblocks, float max_norm, float* norm_clip,
+                                         float* scaler_state, float growth_factor, float backoff_factor,
+                                         float growth_interval, void* stream) {
+  REED_CHECK_ARG(partial && norm_clip && scaler_state, "clip_finalize_scaled: null pointer");
+  REED_KLAUNCH(clip_finalize_scaled_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblocks, max_norm,
+               norm_clip, scaler_state, growth_factor, backoff_factor, growth_interval);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
 extern "C" int reed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, void* shadow,
-                              int64_t n_train, int64_t n_total, const float* norm_clip, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, float bc1, float bc2, float ema_decay,
-                              void* stream) {
+                              int64_t n_train, int64_t n_total, const float* norm_clip, const float* scaler_state,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                              float ema_decay, void* stream) {
   REED_CHECK_ARG(p && (n_train == 0 || (g && m && v)), "adamw_ema: null pointer");
   REED_CHECK_ARG(n_train % 4 == 0 && n_total % 4 == 0 && n_train <= n_total,
                  "adamw_ema: n_train=%ld n_total=%ld must be multiples of 4 with n_train <= n_total", (long)n_train,
@@ -120,7 +170,7 @@ extern "C" int reed_adamw_ema(float* p, const float* g, float* m, float* v, floa
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   REED_KLAUNCH(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema,
-                     (bf16*)shadow, (long)(n_train >> 2), n4, norm_clip, a);
+                     (bf16*)shadow, (long)(n_train >> 2), n4, norm_clip, scaler_state, a);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

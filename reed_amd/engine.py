@@ -94,8 +94,6 @@ class Engine:
     # ---- forward -------------------------------------------------------------------
     def forward(self, x, t, y, inference, need_grad, drop):
         prec = getattr(self.m, "precision", "bf16")
-        if prec != "bf16" and need_grad:
-            raise RuntimeError("reed_amd.SiT: precision='fp16' is the sampling path (inference only); training runs in bf16")
         prev = ops.use(prec)
         try:
             return self._forward(x, t, y, inference, need_grad, drop, prec)
@@ -128,7 +126,7 @@ class Engine:
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
 
-        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x) if need_grad else None
+        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x, prec=prec) if need_grad else None
         # -- embedders
         tok = f32(M, D)
         ops.patch_embed_fwd(x, self.W("x_embedder.proj.weight"), self.W("x_embedder.proj.bias"), self.Wf("pos_embed"),
@@ -305,6 +303,16 @@ class Engine:
         ops.gemm(NN, epi, dy, self.W(wname), Mtok, K, N, out, N, K, K, **kw)
 
     def backward(self, tp, dout, dzs):
+        prec = getattr(self.m, "precision", "bf16")
+        if getattr(tp, "prec", prec) != prec:
+            raise RuntimeError("reed_amd.SiT: model.precision changed between forward and backward")
+        prev = ops.use(prec)
+        try:
+            return self._backward(tp, dout, dzs, ops.half_dtype(prec))
+        finally:
+            ops.use(prev)
+
+    def _backward(self, tp, dout, dzs, hdt):
         m, L = self.m, self.L
         D, H, hd, Hm, T, P, C = self.D, self.H, self.hd, self.Hm, self.T, self.P, self.C
         B = tp.B
@@ -317,7 +325,7 @@ class Engine:
         ch = T // 16  # 16-row chunks per sample
 
         def bf(*s):
-            return torch.empty(s, dtype=torch.bfloat16, device=dev)
+            return torch.empty(s, dtype=hdt, device=dev)
 
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
@@ -379,8 +387,8 @@ class Engine:
         if fg:
             split_ada = False
             W = red.world
-            g_send, g_recv = red.gather_buffers("dmod", B * Nall, torch.bfloat16, dev)
-            s_send, s_all = red.gather_buffers("silu", B * D, torch.bfloat16, dev)
+            g_send, g_recv = red.gather_buffers("dmod", B * Nall, hdt, dev)
+            s_send, s_all = red.gather_buffers("silu", B * D, hdt, dev)
             s_send.view(B, D).copy_(tp.silu_c)
             red.gather(s_send, s_all)
 
@@ -546,10 +554,11 @@ class Engine:
                 self.A.grad[b:e].zero_()
             return
         dz = dz.reshape(R, Z)
-        if dz.dtype != torch.bfloat16:
-            dz = dz.to(torch.bfloat16)
+        hdt = ops.half_dtype()   # the build Engine.backward selected
+        if dz.dtype != hdt:
+            dz = dz.to(hdt)
         dz = dz.contiguous()
-        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)  # noqa: E731
+        bf = lambda *s: torch.empty(s, dtype=hdt, device=dev)  # noqa: E731
         self._wgrad(dz, pj.p2, pre + "4.weight", R, Z, Pd, acc, dev)
         d2 = bf(R, Pd)
         ops.gemm(NN, EPI_DSILU, dz, self.W(pre + "4.weight"), R, Pd, Z, d2, Z, Pd, Pd, R=pj.p2p, ldr=Pd)

@@ -56,7 +56,11 @@ class _Cosine(torch.autograd.Function):
         Z = zt.shape[-1]
         loss = torch.empty(B, dtype=torch.float32, device=zt.device)
         rowdot = torch.empty(B * T, dtype=torch.float32, device=zt.device)
-        ops.cosine_fwd(zt, z, rowdot, loss, B, T, Z)
+        prev = ops.use("fp16" if zt.dtype == torch.float16 else "bf16")   # the projector output's 16-bit type picks the build
+        try:
+            ops.cosine_fwd(zt, z, rowdot, loss, B, T, Z)
+        finally:
+            ops.use(prev)
         ctx.save_for_backward(zt, z)
         ctx.dims = (B, T, Z)
         return loss
@@ -66,7 +70,11 @@ class _Cosine(torch.autograd.Function):
         zt, z = ctx.saved_tensors
         B, T, Z = ctx.dims
         dzt = torch.empty_like(zt)
-        ops.cosine_bwd(zt, z, g.contiguous().float(), dzt, B, T, Z)
+        prev = ops.use("fp16" if zt.dtype == torch.float16 else "bf16")
+        try:
+            ops.cosine_bwd(zt, z, g.contiguous().float(), dzt, B, T, Z)
+        finally:
+            ops.use(prev)
         return dzt, None
 
 
@@ -163,7 +171,7 @@ class SILoss:
                 assert z_tilde.ndim == 2, "Pooling to 2D to align with text embeddings."
             if w == 0.0:
                 wts = torch.ones_like(wts)
-            if z_tilde.dtype != torch.bfloat16:  # foreign model returning fp32 projector outputs
+            if z_tilde.dtype not in (torch.bfloat16, torch.float16):  # foreign model returning fp32 projector outputs
                 z_tilde = z_tilde.to(torch.bfloat16)
             curr_loss = _Cosine.apply(z_tilde.contiguous(), z.to(images.device).contiguous().float())  # [B]
             weighted_loss = (curr_loss * wts).mean()  # [B] x [B,1,1,1] broadcast, as the reference

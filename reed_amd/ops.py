@@ -363,9 +363,15 @@ def clip_finalize(partial, nblocks, max_norm, norm_clip):
     _call("reed_clip_finalize", _p(partial), nblocks, max_norm, _p(norm_clip), _stream())
 
 
-def adamw_ema(p, g, m, v, ema, shadow, n_train, n_total, norm_clip, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay):
+def clip_finalize_scaled(partial, nblocks, max_norm, norm_clip, scaler_state, growth=2.0, backoff=0.5, interval=2000):
+    _call("reed_clip_finalize_scaled", _p(partial), nblocks, max_norm, _p(norm_clip), _p(scaler_state), growth, backoff,
+          float(interval), _stream())
+
+
+def adamw_ema(p, g, m, v, ema, shadow, n_train, n_total, norm_clip, lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay,
+              scaler_state=None):
     _call("reed_adamw_ema", _p(p), _p(g), _p(m), _p(v), _p(ema), _p(shadow), n_train, n_total, _p(norm_clip),
-          lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay, _stream())
+          _p(scaler_state), lr, beta1, beta2, eps, wd, bc1, bc2, ema_decay, _stream())
 
 
 # ---------------- samplers ----------------

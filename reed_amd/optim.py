@@ -13,7 +13,8 @@ _NB = 2048  # partial-sum blocks of the squared-norm reduction
 
 class FusedAdamWEMA:
     def __init__(self, model, ema=None, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8,
-                 max_grad_norm=1.0, ema_decay=0.9999, overlap=False):
+                 max_grad_norm=1.0, ema_decay=0.9999, overlap=False, init_scale=65536.0, growth_factor=2.0,
+                 backoff_factor=0.5, growth_interval=2000):
         """overlap=True: the update runs on the optimiser's own HIP stream, one launch per parameter bucket in the
         order the next forward touches them (ArenaLayout.update_chunks), each followed by an event that the forward
         waits for just before the first kernel that reads the bucket. The pass is HBM-bound (38 B/param), the
@@ -36,6 +37,14 @@ class FusedAdamWEMA:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.partial = torch.empty(_NB, dtype=torch.float32, device=dev)
         self.norm_clip = torch.zeros(2, dtype=torch.float32, device=dev)  # [||g||, clip coefficient]
+        # fp16 training (model.precision == "fp16"; the reference's README recipe): dynamic loss scaling with
+        # torch.amp.GradScaler's defaults, as accelerate builds it — [scale, growth_tracker, found_inf, steps_taken] on the
+        # device. TrainStep multiplies the loss by scaler_state[0]; step() unscales inside the clip coefficient, skips the
+        # update on overflow and updates the scale, all without a host synchronisation (csrc/optim.hip).
+        self.scaler_state = None
+        self.scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
+        if getattr(model, "precision", "bf16") == "fp16":
+            self.scaler_state = torch.tensor([float(init_scale), 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
         if ema is not None:
             if ema._layout.n_total != model._layout.n_total or ema._arena.master.device != dev:
                 raise ValueError("EMA model must be a deepcopy of the model on the same device")
@@ -51,9 +60,24 @@ class FusedAdamWEMA:
         A, L = m._arena, m._layout
         if A.grad is None:
             raise RuntimeError("FusedAdamWEMA.step() called before any backward")
-        A.ensure_shadow()
+        prec = getattr(m, "precision", "bf16")
+        prev = ops.use(prec)      # the update writes the 16-bit shadow in the model's operand type
+        try:
+            self._step(m, A, L, prec)
+        finally:
+            ops.use(prev)
+
+    def _step(self, m, A, L, prec):
+        A.ensure_shadow(prec)
         nc = None
-        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+        st = self.scaler_state
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        if st is not None:        # scaled gradients: the norm pass also finds overflows, the coefficient also unscales
+            ops.grad_sqnorm(A.grad, L.n_train, self.partial, _NB)
+            ops.clip_finalize_scaled(self.partial, _NB, float(self.max_grad_norm) if clip else 0.0, self.norm_clip, st,
+                                     *self.scaler_cfg)
+            nc = self.norm_clip
+        elif clip:
             ops.grad_sqnorm(A.grad, L.n_train, self.partial, _NB)
             ops.clip_finalize(self.partial, _NB, float(self.max_grad_norm), self.norm_clip)
             nc = self.norm_clip
@@ -64,7 +88,7 @@ class FusedAdamWEMA:
         ema_buf = self.ema._arena.master if self.ema is not None else None
         if not self.overlap:
             ops.adamw_ema(A.master, A.grad, self.exp_avg, self.exp_avg_sq, ema_buf, A.shadow, L.n_train, L.n_total, nc,
-                          self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay)
+                          self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay, scaler_state=st)
         else:
             A.wait_all()
             main = torch.cuda.current_stream()
@@ -83,7 +107,8 @@ class FusedAdamWEMA:
                     nt = max(0, min(e, L.n_train) - b)
                     ops.adamw_ema(pp + 4 * b, gp + 4 * b if nt else None, mp + 4 * b if nt else None,
                                   vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + 2 * b, nt,
-                                  e - b, nc, self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay)
+                                  e - b, nc, self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay,
+                                  scaler_state=st)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     A.pending[name] = ev
@@ -112,13 +137,15 @@ class FusedAdamWEMA:
         self.flush()
         L = self.model._layout
         state, idx = {}, []
+        # with a loss scaler torch's per-parameter "step" counts the updates actually applied (skipped steps do not count)
+        steps = self.step_count if self.scaler_state is None else int(self.scaler_state[3].item())
         for i, (name, p) in enumerate(self.model.named_parameters()):
             idx.append(i)
-            if not p.requires_grad or self.step_count == 0:
+            if not p.requires_grad or steps == 0:
                 continue
             off, shp = L.seg[name]
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            state[i] = {"step": torch.tensor(float(steps)),
                         "exp_avg": self.exp_avg[off:off + n].view(shp).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shp).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
@@ -138,6 +165,8 @@ class FusedAdamWEMA:
             self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].flatten())
             steps = max(steps, int(float(st["step"])))
         self.step_count = steps
+        if self.scaler_state is not None:   # the scale itself restarts at init_scale, as accelerate's does on resume
+            self.scaler_state[3] = float(steps)
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
 

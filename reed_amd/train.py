@@ -7,7 +7,7 @@ Same flag surface as image/train.py:483-555 (every flag name, default and choice
 (:349 sample_posterior, :363-385 schedules, :387-412 loss/clip/AdamW/EMA), same checkpoint dict
 {"model","ema","opt","args","steps"} (:418-429) and resume rule (:280-291). The accelerate/DDP machinery is replaced
 by reed_amd.parallel.GradReducer (RCCL over xGMI, bucketed, overlapped with backward); mixed precision is always the
-bf16-MFMA/fp32-master scheme (`--mixed-precision bf16`; "fp16" is accepted and mapped to it with a warning, "no" is
+16-bit-MFMA/fp32-master scheme (`--mixed-precision bf16`, or "fp16" = IEEE-half operands + dynamic loss scaling; "no" is
 rejected: there is no fp32 GEMM path).
 
 Deliberate fixes of reference defects: `--enc-type None` = alignment off (§9-4); the preview
@@ -169,9 +169,8 @@ def main(args):
         dist.init_process_group("nccl", device_id=device)
     is_main = rank == 0
     if args.mixed_precision == "no":
-        raise NotImplementedError("--mixed-precision no: the HIP path computes GEMMs in bf16 (fp32 master weights)")
-    if args.mixed_precision == "fp16" and is_main:
-        print("[reed_amd] --mixed-precision fp16 runs as bf16 MFMA with fp32 master weights (no GradScaler needed)")
+        raise NotImplementedError("--mixed-precision no: the HIP path computes GEMMs with 16-bit operands (fp32 master "
+                                  "weights, fp32 accumulation): choose bf16 or fp16")
 
     curr_time = datetime.datetime.now().strftime("%Y%m%d_%H%M%S")
     exp_name = args.exp_name if args.resume_step > 0 else f"{args.exp_name}_{curr_time}"
@@ -235,6 +234,10 @@ def main(args):
                                    z_dims=z_dims, z_types=z_types, encoder_depth=args.encoder_depth,
                                    encoder_depth_text=args.encoder_depth_text, fused_attn=args.fused_attn,
                                    qk_norm=args.qk_norm).to(device)
+    # accelerate's mixed_precision (train.py:141-151): "bf16" = bf16 operands (libreed_hip.so); "fp16" (the reference's default
+    # and README recipe) = IEEE-half operands (libreed_hip_f16.so) with dynamic loss scaling (GradScaler defaults) in the
+    # fused optimiser pass. Master weights, residual stream, LayerNorm, loss and optimiser state are fp32 either way.
+    model.precision = args.mixed_precision
     ema = copy.deepcopy(model).to(device)
     ema.requires_grad_(False)
     loss_fn = SILoss(prediction=args.prediction, path_type=args.path_type, enc_names=enc_names,

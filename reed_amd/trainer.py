@@ -83,7 +83,11 @@ class TrainStep:
         proj = out["proj_loss"]
         proj_mean = proj.mean() if torch.is_tensor(proj) else torch.zeros((), device=x.device)
         loss = den * w_diff + proj_mean * self.proj_coeff * w_repa
-        (loss / self.grad_accum).backward()
+        st = getattr(self.opt, "scaler_state", None)
+        if st is not None:   # fp16: scaler.scale(loss).backward() (accelerate, train.py:401); the scale is a device scalar
+            (loss * (st[0].detach() / self.grad_accum)).backward()
+        else:
+            (loss / self.grad_accum).backward()
         res = {"loss": loss.detach(), "denoising_loss": den.detach(), "proj_loss": proj_mean.detach(),
                "img_proj_loss": out["img_proj_loss"], "text_proj_loss": out["text_proj_loss"]}
         if syncing:

@@ -51,6 +51,35 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
     assert lat.shape == (8, 4, 32, 32) and np.isfinite(lat).all()
 
 
+def test_train_default_mixed_precision_is_fp16(dev, tmp_path):
+    """No --mixed-precision flag = the reference's default "fp16" (image/train.py:458): IEEE-half operands with the loss
+    scaler in the fused optimiser pass; checkpoint / resume keep working (the Adam step count comes from the scaler), the
+    EMA checkpoint samples, and "no" is refused rather than silently mapped."""
+    from reed_amd import generate, train
+    out = str(tmp_path / "exps")
+    common = ["--model", "SiT-S/2", "--output-dir", out, "--batch-size", "8", "--synthetic", "32", "--num-workers", "0",
+              "--diffusion-warm-up-steps", "0", "--report-to", "none", "--checkpointing-steps", "2", "--enc-type", "dinov2-vit-b"]
+    a = train.parse_args(["--exp-name", "h", "--max-train-steps", "4"] + common)
+    assert a.mixed_precision == "fp16"
+    d = train.main(a)
+    logs = [json.loads(l) for l in open(os.path.join(d, "metrics.jsonl"))]
+    assert len(logs) == 4 and all(np.isfinite(r["training_denoising_loss"]) and np.isfinite(r["grad_norm"]) for r in logs)
+    c = torch.load(os.path.join(d, "checkpoints", "0000004.pt"), map_location="cpu", weights_only=False)
+    assert {v["step"].item() for v in c["opt"]["state"].values()} == {4.0}
+    a2 = train.parse_args(["--exp-name", os.path.basename(d), "--max-train-steps", "5", "--resume-step", "4"] + common)
+    train.main(a2)
+    logs = [json.loads(l) for l in open(os.path.join(d, "metrics.jsonl"))]
+    assert len(logs) == 5 and np.isfinite(logs[-1]["grad_norm"])
+    g = generate.build_parser().parse_args(["--ckpt", os.path.join(d, "checkpoints", "0000004.pt"), "--model", "SiT-S/2",
+                                            "--sample-dir", str(tmp_path / "samples"), "--per-proc-batch-size", "4",
+                                            "--num-fid-samples", "4", "--num-steps", "3", "--save-latents"])
+    folder = generate.main(g)
+    torch.set_grad_enabled(True)
+    assert np.isfinite(np.load(folder + "_latents.npz")["arr_0"]).all()
+    with pytest.raises(NotImplementedError):
+        train.main(train.parse_args(["--exp-name", "n", "--max-train-steps", "1", "--mixed-precision", "no"] + common))
+
+
 @pytest.mark.parametrize("algo", ["allreduce", "rsag"])
 @pytest.mark.parametrize("ada_gather", ["1", "0"])
 @pytest.mark.parametrize("binding", ["native", "torch"])

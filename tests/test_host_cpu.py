@@ -34,7 +34,7 @@ def test_arg_errors_do_not_need_a_gpu():
     rc = lib.reed_attention_fwd(None, None, None, 1, 16, 2, 48, None)
     assert rc == 1001
     assert b"null pointer" in lib.reed_last_error() or b"head_dim" in lib.reed_last_error()
-    rc = lib.reed_adamw_ema(1, 1, 1, 1, None, None, 6, 8, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, 0.1, 0.1, 0.9999, None)
+    rc = lib.reed_adamw_ema(1, 1, 1, 1, None, None, 6, 8, None, None, 1e-4, 0.9, 0.999, 1e-8, 0.0, 0.1, 0.1, 0.9999, None)
     assert rc == 1001 and b"multiples of 4" in lib.reed_last_error()
 
 
@@ -422,3 +422,46 @@ def test_dataset_and_packed_dataset_match_reference_bit_exact(tmp_path):
             assert x.dtype == y.dtype and torch.equal(x, y)
         assert float(a[4][0, 0]) == float(i)
     shutil.rmtree(root)
+
+
+def _gloo_rsag_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reed_amd.parallel import GradReducer
+        red = GradReducer.__new__(GradReducer)          # the collective forms only: no model, no GPU
+        red.rank, red.world, red._rccl = rank, world, False
+        res = {}
+        for algo in ("allreduce", "rsag"):
+            red.algo = algo
+            for n in (1, 7, 4096, 4099):                # below one element per rank, ragged tails, whole multiples
+                t = torch.arange(n, dtype=torch.float32) * (rank + 1) + rank
+                red._t_allreduce_avg(t)
+                res[(algo, n)] = t.clone()
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world4_reduce_scatter_allgather_form():
+    """REED_COMM_ALGO=rsag (each bucket as reduce-scatter + all-gather, tail through all-reduce) on FOUR ranks over gloo:
+    same averages as the plain all-reduce form for bucket sizes below / not divisible by / divisible by the world size,
+    identical on every rank."""
+    import torch.multiprocessing as mp
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_gloo_rsag_worker, args=(r, world, 29771, ret)) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(180)
+        assert p.exitcode == 0
+    for n in (1, 7, 4096, 4099):
+        exp = sum((torch.arange(n, dtype=torch.float32) * (r + 1) + r) for r in range(world)) / world
+        for r in range(world):
+            for algo in ("allreduce", "rsag"):
+                torch.testing.assert_close(ret[r][(algo, n)], exp, rtol=1e-6, atol=1e-6)
+            assert torch.equal(ret[r][("rsag", n)], ret[0][("rsag", n)])

@@ -573,9 +573,10 @@ def test_gradient_accumulation_matches_full_batch(dev):
     torch.testing.assert_close(out[2][2], out[1][2], atol=1e-6, rtol=0)
 
 
-def test_fp16_is_inference_only_and_switch_restores(dev):
-    """precision='fp16' (the sampling build) refuses a training forward, and the library selection is restored after every
-    forward: a bf16 training step right after an fp16 evaluation of another model is bit-identical to one without it."""
+def test_fp16_switch_restores_and_trains(dev):
+    """The library selection is restored after every forward: a bf16 training step right after an fp16 evaluation of
+    another model is bit-identical to one without it; a precision='fp16' model trains too (IEEE-half operands), with
+    gradients close to the bf16 ones, and changing the precision between forward and backward is refused."""
     from reed_amd import ops
     from reed_amd.loss import SILoss
     c = TINY_CASES["hd64"]
@@ -584,14 +585,17 @@ def test_fp16_is_inference_only_and_switch_restores(dev):
     x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 13, c["zspec"], T, cfg["num_classes"])
     lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
 
-    def step(m):
+    def fwd(m):
         m.train()
         m.force_drop_mask = drop_u < 0.1
         for p in m.parameters():
             p.grad = None
         m.engine().zero_grad()
         out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
-        (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+        return out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+
+    def step(m):
+        fwd(m).backward()
         torch.cuda.synchronize()
         return m._arena.grad.clone()
 
@@ -607,8 +611,146 @@ def test_fp16_is_inference_only_and_switch_restores(dev):
     assert ops._PRECISION == "bf16"
     assert torch.isfinite(o16).all() and 0 < (o16 - ob).abs().max().item() < 0.1 * ob.abs().max().item()
     assert torch.equal(step(m), g0)
-    s.precision = "fp16"
-    s.train()
-    with pytest.raises(RuntimeError):
-        lf(s, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+    m.precision = "fp16"
+    g16 = step(m)
     assert ops._PRECISION == "bf16"
+    assert torch.isfinite(g16).all() and not torch.equal(g16, g0)
+    assert cos(g16.cpu(), g0.cpu()) > 0.999
+    total = fwd(m)
+    m.precision = "bf16"
+    with pytest.raises(RuntimeError, match="precision changed"):
+        total.backward()
+    assert ops._PRECISION == "bf16"
+
+
+@pytest.mark.parametrize("name", ["hd64", "xl3"])
+def test_fp16_training_gradients_vs_reference(dev, name):
+    """--mixed-precision fp16: loss x 1024 backward through the IEEE-half build against the reference under
+    autocast(float16) with the same scale (fp16.npz): every parameter's unscaled gradient norm and the element probes."""
+    from reed_amd.loss import SILoss
+    g = load("fp16")
+    c = TINY_CASES[name]
+    cfg = c["cfg"]
+    T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 11, c["zspec"], T, cfg["num_classes"])
+    m = build_hip_model(cfg, dev, 11)
+    m.precision = "fp16"
+    m.train()
+    m.force_drop_mask = drop_u < 0.1
+    lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
+    out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+    total = out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+    (total * 1024.0).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(total.detach()), float(g[f"{name}.total"]), rtol=FP16_TRAIN_LOSS_BAR)
+    np.testing.assert_allclose(out["denoising_loss"].detach().cpu().numpy(), g[f"{name}.denoising_loss"],
+                               rtol=FP16_TRAIN_LOSS_BAR)
+    worst = [0.0, ""]
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = float(g[f"{name}.gnorm.{k}"])
+        nh = p.grad.detach().double().norm().item() / 1024.0
+        if ref < 5e-5:
+            assert nh < 5e-4, (k, nh, ref)
+            continue
+        d = abs(nh / ref - 1)
+        if d > worst[0]:
+            worst = [d, k]
+    worst_c = 1.0
+    for k in ("final_layer.linear.weight", "blocks.0.attn.qkv.bias", "x_embedder.proj.weight", "projectors.0.4.bias",
+              "blocks.1.adaLN_modulation.1.bias"):
+        gh = dict(m.named_parameters())[k].grad.detach().cpu() / 1024.0
+        worst_c = min(worst_c, cos(gh, torch.from_numpy(g[f"{name}.grad.{k}"])))
+    print(f"[fp16 {name}] worst |norm ratio - 1| vs fp16 reference {worst[0]:.5f} ({worst[1]}), worst probe cosine "
+          f"{worst_c:.6f}")
+    assert worst[0] <= FP16_TRAIN_NORM_BAR, worst
+    assert worst_c >= FP16_TRAIN_COS_BAR, worst_c
+
+
+FP16_TRAIN_LOSS_BAR = 1e-3     # fp16 operands carry 3 more mantissa bits than bf16
+FP16_TRAIN_NORM_BAR = 0.001
+FP16_TRAIN_COS_BAR = 0.9999
+
+
+def _fp16_trainer(dev, init_scale, **optkw):
+    import copy
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.optim import FusedAdamWEMA
+    from reed_amd.trainer import TrainStep
+    m = SiT_models["SiT-S/2"](z_dims=[768], z_types=["i"], encoder_depth=8)
+    detfill.fill_state_dict(m.state_dict(), base_seed=0)
+    m = m.to(dev).train()
+    m.precision = "fp16"
+    ema = copy.deepcopy(m).requires_grad_(False).eval()
+    opt = FusedAdamWEMA(m, ema, lr=1e-4, max_grad_norm=1.0, init_scale=init_scale, **optkw)
+    lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+    ts = TrainStep(m, lf, opt, diffusion_warm_up_steps=0)
+    return m, ema, opt, ts
+
+
+def _fp16_steps(m, ts, opt, dev, steps):
+    rec = {"loss": [], "grad_norm": [], "scale": []}
+    for s in range(steps):
+        x, noise, t, y, drop_u, zs = inputs(8, 4, 32, s, [(768, "i")], 256, 1000)
+        m.force_drop_mask = drop_u < 0.1
+        r = ts(x.to(dev), y.to(dev), [z.to(dev) for z in zs], time_input=t, noises=noise)
+        rec["loss"].append(float(r["loss"])); rec["grad_norm"].append(float(r["grad_norm"]))
+        rec["scale"].append(float(opt.scaler_state[0]))
+    opt.flush()
+    return rec
+
+
+def test_fp16_training_trajectory_vs_reference(dev):
+    """SiT-S/2 + 768-d alignment, B = 8, 6 optimiser steps under --mixed-precision fp16 through TrainStep (scaled loss,
+    device-side unscale / clip / step / scale update) against the reference under autocast(float16) + GradScaler."""
+    g = load("fp16")
+    m, ema, opt, ts = _fp16_trainer(dev, 65536.0)
+    rec = _fp16_steps(m, ts, opt, dev, 6)
+    print("HIP :", [f"{v:.5f}" for v in rec["loss"]], [f"{v:.4f}" for v in rec["grad_norm"]])
+    print("REF :", [f"{v:.5f}" for v in g["s2.loss"]], [f"{v:.4f}" for v in g["s2.grad_norm"]])
+    np.testing.assert_allclose(rec["loss"], g["s2.loss"], atol=2e-4)      # measured 1e-5
+    np.testing.assert_allclose(rec["grad_norm"], g["s2.grad_norm"], rtol=2e-3)   # measured 1e-4
+    assert rec["scale"] == list(g["s2.scale"])
+    assert opt.scaler_state.tolist() == [65536.0, 6.0, 0.0, 6.0]
+    sd, esd = m.state_dict(), ema.state_dict()
+    for k in ("blocks.0.attn.qkv.weight", "final_layer.linear.weight", "t_embedder.mlp.2.bias"):
+        np.testing.assert_allclose(sd[k].flatten()[:64].cpu().numpy(), g["s2.w." + k], atol=2e-4)
+        np.testing.assert_allclose(esd[k].flatten()[:64].cpu().numpy(), g["s2.ema." + k], atol=1e-5)
+    assert {v["step"].item() for v in opt.state_dict()["state"].values()} == {6.0}
+
+
+def test_fp16_overflow_steps_are_skipped(dev):
+    """init_scale 2^40: every one of the 6 steps overflows fp16 in the backward. As GradScaler does: the logged norm is not
+    finite, the scale halves, weights / Adam moments / step count stay, the EMA update still runs (and leaves EMA = weights)."""
+    g = load("fp16")
+    m, ema, opt, ts = _fp16_trainer(dev, 2.0 ** 40)
+    w0 = m._arena.master.clone()
+    rec = _fp16_steps(m, ts, opt, dev, 6)
+    np.testing.assert_allclose(rec["loss"], g["s2_overflow.loss"], atol=2e-3)
+    assert not np.isfinite(rec["grad_norm"]).any() and not np.isfinite(g["s2_overflow.grad_norm"]).any()
+    assert rec["scale"] == list(g["s2_overflow.scale"])
+    assert torch.equal(m._arena.master, w0) and torch.equal(ema._arena.master, w0)
+    assert not opt.exp_avg.any() and not opt.exp_avg_sq.any()
+    assert opt.scaler_state.tolist() == [2.0 ** 34, 0.0, 1.0, 0.0]
+    assert opt.state_dict()["state"] == {}
+
+
+def test_fp16_scale_grows_and_first_clean_step_matches(dev):
+    """growth_interval clean steps double the scale (GradScaler.update); a run that first overflows once (scale 2^17 x 2^23)
+    then takes the same first step as one that never did: skipped steps leave no trace in the bias corrections."""
+    m, ema, opt, ts = _fp16_trainer(dev, 65536.0, growth_interval=2)
+    rec = _fp16_steps(m, ts, opt, dev, 5)
+    assert rec["scale"] == [65536.0, 131072.0, 131072.0, 262144.0, 262144.0]
+    assert opt.scaler_state.tolist() == [262144.0, 1.0, 0.0, 5.0]
+    a = _fp16_trainer(dev, 65536.0)
+    b = _fp16_trainer(dev, 2.0 ** 40, backoff_factor=2.0 ** -24)
+    x, noise, t, y, drop_u, zs = inputs(8, 4, 32, 0, [(768, "i")], 256, 1000)
+    for mm, _, oo, tt in (a, b, b):
+        mm.force_drop_mask = drop_u < 0.1
+        tt(x.to(dev), y.to(dev), [z.to(dev) for z in zs], time_input=t, noises=noise)
+        oo.flush()
+    assert b[2].scaler_state.tolist() == [65536.0, 1.0, 0.0, 1.0]
+    # both ran the clean step at scale 65536 from the same weights: the same update
+    torch.testing.assert_close(b[0]._arena.master, a[0]._arena.master, atol=1e-7, rtol=0)

@@ -317,3 +317,42 @@ def test_vit_towers():
     np.testing.assert_allclose(ot.preprocess(raw, "jepa")[:, :, ::37, ::41].numpy(), g["pre.jepa.sample"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(ot.preprocess(raw, "mae")[:, :, ::37, ::41].numpy(), g["pre.mae.sample"], rtol=1e-6, atol=1e-6)
     assert ot.preprocess(raw, "mocov3").shape == (2, 3, 256, 256) and ot.preprocess(raw, "dinov2").shape == (2, 3, 224, 224)
+
+
+def test_fp16_autocast_and_grad_scaler():
+    """--mixed-precision fp16 (fp16.npz: the reference under autocast(float16) + GradScaler): the oracle's tiny-case
+    losses, two steps of the S/2 trajectory, and the skipped-step path (scale halves, weights stay)."""
+    g = load("fp16")
+    for name in ("hd64", "xl3"):
+        case = TINY_CASES[name]
+        cfg = case["cfg"]
+        P = detfill.fill_state_dict(osit.init_params(cfg), base_seed=11)
+        P = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in P.items()}
+        T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+        x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 11, case["zspec"], T, cfg["num_classes"])
+        om = osit.OracleModel(P, cfg, training=True, autocast_dtype=torch.float16)
+        om.drop_mask = drop_u < 0.1
+        o = oloss.si_loss(om, x, dict(y=y), zs, enc_names=case["enc"], loss_weights={"dinov2": 1.0}, t=t, noise=noise)
+        total = o["denoising_loss"].mean() + 0.5 * o["proj_loss"]
+        np.testing.assert_allclose(float(total.detach()), g[f"{name}.total"], rtol=1e-3)
+        (total * 1024.0).backward()
+        for k in ("final_layer.linear.weight", "blocks.0.attn.qkv.bias", "projectors.0.4.bias"):
+            ref = g[f"{name}.grad.{k}"]
+            got = (P[k].grad / 1024.0).numpy()
+            assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-7, (name, k)
+    cfg = osit.make_config("SiT-S/2", z_dims=[768], z_types=["i"], encoder_depth=8)
+    for tag, init, steps in (("s2", 65536.0, 2), ("s2_overflow", 2.0 ** 40, 2)):
+        P = detfill.fill_state_dict(osit.init_params(cfg), base_seed=0)
+        tr = otrain.Trainer(P, cfg, ["dinov2"], [1.0], diffusion_warm_up_steps=0, autocast_dtype=torch.float16,
+                            init_scale=init)
+        for s in range(steps):
+            x, noise, t, y, drop_u, zs = inputs(8, 4, 32, s, [(768, "i")], 256, 1000)
+            r = tr.step(x, y, zs, t=t, noise=noise, drop_mask=drop_u < 0.1)
+            np.testing.assert_allclose(r["loss"], g[f"{tag}.loss"][s], rtol=2e-3)
+            assert r["scale"] == g[f"{tag}.scale"][s]
+            if tag == "s2":
+                np.testing.assert_allclose(r["grad_norm"], g[f"{tag}.grad_norm"][s], rtol=1e-2)
+            else:
+                assert not np.isfinite(r["grad_norm"]) and not np.isfinite(g[f"{tag}.grad_norm"][s])
+        if tag == "s2_overflow":   # every step skipped: the weights are the initial ones
+            assert torch.equal(tr.P["blocks.0.attn.qkv.weight"].detach(), P["blocks.0.attn.qkv.weight"])

@@ -366,7 +366,7 @@ def grad_probe(g):
 
 
 def ref_train_traj(ref_sit, ref_loss, model_name, kw, B, steps, zspec, enc_names, coeffs, autocast, proj_coeff=0.5,
-                   align=True, seed=0, grad_probes=None):
+                   align=True, seed=0, grad_probes=None, ac_dtype=torch.bfloat16, scaler=None):
     """Reference-equivalent optimisation steps (train.py:387-412): SILoss -> combine -> backward -> clip -> AdamW -> EMA."""
     m = build_ref_model(ref_sit, model_name, seed=seed, **kw)
     m.train()
@@ -374,11 +374,11 @@ def ref_train_traj(ref_sit, ref_loss, model_name, kw, B, steps, zspec, enc_names
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8)
     lf = ref_loss.SILoss(enc_names=list(enc_names), loss_weights={n: c for n, c in zip(enc_names, coeffs)})
     T = (kw.get("input_size", 32) // 2) ** 2
-    rec = {k: [] for k in ("loss", "denoising_loss", "proj_loss", "grad_norm")}
+    rec = {k: [] for k in ("loss", "denoising_loss", "proj_loss", "grad_norm", "scale")}
 
     def model(xx, tt, **k):
         if autocast:
-            with torch.autocast("cpu", dtype=torch.bfloat16):
+            with torch.autocast("cpu", dtype=ac_dtype):
                 o, z = m(xx, tt, **k)
             return o.float(), [a.float() for a in z]
         return m(xx, tt, **k)
@@ -392,18 +392,27 @@ def ref_train_traj(ref_sit, ref_loss, model_name, kw, B, steps, zspec, enc_names
         proj = o["proj_loss"].mean()
         total = den * 1.0 + (proj * proj_coeff * 1.0 if align else 0.0)
         opt.zero_grad(set_to_none=True)
-        total.backward()
+        if scaler is not None:   # accelerate fp16: scaler.scale(loss).backward(); unscale_ before clip_grad_norm_ (train.py:401-407)
+            scaler.scale(total).backward()
+            scaler.unscale_(opt)
+        else:
+            total.backward()
         if grad_probes is not None and s == 0:   # step-1 gradients, before clipping
             named = dict(m.named_parameters())
             for k in grad_probes[0]:
                 grad_probes[1]["gnorm." + k], grad_probes[1]["gslice." + k] = grad_probe(named[k].grad)
         gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
-        opt.step()
+        if scaler is not None:
+            scaler.step(opt)          # skipped when unscale_ found inf / nan
+            scaler.update()
+        else:
+            opt.step()
         with torch.no_grad():
             for k, p in m.named_parameters():
                 ema[k].mul_(0.9999).add_(p.data, alpha=1 - 0.9999)
         rec["loss"].append(float(total)); rec["denoising_loss"].append(float(den))
         rec["proj_loss"].append(float(proj)); rec["grad_norm"].append(float(gn))
+        rec["scale"].append(scaler.get_scale() if scaler is not None else 1.0)
         print(f"    step {s}: loss {float(total):.6f} den {float(den):.6f} proj {float(proj):.6f} gn {float(gn):.4f} ({time.time() - t0:.1f}s)")
     sd = m.state_dict()
     probe = {k: sd[k].flatten()[:64].clone() for k in ("blocks.0.attn.qkv.weight", "final_layer.linear.weight", "t_embedder.mlp.2.bias")}
@@ -482,6 +491,50 @@ def g_samplers_long(ref_sit, ref_loss, ref_samplers):
     out["n_evals"] = np.array(len(states))
     out["states"] = torch.stack(states[::9])
     save("samplers_long", **out)
+
+
+def g_fp16(ref_sit, ref_loss, ref_samplers):
+    """--mixed-precision fp16 (the reference's default and README recipe): the reference under torch.autocast(float16)
+    with torch.amp.GradScaler at accelerate's defaults (init 65536, x2 after 2000 clean steps, x0.5 on overflow).
+    (a) tiny cases: loss and every unscaled gradient norm + element probes at a fixed scale of 1024; (b) SiT-S/2 + 768-d
+    alignment, B = 8, 6 optimiser steps: per-step loss, unscaled grad-norm, scale after the step, weight / EMA probes;
+    (c) the same with init_scale 2^40: the first steps overflow and are skipped (scale halves, weights and Adam state
+    untouched, EMA still updated) until the scaled gradients fit fp16."""
+    out = {}
+    cases = {"hd64": dict(kw=tiny_kwargs(), zspec=[(128, "i")]),
+             "xl3": dict(kw=tiny_kwargs(D=1152, heads=16, input_size=16, projector_dim=256), zspec=[(128, "i")])}
+    for name, c in cases.items():
+        kw = c["kw"]
+        m = build_ref_model(ref_sit, "custom", seed=11, **kw)
+        m.train()
+        T = (kw["input_size"] // kw["patch_size"]) ** 2
+        x, noise, t, y, drop_u, zs = inputs(4, 4, kw["input_size"], 11, c["zspec"], T, kw["num_classes"])
+        lf = ref_loss.SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+
+        def model(xx, tt, **k):
+            with torch.autocast("cpu", dtype=torch.float16):
+                o, z = m(xx, tt, **k)
+            return o.float(), [a.float() for a in z]
+        with inject(t=t, noise=noise, drop_u=drop_u):
+            o = lf(model, x, dict(y=y), zs=zs)
+        total = o["denoising_loss"].mean() + 0.5 * o["proj_loss"]
+        (total * 1024.0).backward()
+        out[f"{name}.total"], out[f"{name}.denoising_loss"], out[f"{name}.proj_loss"] = total, o["denoising_loss"], o["proj_loss"]
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                out[f"{name}.gnorm.{k}"] = (p.grad / 1024.0).double().norm()
+        for k in ("final_layer.linear.weight", "blocks.0.attn.qkv.bias", "x_embedder.proj.weight", "projectors.0.4.bias",
+                  "blocks.1.adaLN_modulation.1.bias"):
+            out[f"{name}.grad.{k}"] = dict(m.named_parameters())[k].grad / 1024.0
+    kw = dict(input_size=32, num_classes=1000, z_dims=[768], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False)
+    for tag, init in (("s2", 65536.0), ("s2_overflow", 2.0 ** 40)):
+        sc = torch.amp.GradScaler("cpu", init_scale=init)
+        rec, probe, ema = ref_train_traj(ref_sit, ref_loss, "SiT-S/2", kw, 8, 6, [(768, "i")], ["dinov2"], [1.0], True,
+                                         ac_dtype=torch.float16, scaler=sc)
+        out.update({f"{tag}.{k}": np.array(v) for k, v in rec.items()})
+        out.update({f"{tag}.w.{k}": v for k, v in probe.items()})
+        out.update({f"{tag}.ema.{k}": v for k, v in ema.items()})
+    save("fp16", **out)
 
 
 def g_xl_c4(ref_sit, ref_loss, ref_samplers):
@@ -665,7 +718,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "clip": g_clip, "dataset": g_dataset, "towers": g_towers}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
