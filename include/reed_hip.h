@@ -48,6 +48,14 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
               int64_t ldr, const void* bias, const void* gate, int64_t ldgate, int rows_per_gate,
               float* dbias, int accumulate, int split_k, int64_t slab_stride, void* stream);
 
+/* The weight gradients of one transformer block (autograd of the four nn.Linear of image/models/sit.py:114-129's Attention /
+ * Mlp) in ONE launch without split-K: n <= 4 problems dw_i f32 [n_out_i, k_in_i] (+)= dy_i[tokens, n_out_i]^T x_i[tokens, k_in_i]
+ * (16-bit operands, row-major, leading dims = widths), optional dbias_i f32 [n_out_i] (+)= colsum(dy_i).  Pointer / int
+ * arrays live on the host.  k_in % 128 == 0, n_out % 16 == 0.  Returns 1002 without launching when the problems' 256x128 /
+ * 128x256 tiles do not fit one round of 2 x CUs workgroups (use reed_gemm layout 3 / 4 with split_k then). */
+int reed_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* dw, float* const* dbias,
+                     const int* n_out, const int* k_in, int tokens, int accumulate, void* stream);
+
 /* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel, 144 = force
  * the 256x144 kernel wherever it applies (NT / NN, bf16-output epilogue, N % 144 == 0, no split-K) */
 int reed_gemm_force_tile(int tile);

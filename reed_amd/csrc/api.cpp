@@ -1,5 +1,6 @@
 // C-ABI glue: error reporting, version, and the GEMM entry point (see include/reed_hip.h).
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -58,4 +59,31 @@ extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, c
   if (epilogue == EPI_GATE_RES) REED_CHECK_ARG(R && gate, "reed_gemm: gate-residual epilogue needs R and gate");
   if (epilogue == EPI_DGELU || epilogue == EPI_DSILU) REED_CHECK_ARG(R, "reed_gemm: activation-grad epilogue needs R");
   return reed_gemm_launch(layout, epilogue, a, split_k, (hipStream_t)stream);
+}
+
+int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream);   // gemm_tn.hip
+
+extern "C" int reed_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* dw, float* const* dbias,
+                                const int* n_out, const int* k_in, int tokens, int accumulate, void* stream) {
+  REED_CHECK_ARG(n >= 1 && n <= 4 && dy && x && dw && n_out && k_in && tokens > 0, "reed_wgrad_group: bad arguments");
+  GemmArgs a[4];
+  memset(a, 0, sizeof(a));
+  for (int i = 0; i < n; ++i) {
+    REED_CHECK_ARG(dy[i] && x[i] && dw[i], "reed_wgrad_group: null operand in problem %d", i);
+    REED_CHECK_ARG(((uintptr_t)dy[i] % 16) == 0 && ((uintptr_t)x[i] % 16) == 0 && ((uintptr_t)dw[i] % 16) == 0 &&
+                       n_out[i] % 8 == 0, "reed_wgrad_group: problem %d: operands must be 16-byte aligned", i);
+    a[i].P = (const bf16*)dy[i];
+    a[i].Q = (const bf16*)x[i];
+    a[i].ldp = n_out[i];
+    a[i].ldq = k_in[i];
+    a[i].M = n_out[i];
+    a[i].N = k_in[i];
+    a[i].K = tokens;
+    a[i].C = dw[i];
+    a[i].ldc = k_in[i];
+    a[i].dbias = dbias ? dbias[i] : nullptr;
+    a[i].accumulate = accumulate;
+    a[i].rows_per_gate = 1;
+  }
+  return reed_gemm_tn_group_launch(n, a, (hipStream_t)stream);
 }

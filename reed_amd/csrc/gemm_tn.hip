@@ -12,6 +12,8 @@
 // for fc2 (1152x4608).  Ragged M needs no masking: rows >= M read whatever the descriptor returns and are never stored.
 // Operand tiles use gemm_common.hpp's k-strided format ([k][128 columns], 256-B rows, chunk swizzle tr_sw) at 32
 // k-rows per tile and are read with the transposing LDS read; staging is LDS-DMA as in gemm.hip.
+#include <string.h>
+
 #include "gemm_common.hpp"
 
 namespace {
@@ -34,20 +36,19 @@ __device__ __forceinline__ void stage_sub(__amdgpu_buffer_rsrc_t rs, char* tile,
   }
 }
 
+// bid: the workgroup's index among the problem's tiles; z / nz: K slice and slice count (1 = write C directly)
 template <bool WIDE>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, int bid, const int z, const int nz) {
   constexpr int TM = WIDE ? 4 : 8, TNN = WIDE ? 8 : 4;        // 16x16 MFMA tiles per wave along M / N
   constexpr int PSUB = WIDE ? 1 : 2, QSUB = WIDE ? 2 : 1;     // 128-column sub-tiles of the P / Q operand tile
   constexpr int BMT = PSUB * 128, BNT = QSUB * 128;
   constexpr int STAGE = (PSUB + QSUB) * SUB_BYTES;            // 24 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
   const int ntm = (a.M + BMT - 1) / BMT, ntn = a.N / BNT;
   const int nwg = ntm * ntn;
-  int bid = blockIdx.x;
   {
     int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -58,7 +59,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   const int gs = min(ntm - first_m, GM);
   const int tm = first_m + (bid % per_group) % gs;
   const int tn = (bid % per_group) / gs;
-  const int z = blockIdx.y;
   const int m0 = tm * BMT, n0 = tn * BNT;
   const int kbeg = z * a.ksplit_len;
   const int kend = min(a.K, kbeg + a.ksplit_len);
@@ -136,12 +136,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + prow + i * 16 + (lane & 15);
       if (m < a.M) {
-        if (gridDim.y > 1) a.dbias[(long)z * a.slab_stride + m] = accb[i][0];
+        if (nz > 1) a.dbias[(long)z * a.slab_stride + m] = accb[i][0];
         else if (a.accumulate) a.dbias[m] += accb[i][0];
         else a.dbias[m] = accb[i][0];
       }
     }
   }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_tn_body<WIDE>(a, smem, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// The weight gradients of one transformer block in ONE launch, no split-K: at K = b x 256 tokens a single wgrad has too
+// few tiles for the 512 workgroup slots (SiT-XL/2: 162 / 162 / 126 / 45), which the per-GEMM path fills with 3-6 K slices
+// written as fp32 slabs and summed by a second kernel (at b = 32 that reduce was 6 % of the step and the slab traffic
+// slowed the GEMMs to 490-870 TFLOP/s).  Together the four problems have 495 tiles, 512 with each problem's run padded to
+// a multiple of 8 (the XCD interleave): one full round of equal-length K loops writing the gradient arena directly —
+// deterministic, and the same at every batch size.
+struct TnGroupArgs {
+  GemmArgs a[4];
+  int first[5];   // first workgroup of each problem (multiples of 8); first[n] = grid size
+  int wide[4];
+  int n;
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.first[i]) p = i;
+  const int bid = blockIdx.x - g.first[p];
+  const GemmArgs& a = g.a[p];
+  const int wide = g.wide[p];
+  const int tiles = wide ? ((a.M + 127) / 128) * (a.N / 256) : ((a.M + 255) / 256) * (a.N / 128);
+  if (bid >= tiles) return;   // padding of the problem's run
+  if (wide) gemm_tn_body<true>(a, smem, bid, 0, 1);
+  else gemm_tn_body<false>(a, smem, bid, 0, 1);
 }
 
 template <bool WIDE>
@@ -160,6 +193,44 @@ int launch_tn(const GemmArgs& a, int splits, hipStream_t stream) {
 }
 
 }  // namespace
+
+int reed_num_cus();   // gemm256.hip
+
+// n <= 4 problems dw_i[M_i, N_i] f32 (+)= dy_i[K, M_i]^T x_i[K, N_i] (+ optional dbias_i) sharing the token count K.
+// Returns REED_ERR_UNSUPPORTED (nothing launched) when the tiles do not fit one round of workgroup slots.
+int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) {
+  REED_CHECK_ARG(n >= 1 && n <= 4, "wgrad_group: 1..4 problems, got %d", n);
+  TnGroupArgs g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  int at = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& a = probs[i];
+    REED_CHECK_ARG(a.N % 128 == 0 && a.M % 16 == 0 && a.K == probs[0].K && a.K > 0,
+                   "wgrad_group: problem %d: M=%d N=%d K=%d (N must be a multiple of 128, M of 16, K shared)", i, a.M, a.N, a.K);
+    const int tall = cdiv(a.M, 256) * (a.N / 128);
+    const int wid = (a.N % 256 == 0) ? cdiv(a.M, 128) * (a.N / 256) : (1 << 30);
+    g.a[i] = a;
+    g.a[i].ksplit_len = cdiv(a.K, TBK) * TBK;
+    g.wide[i] = wid < tall;
+    g.first[i] = at;
+    at += (min(tall, wid) + 7) & ~7;
+  }
+  g.first[n] = at;
+  if (at > 2 * reed_num_cus()) {
+    reed_set_error("wgrad_group: %d workgroups do not fit one round of %d slots", at, 2 * reed_num_cus());
+    return REED_ERR_UNSUPPORTED;
+  }
+  constexpr int LDS = 2 * 3 * SUB_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  REED_KLAUNCH(gemm_tn_group_kernel, dim3(at), dim3(256), LDS, stream, g);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
 
 // tile: 1 = 256x128, 2 = 128x256.  EPI_F32 only (weight gradients); the caller has validated the arguments.
 int reed_gemm_tn_launch(int tile, GemmArgs a, int splits, hipStream_t stream) {

@@ -10,6 +10,7 @@ Per block the launch sequence is
         qkv {wgrad, dgrad}, LN-bwd, modulation-grad reduce                                (14 launches)
 and the modulation of ALL blocks is one GEMM forward (silu(c) @ W_ada_all^T) and two backward.
 """
+import contextlib
 import os
 import types
 
@@ -274,6 +275,23 @@ class Engine:
         return zt.view(B, T, Z) if img else zt
 
     # ---- backward ------------------------------------------------------------------
+    def _wgrad_block(self, probs, Mtok, acc, dev, side):
+        """The four weight gradients of a block as one launch without split-K (ops.wgrad_group; csrc/gemm_tn.hip): probs =
+        [(dy, x, weight name, n_out, k_in), ...].  Falls back to the per-GEMM path when the device is too small."""
+        args = [(dy, x, self.G(w), self.G(w.replace("weight", "bias")), N, K) for dy, x, w, N, K in probs]
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            done = ops.wgrad_group(args, Mtok, accumulate=acc)
+        if not done:
+            for dy, x, w, N, K in probs:
+                self._wgrad(dy, x, w, Mtok, N, K, acc, dev, side=side)
+            return
+        if side is not None:
+            for dy, x, _, _, _ in probs:
+                dy.record_stream(side)
+                x.record_stream(side)
+
     def _wgrad(self, dy, x, wname, Mtok, N, K, acc, dev, bias_done=False, side=None):
         """dW (+)= dy^T x and db (+)= colsum(dy) into the gradient arena: the TN kernel / tile ops.plan_wgrad picks
         (256x128, 128x256 or 128x128) with wave-quantised split-K through slabs (deterministic reduce); the bias gradient rides along as an extra
@@ -330,6 +348,7 @@ class Engine:
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
 
+        group_wgrad = ops.wgrad_group_fits([(D, Hm), (Hm, D), (D, D), (3 * D, D)])
         side = None
         if self.wgrad_stream or (self.wgrad_stream is None and M <= self.wgrad_stream_max_tokens):
             if self._side is None:
@@ -439,18 +458,29 @@ class Engine:
             else:
                 pg2, dy2 = f32(M // 16, D), bf(M, D)
                 ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T)
-            self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, side=side)
+            wg = [] if group_wgrad else None   # the block's four weight gradients: one launch at the end of the block
+            if wg is not None:
+                wg.append((dy2, bk.u, b + "mlp.fc2.weight", D, Hm))
+            else:
+                self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, side=side)
             da1 = bf(M, Hm)
             self._dgrad(EPI_DGELU, dy2, b + "mlp.fc2.weight", M, D, Hm, da1, R=bk.a1, ldr=Hm)
-            self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev, side=side)
-            dh2 = dy2 if side is None else bf(M, D)  # reuse dy2 unless the side stream may still be reading it
+            if wg is not None:
+                wg.append((da1, bk.h2, b + "mlp.fc1.weight", Hm, D))
+            else:
+                self._wgrad(da1, bk.h2, b + "mlp.fc1.weight", M, Hm, D, acc, dev, side=side)
+            # reuse dy2 unless its weight gradient (side stream / grouped launch) may still have to read it
+            dh2 = dy2 if side is None and wg is None else bf(M, D)
             self._dgrad(EPI_BF16, da1, b + "mlp.fc1.weight", M, Hm, D, dh2)
             # LN2 backward + the attention branch's gate backward in one pass over dx
             pl2 = f32(M // 16, 2, D)
             pg1, dy1 = f32(M // 16, D), bf(M, D)
             ops.ln_modulate_bwd_gate(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, bk.y1, mb + 4 * D, Nall,
                                      dy1, pg1, None, M, D, T)
-            self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, side=side)
+            if wg is not None:
+                wg.append((dy1, bk.o, b + "attn.proj.weight", D, D))
+            else:
+                self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, side=side)
             do = bf(M, D)
             self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
             dqkv = bf(M, 3 * D)
@@ -464,7 +494,11 @@ class Engine:
                 ops.rowsum_f32(part, nb, self.G(b + "attn.q_norm.weight"), 4 * hd, acc,
                                ws=self.ws((nb + 63) // 64 * 4 * hd, dev))
                 dqkv = dpre
-            self._wgrad(dqkv, bk.h, b + "attn.qkv.weight", M, 3 * D, D, acc, dev, side=side)
+            if wg is not None:
+                wg.append((dqkv, bk.h, b + "attn.qkv.weight", 3 * D, D))
+                self._wgrad_block(wg, M, acc, dev, side)
+            else:
+                self._wgrad(dqkv, bk.h, b + "attn.qkv.weight", M, 3 * D, D, acc, dev, side=side)
             dh1 = do  # reuse
             self._dgrad(EPI_BF16, dqkv, b + "attn.qkv.weight", M, 3 * D, D, dh1)
             pl1 = f32(M // 16, 2, D)

@@ -155,6 +155,52 @@ WGRAD_SPLIT_MAX = int(__import__("os").environ.get("REED_WGRAD_SPLIT_MAX", "8"))
 WGRAD_TILES = ((TN, 128, 128, 1.0), (TN_TALL, 256, 128, 1.10), (TN_WIDE, 128, 256, 1.10))   # layout, rows, cols, rate
 
 
+def wgrad_group_blocks(shapes):
+    """Workgroups reed_wgrad_group launches for [(n_out, k_in), ...]: per problem the smaller of its 256x128 / 128x256 tile
+    counts, each run padded to a multiple of 8 (csrc/gemm_tn.hip)."""
+    tot = 0
+    for n_out, k_in in shapes:
+        if k_in % 128 or n_out % 16:
+            return None
+        tall = ((n_out + 255) // 256) * (k_in // 128)
+        wide = ((n_out + 127) // 128) * (k_in // 256) if k_in % 256 == 0 else 1 << 30
+        tot += (min(tall, wide) + 7) // 8 * 8
+    return tot
+
+
+def wgrad_group_fits(shapes, min_fill=0.75):
+    """True when the block's weight gradients should go out as ONE launch without split-K: their tiles fill one round of
+    workgroup slots to at least min_fill (SiT-XL/2: exactly 512 of 512; smaller models leave the slots to split-K)."""
+    import os
+    if os.environ.get("REED_WGRAD_GROUP", "1") == "0":
+        return False
+    n = wgrad_group_blocks(shapes)
+    slots = 2 * int(os.environ.get("REED_GEMM_CUS", "0") or 0) or WGRAD_SLOTS
+    return n is not None and len(shapes) <= 4 and min_fill * slots <= n <= slots
+
+
+def wgrad_group(problems, tokens, accumulate=False):
+    """problems: [(dy [tokens, n_out], x [tokens, k_in], dw f32 [n_out, k_in], dbias f32 [n_out] | None, n_out, k_in), ...]
+    (tensors or raw device addresses) -> one launch of the 256x128 / 128x256 TN tiles, no split-K (reed_wgrad_group).
+    Returns False, with nothing launched, when the device has too few workgroup slots for one round."""
+    n = len(problems)
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    dy = vp(*[_p(q[0]) for q in problems])
+    x = vp(*[_p(q[1]) for q in problems])
+    dw = vp(*[_p(q[2]) for q in problems])
+    db = vp(*[_p(q[3]) for q in problems])
+    no = ip(*[int(q[4]) for q in problems])
+    ki = ip(*[int(q[5]) for q in problems])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
+    L = _lib.load(_PRECISION)
+    rc = L.reed_wgrad_group(n, cast(dy), cast(x), cast(dw), cast(db), cast(no), cast(ki), int(tokens), int(accumulate),
+                            _stream())
+    if rc == 1002:
+        return False
+    _lib.check(rc, "reed_wgrad_group", L)
+    return True
+
+
 def plan_wgrad(Mtok, N, K):
     """(layout, split_k) for dw[N,K] = dy[Mtok,N]^T x[Mtok,K]: which TN kernel and how many K slices.
     Tiles: gemm.hip's 128x128 (64x64 per wave) or gemm_tn.hip's 256x128 / 128x256 (128x64 / 64x128 per wave: 0.375

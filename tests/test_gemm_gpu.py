@@ -184,6 +184,65 @@ def test_tn_wgrad_tall_wide_tiles(dev, lay, Mtok, N, K, split, force_tile):
         assert torch.equal(d2, xx.float()[:N])
 
 
+@pytest.mark.parametrize("tokens,shapes", [
+    (512, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),     # the SiT-XL/2 block: 162 + 162 + 45 + 126 tiles
+    (1000, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),    # ragged token count
+    (256, [(384, 256), (640, 128)]),                                     # ragged last tile rows (1.5 and 2.5 tiles of 256)
+    (300, [(128, 128)]),
+])
+def test_wgrad_group(dev, tokens, shapes, force_tile):
+    """reed_wgrad_group (csrc/gemm_tn.hip): the weight + bias gradients of up to four linears in one launch without
+    split-K, against fp32 torch and against the per-GEMM path; accumulate; run-to-run bit-identical; identity operand."""
+    from reed_amd import ops
+    if force_tile != 0:
+        pytest.skip("one kernel: tile forcing does not apply")
+    g = torch.Generator().manual_seed(17)
+    probs, refs = [], []
+    for n_out, k_in in shapes:
+        dy = _bf(torch.randn(tokens, n_out, generator=g)).to(dev)
+        x = _bf(torch.randn(tokens, k_in, generator=g)).to(dev)
+        out = torch.full((n_out * k_in + n_out,), float("nan"), device=dev)
+        probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:], n_out, k_in))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    assert ops.wgrad_group(probs, tokens)
+    first = [(q[2].clone(), q[3].clone()) for q in probs]
+    for (dw, db), (rw, rb), q in zip(first, refs, probs):
+        torch.testing.assert_close(dw, rw, atol=1e-2, rtol=1e-3)
+        torch.testing.assert_close(db, rb, atol=1e-2, rtol=1e-3)
+        dw0, db0 = torch.zeros_like(dw), torch.zeros_like(db)
+        ops.linear_wgrad(q[0], q[1], dw0, dbias=db0, lay=ops.TN)
+        torch.testing.assert_close(dw, dw0, atol=2e-3, rtol=1e-4)        # same products, different summation order
+    for q in probs:
+        q[2].fill_(float("nan"))
+    assert ops.wgrad_group(probs, tokens)
+    assert all(torch.equal(q[2], f[0]) and torch.equal(q[3], f[1]) for q, f in zip(probs, first))
+    assert ops.wgrad_group(probs, tokens, accumulate=True)
+    for q, (rw, rb) in zip(probs, refs):
+        torch.testing.assert_close(q[2], 2 * rw, atol=2e-2, rtol=1e-3)
+        torch.testing.assert_close(q[3], 2 * rb, atol=2e-2, rtol=1e-3)
+    # without bias gradients, identity dy: dw = the first n_out rows of x exactly
+    n_out, k_in = shapes[-1]
+    eye = torch.eye(tokens, n_out, device=dev).to(torch.bfloat16)
+    xx = (torch.arange(tokens * k_in, device=dev).reshape(tokens, k_in) % 251).float().to(torch.bfloat16)
+    d2 = torch.full((n_out, k_in), float("nan"), device=dev)
+    assert ops.wgrad_group([(eye, xx, d2, None, n_out, k_in)], tokens)
+    assert torch.equal(d2[:min(n_out, tokens)], xx.float()[:min(n_out, tokens)])
+
+
+def test_wgrad_group_planning(dev):
+    """The SiT-XL/2 block fills the 512 workgroup slots exactly and is grouped; small models are left to split-K; a group
+    that does not fit one round is refused without launching."""
+    from reed_amd import ops
+    D, Hm = 1152, 4608
+    assert ops.wgrad_group_blocks([(D, Hm), (Hm, D), (D, D), (3 * D, D)]) == 512
+    assert ops.wgrad_group_fits([(D, Hm), (Hm, D), (D, D), (3 * D, D)])
+    assert not ops.wgrad_group_fits([(384, 1536), (1536, 384), (384, 384), (1152, 384)])      # SiT-S/2: 72 of 512
+    assert not ops.wgrad_group_fits([(Hm, Hm)] * 4)
+    z = torch.zeros(64, Hm, dtype=torch.bfloat16, device=dev)
+    dw = torch.zeros(Hm, Hm, device=dev)
+    assert ops.wgrad_group([(z, z, dw, None, Hm, Hm)] * 4, 64) is False
+
+
 def test_plan_wgrad_choices():
     """ops.plan_wgrad on the SiT-XL/2 block shapes: the tile the wave-quantisation model picks (tools/wgrad_sweep.py)."""
     from reed_amd import ops
