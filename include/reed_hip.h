@@ -37,7 +37,8 @@ int reed_half_kind(void);
  *   layout 2 TN: C[M,N] = P[K,M]^T Q[K,N]     (wgrad    dW = dy^T x), optional dbias[M] = colsum(P)
  *   layout 3 / 4: TN on a 256x128 / 128x256 output tile (128x64 / 64x128 per wave; epilogue 6 only; 4 needs N%256==0)
  * epilogue codes: see reed_amd/csrc/gemm.h (11 = exact GELU(erf) with the layout of 9; 0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
- *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual).  N%128==0 (NT/NN with a
+ *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual, 12 LayerScale + fp32 residual:
+ *   C f32 = R f32 + gamma[n] * float(bf16(acc + bias)) with `gate` = the fp32 gamma vector, NT only).  N%128==0 (NT/NN with a
  *   bf16-output epilogue also N%144==0: the 256x144 tile of csrc/gemm144.hip); K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
  *   dbias likewise holds split_k slabs of M floats AT THE SAME slab_stride — put slab 0 of dbias right behind slab 0
@@ -272,8 +273,9 @@ int reed_ln_affine_bf16(const void* x, const float* w, const float* b, void* out
 /* out (bf16 or f32, row stride ldo) = LayerNorm_fp32(x f32 [M,D]; eps) * w + b */
 int reed_ln_affine_f32(const float* x, const float* w, const float* b, void* out, int out_is_f32, int M, int D,
                        int64_t ldo, float eps, void* stream);
-/* out f32 [B,T,D]: row 0 = cls + pos[0] when cls != NULL (T = patches + 1), row t = float(patches bf16[b, t - ncls]) + pos[t] */
-int reed_vit_tokens(const void* patches, const float* cls, const float* pos, float* out, int B, int T, int D,
+/* out f32 [B,T,D]: rows t < nprefix = cls[t] + pos[t] (cls f32 [nprefix, D]: the class token, then DINOv2's register tokens
+ * with zero pos rows), rows t >= nprefix = float(patches bf16[b, t - nprefix]) + pos[t]; T = nprefix + patches */
+int reed_vit_tokens(const void* patches, const float* cls, int nprefix, const float* pos, float* out, int B, int T, int D,
                     void* stream);
 /* preprocess_raw_image (image/train.py:53-74): raw u8 [B,3,R,R] -> out f32 [B,3,S,S]; order 0: /255 -> bicubic -> normalise
  * ('clip'), order 1: /255 -> normalise -> bicubic ('dinov2', 'jepa'); S == R: no resampling ('mocov3', 'mae').

@@ -10,6 +10,15 @@ CLIP that image/utils.py:load_encoders can build, as image/train.py:351-357 runs
           position zero), forward_features incl. the final norm, class token dropped by train.py:355 — vit_base /
           vit_large at 256 x 256 (utils.py:73-82).
 
+  dinov2  image/utils.py:92-104: torch.hub facebookresearch/dinov2 `dinov2_vit{s,b,l}14[_reg]` (class DinoVisionTransformer, NOT
+          in the reference tree; restated from the published model: dinov2/models/vision_transformer.py prepare_tokens_with_masks
+          / forward_features, layers/block.py, layers/layer_scale.py): patch 14, [cls | patches] + pos_embed (learned 37 x 37
+          grid, resampled to 16 x 16 by utils.py:99-101), then 4 register tokens inserted behind the class token in the _reg
+          models, blocks x = x + gamma1 * attn(norm1 x); x = x + gamma2 * mlp(norm2 x) (LayerScale), final LayerNorm;
+          train.py:356 takes ['x_norm_patchtokens'] = normed tokens without class / register tokens.  Pinned against
+          transformers' Dinov2Model / Dinov2WithRegistersModel (an independent port of the hub model; tools/gen_golden.py:g_dinov2)
+          since the hub class cannot be fetched here.
+
 timm is un-vendored and unpinned (image/requirements.txt:5); its VisionTransformer semantics restated here (>= 0.9): Block =
 x + attn(norm1 x); x + mlp(norm2 x), LayerNorm(eps 1e-6 as the reference's constructors pass), Attention with qkv bias and
 softmax(q k^T / sqrt(hd)) v, Mlp fc1 -> nn.GELU() (exact) -> fc2, no LayerScale / drop-path at inference.
@@ -31,11 +40,16 @@ TOWERS = {   # the configurations image/utils.py:55-164 can name
     "mocov3-vit-b": dict(embed=768, depth=12, heads=12, patch=16, image=256, cls=True, final_norm=True, pos="moco"),
     "mocov3-vit-l": dict(embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=True, pos="moco"),
     "mae-vit-l": dict(embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=False, pos="learned"),
+    "dinov2-vit-b": dict(embed=768, depth=12, heads=12, patch=14, image=224, cls=True, final_norm=True, pos="learned", ls=True),
+    "dinov2-vit-l": dict(embed=1024, depth=24, heads=16, patch=14, image=224, cls=True, final_norm=True, pos="learned", ls=True),
+    "dinov2reg-vit-l": dict(embed=1024, depth=24, heads=16, patch=14, image=224, cls=True, final_norm=True, pos="learned",
+                            ls=True, reg=4),
 }
 
 
-def make_config(embed, depth, heads, patch, image, cls, final_norm, pos):
-    return dict(embed=embed, depth=depth, heads=heads, patch=patch, image=image, cls=cls, final_norm=final_norm, pos=pos)
+def make_config(embed, depth, heads, patch, image, cls, final_norm, pos, ls=False, reg=0):
+    return dict(embed=embed, depth=depth, heads=heads, patch=patch, image=image, cls=cls, final_norm=final_norm, pos=pos,
+                ls=ls, reg=reg)
 
 
 def param_shapes(cfg):
@@ -44,12 +58,16 @@ def param_shapes(cfg):
     s = {"patch_embed.proj.weight": (E, 3, P, P), "patch_embed.proj.bias": (E,), "pos_embed": (1, T, E)}
     if cfg["cls"]:
         s["cls_token"] = (1, 1, E)
+    if cfg.get("reg"):
+        s["register_tokens"] = (1, cfg["reg"], E)
     for i in range(cfg["depth"]):
         b = f"blocks.{i}."
         s.update({b + "norm1.weight": (E,), b + "norm1.bias": (E,), b + "attn.qkv.weight": (3 * E, E),
                   b + "attn.qkv.bias": (3 * E,), b + "attn.proj.weight": (E, E), b + "attn.proj.bias": (E,),
                   b + "norm2.weight": (E,), b + "norm2.bias": (E,), b + "mlp.fc1.weight": (4 * E, E),
                   b + "mlp.fc1.bias": (4 * E,), b + "mlp.fc2.weight": (E, 4 * E), b + "mlp.fc2.bias": (E,)})
+        if cfg.get("ls"):
+            s.update({b + "ls1.gamma": (E,), b + "ls2.gamma": (E,)})
     s.update({"norm.weight": (E,), "norm.bias": (E,)})
     return s
 
@@ -100,8 +118,10 @@ def fill_params(cfg, base_seed=0):
             v = detfill.uniform(shp, seed, -0.05, 0.05)
         elif "norm" in name:
             v = 1.0 + detfill.uniform(shp, seed, -0.1, 0.1)
-        elif name == "cls_token":
+        elif name in ("cls_token", "register_tokens"):
             v = detfill.uniform(shp, seed, -0.1, 0.1)
+        elif name.endswith("gamma"):    # LayerScale: trained DINOv2 gammas spread over ~[0.01, 3]
+            v = 0.6 + detfill.uniform(shp, seed, -0.5, 0.5)
         else:
             fan_in = int(np.prod(shp[1:]))
             v = detfill.uniform(shp, seed, -(3.0 / fan_in) ** 0.5, (3.0 / fan_in) ** 0.5)
@@ -140,6 +160,9 @@ def forward(P, cfg, x, autocast_bf16=False):
         if cfg["cls"]:
             x = torch.cat((P["cls_token"].expand(x.shape[0], -1, -1), x), dim=1)
         x = x + P["pos_embed"]
+        if cfg.get("reg"):   # registers go in behind the class token AFTER the position embedding was added
+            x = torch.cat((x[:, :1], P["register_tokens"].expand(x.shape[0], -1, -1), x[:, 1:]), dim=1)
+        g = (lambda k: P[k]) if cfg.get("ls") else (lambda k: 1.0)
         for i in range(cfg["depth"]):
             b = f"blocks.{i}."
             h = F.layer_norm(x, (E,), P[b + "norm1.weight"], P[b + "norm1.bias"], 1e-6)
@@ -148,10 +171,23 @@ def forward(P, cfg, x, autocast_bf16=False):
             q, k, v = qkv[0], qkv[1], qkv[2]
             a = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
             a = (a @ v).transpose(1, 2).reshape(B, N, E)
-            x = x + F.linear(a, P[b + "attn.proj.weight"], P[b + "attn.proj.bias"])
+            x = x + F.linear(a, P[b + "attn.proj.weight"], P[b + "attn.proj.bias"]) * g(b + "ls1.gamma")
             h = F.layer_norm(x, (E,), P[b + "norm2.weight"], P[b + "norm2.bias"], 1e-6)
             u = F.gelu(F.linear(h, P[b + "mlp.fc1.weight"], P[b + "mlp.fc1.bias"]))
-            x = x + F.linear(u, P[b + "mlp.fc2.weight"], P[b + "mlp.fc2.bias"])
+            x = x + F.linear(u, P[b + "mlp.fc2.weight"], P[b + "mlp.fc2.bias"]) * g(b + "ls2.gamma")
         if cfg["final_norm"]:
             x = F.layer_norm(x, (E,), P["norm.weight"], P["norm.bias"], 1e-6)
-        return x[:, 1:] if cfg["cls"] else x
+        npre = (1 if cfg["cls"] else 0) + cfg.get("reg", 0)
+        return x[:, npre:] if npre else x
+
+
+def resample_abs_pos_embed(posemb, new_size, num_prefix_tokens=1):
+    """timm.layers.pos_embed.resample_abs_pos_embed as image/utils.py:99-101,140-146 call it (bicubic, antialias=True)."""
+    pre, grid = posemb[:, :num_prefix_tokens], posemb[:, num_prefix_tokens:]
+    hw = int(round(grid.shape[1] ** 0.5))
+    if (hw, hw) == tuple(new_size):
+        return posemb
+    g = grid.reshape(1, hw, hw, -1).permute(0, 3, 1, 2).float()
+    g = F.interpolate(g, size=tuple(new_size), mode="bicubic", antialias=True)
+    g = g.permute(0, 2, 3, 1).reshape(1, -1, posemb.shape[-1]).to(posemb.dtype)
+    return torch.cat([pre, g], dim=1)

@@ -57,6 +57,8 @@ extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, c
   if (act_epi) REED_CHECK_ARG(C2, "reed_gemm: activation epilogue needs C2");
   if (epilogue == EPI_RES_BF16) REED_CHECK_ARG(R, "reed_gemm: residual epilogue needs R");
   if (epilogue == EPI_GATE_RES) REED_CHECK_ARG(R && gate, "reed_gemm: gate-residual epilogue needs R and gate");
+  if (epilogue == EPI_LS_RES)
+    REED_CHECK_ARG(R && gate && layout == LAY_NT && split_k <= 1, "reed_gemm: LayerScale-residual epilogue: NT, R and gamma (gate)");
   if (epilogue == EPI_DGELU || epilogue == EPI_DSILU) REED_CHECK_ARG(R, "reed_gemm: activation-grad epilogue needs R");
   return reed_gemm_launch(layout, epilogue, a, split_k, (hipStream_t)stream);
 }

@@ -120,11 +120,12 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const void* __restrict__
 }
 
 // ViT tower token assembly (timm VisionTransformer._pos_embed / I-JEPA forward): fp32 residual stream
-//   out[b, 0] = cls + pos[0] (when the tower has a class token); out[b, t] = float(patches[b, t - ncls]) + pos[t]
+//   out[b, t] = prefix[t] + pos[t] for the ncls prefix rows (class token; DINOv2: class token + register tokens, whose pos rows
+//   the caller zeroes); out[b, t] = float(patches[b, t - ncls]) + pos[t]
 __global__ __launch_bounds__(256) void vit_tokens_kernel(const bf16* __restrict__ patches, const float* __restrict__ cls,
                                                          const float* __restrict__ pos, float* __restrict__ out, int B,
-                                                         int T, int D) {
-  const int nch = D >> 3, ncls = cls ? 1 : 0;
+                                                         int T, int D, int ncls) {
+  const int nch = D >> 3;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * T * nch) return;
   const int ch = (int)(idx % nch);
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void vit_tokens_kernel(const bf16* __restrict_
   float v[8];
   if (t < ncls) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = cls[ch * 8 + j];
+    for (int j = 0; j < 8; ++j) v[j] = cls[(long)t * D + ch * 8 + j];
   } else {
     const bf16x8 p = *(const bf16x8*)(patches + (b * (T - ncls) + t - ncls) * D + ch * 8);
 #pragma unroll
@@ -247,12 +248,13 @@ extern "C" int reed_ln_affine_f32(const float* x, const float* w, const float* b
   return REED_OK;
 }
 
-extern "C" int reed_vit_tokens(const void* patches, const float* cls, const float* pos, float* out, int B, int T, int D,
-                               void* stream) {
-  REED_CHECK_ARG(patches && pos && out && B > 0 && T > (cls ? 1 : 0) && D % 8 == 0, "vit_tokens: bad args");
+extern "C" int reed_vit_tokens(const void* patches, const float* cls, int nprefix, const float* pos, float* out, int B, int T,
+                               int D, void* stream) {
+  REED_CHECK_ARG(patches && pos && out && B > 0 && nprefix >= 0 && (cls || nprefix == 0) && T > nprefix && D % 8 == 0,
+                 "vit_tokens: bad args");
   const long n = (long)B * T * (D / 8);
   REED_KLAUNCH(vit_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)patches, cls, pos,
-               out, B, T, D);
+               out, B, T, D, nprefix);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -17,6 +17,8 @@ enum {
   // inference-only epilogues of the frozen CLIP image encoder (bf16 residual stream):
   EPI_QGELU = 9,      // C2 bf16 = QuickGELU(pre) = bf16(pre * bf16(sigmoid(bf16(1.702 pre)))), pre = bf16(acc+bias) (C optional)
   EPI_RES_BF16 = 10,  // C bf16 = bf16(bf16(acc+bias) + R bf16)
+  EPI_LS_RES = 12,    // C f32 = R f32 + gamma f32[n] * float(bf16(acc+bias)): LayerScale + fp32 residual (DINOv2 blocks); `gate`
+                      //   points at the fp32 gamma vector; NT only
   EPI_GELU_ERF = 11   // ABI id only: exact GELU on the EPI_QGELU instantiation (GemmArgs::act_variant = 1); the ViT towers' Mlp
 };
 

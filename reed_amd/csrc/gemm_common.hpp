@@ -81,6 +81,7 @@ struct EpiOps {
                                : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU ||
                                   EPI == EPI_QGELU || EPI == EPI_RES_BF16) ? 1 + NI * 4
                                : EPI == EPI_GATE_RES ? 1 + NI * 12
+                               : EPI == EPI_LS_RES ? 3 + NI * 8
                                                      : -1;  // fp32-accumulate epilogues: pointer path, not counted
 };
 
@@ -243,6 +244,34 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
             xo[e >> 2][e & 3] = xin[h][e >> 2][e & 3] + bfround(bf2f(g[h][e]) * bf2f(y[e]));
           }
           st_bf16x8(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
+          st_f32x4(xo[0], rsC, oc + h * s8);
+          st_f32x4(xo[1], rsC, oc + h * s8 + 16);
+        }
+      }
+    } else if constexpr (EPI == EPI_LS_RES) {
+      // x_out = x_in + gamma * float(bf16(acc+bias)): LayerScale (an fp32 parameter times the bf16 linear output promotes
+      // to fp32 under autocast) and the fp32 residual add of a DINOv2 block
+      const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 4), rsR = tile_rsrc(a.R, a.ldr, 4);
+      const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(a.gate, (long)a.N * 4);
+      int oc = lane_off(a.ldc, 4), orr = lane_off(a.ldr, 4);
+      const int s8 = (int)(8 * a.ldc * 4), r8 = (int)(8 * a.ldr * 4);
+      const f32x4 gm0 = ld_f32x4(rsG, cv ? col * 4 : EPI_OOB), gm1 = ld_f32x4(rsG, cv ? col * 4 + 16 : EPI_OOB);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8, orr += 2 * r8) {
+        f32x4 xin[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          xin[h][0] = ld_f32x4(rsR, orr + h * r8);
+          xin[h][1] = ld_f32x4(rsR, orr + h * r8 + 16);
+        }
+        float v[2][8];
+        transpose(i, v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 xo[2];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            xo[e >> 2][e & 3] = xin[h][e >> 2][e & 3] + (e < 4 ? gm0[e & 3] : gm1[e & 3]) * bfround(v[h][e]);
           st_f32x4(xo[0], rsC, oc + h * s8);
           st_f32x4(xo[1], rsC, oc + h * s8 + 16);
         }

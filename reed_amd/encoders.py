@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .ops import EPI_BF16, EPI_GATE_RES, EPI_GELU_ERF, EPI_QGELU, EPI_RES_BF16, NT
+from .ops import EPI_BF16, EPI_GATE_RES, EPI_GELU_ERF, EPI_LS_RES, EPI_QGELU, EPI_RES_BF16, NT
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -175,6 +175,18 @@ VIT_TOWERS = {
     "mocov3-vit-l": dict(embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=True),
     # "mae-vit-l": mae_vit.vit_large_patch16(img_size=256): forward_features WITHOUT the final norm (mae_vit.py:33-48)
     "mae-vit-l": dict(embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=False),
+    # "dinov2-vit-{s,b,l}" / "dinov2reg-vit-{s,b,l}": torch.hub facebookresearch/dinov2 dinov2_vit{s,b,l}14[_reg] (utils.py:92-104):
+    # patch 14 at 224 x 224 (preprocess_raw_image resizes), class token, 0 / 4 register tokens, LayerScale, final norm; the
+    # learned 37 x 37 pos_embed resampled to 16 x 16 by the loader as utils.py:99-101 does
+    "dinov2-vit-s": dict(embed=384, depth=12, heads=6, patch=14, image=224, cls=True, final_norm=True, layerscale=True),
+    "dinov2-vit-b": dict(embed=768, depth=12, heads=12, patch=14, image=224, cls=True, final_norm=True, layerscale=True),
+    "dinov2-vit-l": dict(embed=1024, depth=24, heads=16, patch=14, image=224, cls=True, final_norm=True, layerscale=True),
+    "dinov2reg-vit-s": dict(embed=384, depth=12, heads=6, patch=14, image=224, cls=True, final_norm=True, layerscale=True,
+                            registers=4),
+    "dinov2reg-vit-b": dict(embed=768, depth=12, heads=12, patch=14, image=224, cls=True, final_norm=True, layerscale=True,
+                            registers=4),
+    "dinov2reg-vit-l": dict(embed=1024, depth=24, heads=16, patch=14, image=224, cls=True, final_norm=True, layerscale=True,
+                            registers=4),
 }
 
 
@@ -187,9 +199,15 @@ class VitEncoder(nn.Module):
     bf16 (train.py:351-357): bf16 GEMM operands and linear outputs, fp32 residual stream / LayerNorm, as SiT's.
     Parameter names are the reference's / timm's (patch_embed.proj.*, cls_token, pos_embed, blocks.{i}.norm1.*,
     attn.qkv.*, attn.proj.*, norm2.*, mlp.fc1.*, mlp.fc2.*, norm.*), so the checkpoints utils.py loads load here.  No
-    weights ship; no CPU path."""
+    weights ship; no CPU path.
+    DINOv2 (utils.py:92-104 loads it from torch.hub; the class is facebookresearch/dinov2's DinoVisionTransformer, not in the
+    reference tree) is the same tower plus LayerScale (blocks.{i}.ls1.gamma / ls2.gamma: x + gamma * branch(x), the fp32
+    gamma times the bf16 branch output in fp32) and, in the *_reg models, 4 register tokens inserted behind the class token
+    after the position embedding was added (register_tokens); forward_features(...)['x_norm_patchtokens'] (train.py:356) =
+    the final-normed tokens without class and register tokens, which is what forward() returns."""
 
-    def __init__(self, embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=True):
+    def __init__(self, embed=1024, depth=24, heads=16, patch=16, image=256, cls=True, final_norm=True, layerscale=False,
+                 registers=0):
         super().__init__()
         hd = embed // heads
         if embed % 128 or hd not in (64, 80) or heads * hd != embed:
@@ -197,9 +215,13 @@ class VitEncoder(nn.Module):
         self.embed_dim = self.embed = embed
         self.depth, self.heads, self.hd, self.patch, self.image = depth, heads, hd, patch, image
         self.has_cls, self.final_norm = bool(cls), bool(final_norm)
+        self.layerscale, self.registers = bool(layerscale), int(registers)
+        if self.registers and not cls:
+            raise ValueError("VitEncoder: register tokens follow a class token")
         G = image // patch
         self.npatch = G * G
-        self.tokens = self.npatch + (1 if cls else 0)
+        self.nprefix = (1 if cls else 0) + self.registers
+        self.tokens = self.npatch + self.nprefix
         if hd == 80 and self.tokens > 256:
             raise ValueError("VitEncoder: head_dim 80 is built for <= 256 tokens (I-JEPA ViT-H/14 at 224)")
         self.kp = (3 * patch * patch + 63) // 64 * 64
@@ -207,7 +229,9 @@ class VitEncoder(nn.Module):
         self.patch_embed.proj = nn.Conv2d(3, embed, patch, patch)
         if cls:
             self.cls_token = nn.Parameter(torch.zeros(1, 1, embed))
-        self.pos_embed = nn.Parameter(torch.zeros(1, self.tokens, embed), requires_grad=False)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.tokens - self.registers, embed), requires_grad=False)
+        if self.registers:
+            self.register_tokens = nn.Parameter(torch.zeros(1, self.registers, embed))
         blocks = []
         for _ in range(depth):
             b = nn.Module()
@@ -216,6 +240,9 @@ class VitEncoder(nn.Module):
             b.attn.qkv, b.attn.proj = nn.Linear(embed, 3 * embed), nn.Linear(embed, embed)
             b.mlp = nn.Module()
             b.mlp.fc1, b.mlp.fc2 = nn.Linear(embed, 4 * embed), nn.Linear(4 * embed, embed)
+            if self.layerscale:
+                b.ls1, b.ls2 = nn.Module(), nn.Module()
+                b.ls1.gamma, b.ls2.gamma = nn.Parameter(torch.ones(embed)), nn.Parameter(torch.ones(embed))
             blocks.append(b)
         self.blocks = nn.ModuleList(blocks)
         self.norm = nn.LayerNorm(embed, eps=1e-6)
@@ -223,7 +250,7 @@ class VitEncoder(nn.Module):
         self._bf = None
 
     def load_state_dict(self, sd, strict=False):
-        sd = {k: v for k, v in sd.items() if not k.startswith(("head.", "fc_norm."))}
+        sd = {k: v for k, v in sd.items() if not k.startswith(("head.", "fc_norm.")) and k != "mask_token"}
         r = super().load_state_dict(sd, strict=strict)
         self._bf = None
         return r
@@ -243,10 +270,15 @@ class VitEncoder(nn.Module):
             blocks = [dict(qkv_w=bf(b.attn.qkv.weight), qkv_b=bf(b.attn.qkv.bias), proj_w=bf(b.attn.proj.weight),
                            proj_b=bf(b.attn.proj.bias), fc1_w=bf(b.mlp.fc1.weight), fc1_b=bf(b.mlp.fc1.bias),
                            fc2_w=bf(b.mlp.fc2.weight), fc2_b=bf(b.mlp.fc2.bias),
-                           n1=(f32(b.norm1.weight), f32(b.norm1.bias)), n2=(f32(b.norm2.weight), f32(b.norm2.bias)))
+                           n1=(f32(b.norm1.weight), f32(b.norm1.bias)), n2=(f32(b.norm2.weight), f32(b.norm2.bias)),
+                           ls1=f32(b.ls1.gamma) if self.layerscale else None,
+                           ls2=f32(b.ls2.gamma) if self.layerscale else None)
                       for b in self.blocks]
-            self._bf = dict(conv=w, conv_b=bf(self.patch_embed.proj.bias), pos=f32(self.pos_embed[0]),
-                            cls=f32(self.cls_token.reshape(-1)) if self.has_cls else None,
+            pos, cls = f32(self.pos_embed[0]), f32(self.cls_token.reshape(1, E)) if self.has_cls else None
+            if self.registers:   # prefix rows = [class token, registers]; the registers take no position embedding
+                cls = torch.cat([cls, f32(self.register_tokens[0])], 0).contiguous()
+                pos = torch.cat([pos[:1], torch.zeros(self.registers, E, device=dev), pos[1:]], 0).contiguous()
+            self._bf = dict(conv=w, conv_b=bf(self.patch_embed.proj.bias), pos=pos, cls=cls,
                             norm=(f32(self.norm.weight), f32(self.norm.bias)), blocks=blocks,
                             ones=torch.ones(E, dtype=torch.bfloat16, device=dev))
         return self._bf
@@ -270,25 +302,26 @@ class VitEncoder(nn.Module):
         patches = bf(Mp, E)
         ops.gemm(NT, EPI_BF16, cols, w["conv"], Mp, E, self.kp, patches, self.kp, self.kp, E, bias=w["conv_b"])
         xa, xb = f32(M, E), f32(M, E)
-        ops.vit_tokens(patches, w["cls"], w["pos"], xa, B, T, E)
+        ops.vit_tokens(patches, w["cls"], w["pos"], xa, B, T, E, nprefix=self.nprefix)
         h, qkv, o, u = bf(M, E), bf(M, 3 * E), bf(M, E), bf(M, 4 * E)
         one = w["ones"]
+        # x + bf16(branch) in fp32: the gate-residual epilogue with a gate of ones; with LayerScale x + gamma * bf16(branch)
+        res = (lambda g: dict(gate=g)) if self.layerscale else (lambda g: dict(gate=one, ldgate=0, rows_per_gate=T))
+        epi_res = EPI_LS_RES if self.layerscale else EPI_GATE_RES
         for blk in w["blocks"]:
             ops.ln_affine_f32(xa, blk["n1"][0], blk["n1"][1], h, False, M, E)
             ops.gemm(NT, EPI_BF16, h, blk["qkv_w"], M, 3 * E, E, qkv, E, E, 3 * E, bias=blk["qkv_b"])
             ops.attention_fwd(qkv, o, None, B, T, H, self.hd)
-            # x + bf16(proj(o)) in fp32: the gate-residual epilogue with a gate of ones
-            ops.gemm(NT, EPI_GATE_RES, o, blk["proj_w"], M, E, E, xb, E, E, E, R=xa, ldr=E, bias=blk["proj_b"], gate=one,
-                     ldgate=0, rows_per_gate=T)
+            ops.gemm(NT, epi_res, o, blk["proj_w"], M, E, E, xb, E, E, E, R=xa, ldr=E, bias=blk["proj_b"], **res(blk["ls1"]))
             ops.ln_affine_f32(xb, blk["n2"][0], blk["n2"][1], h, False, M, E)
             ops.gemm(NT, EPI_GELU_ERF, h, blk["fc1_w"], M, 4 * E, E, None, E, E, 4 * E, C2=u, ldc2=4 * E, bias=blk["fc1_b"])
-            ops.gemm(NT, EPI_GATE_RES, u, blk["fc2_w"], M, E, 4 * E, xa, 4 * E, 4 * E, E, R=xb, ldr=E, bias=blk["fc2_b"],
-                     gate=one, ldgate=0, rows_per_gate=T)
+            ops.gemm(NT, epi_res, u, blk["fc2_w"], M, E, 4 * E, xa, 4 * E, 4 * E, E, R=xb, ldr=E, bias=blk["fc2_b"],
+                     **res(blk["ls2"]))
         if self.final_norm:
             ops.ln_affine_f32(xa, w["norm"][0], w["norm"][1], xb, True, M, E)
             xa = xb
         out = xa.view(B, T, E)
-        return out[:, 1:] if self.has_cls else out
+        return out[:, self.nprefix:] if self.nprefix else out
 
     def forward_features(self, x):
         return self.forward(x)
@@ -299,11 +332,27 @@ class VitEncoder(nn.Module):
         return self.forward(preprocess_raw_image(raw_u8, self.enc_type))
 
 
+def resample_abs_pos_embed(posemb, new_size, num_prefix_tokens=1):
+    """timm.layers.pos_embed.resample_abs_pos_embed as image/utils.py:99-101,140-146 call it: the grid part of a learned
+    [1, prefix + g*g, D] table to new_size by bicubic interpolation with antialiasing, prefix rows kept.  Checkpoint
+    conversion at load time (CPU torch), not part of the per-step path."""
+    pre, grid = posemb[:, :num_prefix_tokens], posemb[:, num_prefix_tokens:]
+    hw = int(round(grid.shape[1] ** 0.5))
+    if (hw, hw) == tuple(new_size) or hw * hw != grid.shape[1]:
+        return posemb
+    g = grid.reshape(1, hw, hw, -1).permute(0, 3, 1, 2).float()
+    g = torch.nn.functional.interpolate(g, size=tuple(new_size), mode="bicubic", antialias=True)
+    g = g.permute(0, 2, 3, 1).reshape(1, -1, posemb.shape[-1]).to(posemb.dtype)
+    return torch.cat([pre, g], dim=1)
+
+
 def load_vit_encoder(enc_type, ckpt_path, device):
     """`jepa-vit-h`, `mocov3-vit-{b,l}`, `mae-vit-l` of image/utils.py:73-82,133-160 from the checkpoint files the reference
     names (ckpts/ijepa_vith.pth: state_dict['encoder'] with a 'module.' prefix; ckpts/mocov3_vit{b,l}.pth: ['state_dict']
     with 'module.base_encoder.' (fix_mocov3_state_dict, utils.py:27-52); ckpts/mae_vitl.pth: ['model']) or a plain state
-    dict.  A learned pos_embed of another grid must be resampled by the caller (utils.py:140-146 uses timm's helper)."""
+    dict; `dinov2[reg]-vit-{s,b,l}` of utils.py:92-104 from the torch.hub checkpoint file (dinov2_vit{s,b,l}14[_reg4]_pretrain.pth,
+    a plain state dict).  A learned pos_embed of another grid (DINOv2: 37 x 37, MAE: 14 x 14) is resampled to the tower's
+    as utils.py:99-101,140-146 do with timm's resample_abs_pos_embed (bicubic, antialias; a load-time torch call on the CPU)."""
     cfg = VIT_TOWERS[enc_type]
     enc = VitEncoder(**cfg)
     sd = torch.load(ckpt_path, map_location="cpu")
@@ -319,8 +368,11 @@ def load_vit_encoder(enc_type, ckpt_path, device):
                 break
         out[k] = v.float() if torch.is_floating_point(v) else v
     if "pos_embed" in out and out["pos_embed"].shape != enc.pos_embed.shape:
-        raise RuntimeError(f"{ckpt_path}: pos_embed {tuple(out['pos_embed'].shape)} != {tuple(enc.pos_embed.shape)}; resample it "
-                           "to the tower's grid first (image/utils.py:140-146)")
+        G = enc.image // enc.patch
+        out["pos_embed"] = resample_abs_pos_embed(out["pos_embed"], (G, G), 1 if enc.has_cls else 0)
+        if out["pos_embed"].shape != enc.pos_embed.shape:
+            raise RuntimeError(f"{ckpt_path}: pos_embed {tuple(out['pos_embed'].shape)} does not resample to "
+                               f"{tuple(enc.pos_embed.shape)}")
     missing, unexpected = enc.load_state_dict(out, strict=False)
     missing = [k for k in missing if not (k.startswith("norm.") and not enc.final_norm)]
     if missing:

@@ -15,7 +15,7 @@ from . import _lib
 NT, NN, TN = 0, 1, 2
 TN_TALL, TN_WIDE = 3, 4   # TN on the 256x128 / 128x256 tile of csrc/gemm_tn.hip (weight gradients)
 (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32, EPI_QGELU,
- EPI_RES_BF16, EPI_GELU_ERF) = range(12)
+ EPI_RES_BF16, EPI_GELU_ERF, EPI_LS_RES) = range(13)
 
 
 def _p(t):
@@ -387,8 +387,11 @@ def ln_affine_f32(x, w, b, out, out_is_f32, M, D, ldo=None, eps=1e-6):
     _call("reed_ln_affine_f32", _p(x), _p(w), _p(b), _p(out), int(out_is_f32), M, D, D if ldo is None else ldo, eps, _stream())
 
 
-def vit_tokens(patches, cls, pos, out, B, T, D):
-    _call("reed_vit_tokens", _p(patches), _p(cls), _p(pos), _p(out), B, T, D, _stream())
+def vit_tokens(patches, cls, pos, out, B, T, D, nprefix=None):
+    """cls: f32 [nprefix, D] prefix rows (class token [+ register tokens]) or None."""
+    if nprefix is None:
+        nprefix = 0 if cls is None else 1
+    _call("reed_vit_tokens", _p(patches), _p(cls), int(nprefix), _p(pos), _p(out), B, T, D, _stream())
 
 
 def preprocess_image(raw_u8, out, B, R, S, mean, std, order):

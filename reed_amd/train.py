@@ -204,7 +204,7 @@ def main(args):
             f"Number of alignment loss coefficients {len(args.repa_coeff)} must match the total number of encoders {len(enc_names)}."
     n_img_enc = z_types.count("i")
     encoders = []
-    if args.encoder_ckpts:   # on-the-fly frozen encoders, as train.py:182-186,351-357 (CLIP, I-JEPA, MoCo-v3, MAE towers)
+    if args.encoder_ckpts:   # on-the-fly frozen encoders, as train.py:182-186,351-357 (DINOv2, CLIP, I-JEPA, MoCo-v3, MAE towers)
         from .encoders import VIT_TOWERS, load_clip_encoder, load_vit_encoder
         if args.features_dirs or args.synthetic:
             raise ValueError("--encoder-ckpts excludes --features-dirs / --synthetic")
@@ -220,8 +220,8 @@ def main(args):
                 encoders.append(load_vit_encoder(key, path, device))
             else:
                 raise NotImplementedError(f"on-device frozen encoder '{item}': built are clip-vit-*, {sorted(VIT_TOWERS)} (the "
-                                          "towers image/utils.py:55-164 defines or configures; DINOv2 comes from torch.hub: use "
-                                          "--features-dirs for it)")
+                                          "towers image/utils.py:55-164 defines, configures or fetches; for others use "
+                                          "--features-dirs)")
     if n_img_enc and not args.synthetic and not args.features_dirs and not encoders and not args.packed_dir:
         raise NotImplementedError(
             "this build ships no encoder weights (no network; SURVEY.md §8f N2). Pass --encoder-ckpts <state dict per "

@@ -342,7 +342,7 @@ def test_train_with_on_device_clip_encoder(dev, tmp_path, monkeypatch):
 
 
 def test_train_with_on_device_jepa_and_mae_towers(dev, tmp_path, monkeypatch):
-    """train.py counterpart with TWO frozen image encoders running on the GPU every step (--enc-type jepa-vit-h,mae-vit-l
+    """train.py counterpart with THREE frozen image encoders running on the GPU every step (--enc-type jepa-vit-h,mae-vit-l,dinov2reg-vit-b
     --encoder-ckpts a b; image/train.py:182-186,351-357 with the jepa / mae branches of preprocess_raw_image and
     load_encoders): 1-block towers of the real widths stand in; checkpoints in the reference's file layouts
     ({'encoder': {'module.*'}} for I-JEPA, utils.py:153-158; {'model': ...} for MAE, utils.py:137-145)."""
@@ -369,9 +369,18 @@ def test_train_with_on_device_jepa_and_mae_towers(dev, tmp_path, monkeypatch):
         path = str(tmp_path / (key + ".pth"))
         torch.save(wrap(P), path)
         cks.append(path)
+    # DINOv2 with registers (utils.py:92-104): the torch.hub checkpoint layout — a plain state dict with the 37 x 37 pos_embed
+    # (resampled to 16 x 16 at load), mask_token, register_tokens, ls{1,2}.gamma
+    kw = dict(encoders.VIT_TOWERS["dinov2reg-vit-b"], depth=1)
+    monkeypatch.setitem(encoders.VIT_TOWERS, "dinov2reg-vit-b", kw)
+    P = ot.fill_params(ot.make_config(768, 1, 12, 14, 224, True, True, "learned", ls=True, reg=4), base_seed=2)
+    P["pos_embed"] = torch.randn(1, 1 + 37 * 37, 768, generator=torch.Generator().manual_seed(1)) * 0.02
+    P["mask_token"] = torch.zeros(1, 768)
+    cks.append(str(tmp_path / "dinov2_vitb14_reg4_pretrain.pth"))
+    torch.save(P, cks[-1])
     a = train.parse_args(["--exp-name", "towers", "--model", "SiT-S/2", "--output-dir", str(tmp_path / "exps"),
-                          "--data-dir", str(data), "--enc-type", "jepa-vit-h,mae-vit-l", "--encoder-ckpts", cks[0], cks[1],
-                          "--repa-coeff", "1.0", "0.5", "--mixed-precision", "bf16", "--batch-size", "4", "--num-workers", "0",
+                          "--data-dir", str(data), "--enc-type", "jepa-vit-h,mae-vit-l,dinov2reg-vit-b", "--encoder-ckpts", *cks,
+                          "--repa-coeff", "1.0", "0.5", "0.5", "--mixed-precision", "bf16", "--batch-size", "4", "--num-workers", "0",
                           "--diffusion-warm-up-steps", "0", "--report-to", "none", "--max-train-steps", "2",
                           "--num-classes", "5", "--checkpointing-steps", "100"])
     d = train.main(a)

@@ -145,6 +145,55 @@ def test_vit_tower_vs_reference(dev, tag):
     assert e32 <= 2.0 * eref + 2e-3 and c32 > 0.9998
 
 
+@pytest.mark.parametrize("tag,E,H,depth,image,reg,B", [("plain", 128, 2, 2, 56, 0, 3), ("reg4", 256, 4, 3, 28, 4, 2)])
+def test_dinov2_tower_vs_hf_port(dev, tag, E, H, depth, image, reg, B):
+    """DINOv2 (image/utils.py:92-104; torch.hub class, not in the reference tree) on the HIP tower — LayerScale + fp32 residual
+    as the GEMM epilogue 12, register tokens through reed_vit_tokens' prefix rows — against transformers' independent port
+    of the model (tests/golden/dinov2.npz) under bf16 autocast and in fp32, hub parameter names."""
+    from oracle import detfill
+    from oracle import vit_towers as ot
+    from reed_amd.encoders import VitEncoder
+    from tests.test_oracle_golden import load
+    g = load("dinov2")
+    cfg = ot.make_config(E, depth, H, 14, image, True, True, "learned", ls=True, reg=reg)
+    P = ot.fill_params(cfg, base_seed=21)
+    P["mask_token"] = torch.zeros(1, E)          # present in the hub checkpoints, unused at inference
+    enc = VitEncoder(embed=E, depth=depth, heads=H, patch=14, image=image, cls=True, final_norm=True, layerscale=True,
+                     registers=reg)
+    missing, unexpected = enc.load_state_dict(P)
+    assert not missing and not unexpected
+    enc = enc.to(dev).eval()
+    x = detfill.normal((B, 3, image, image), 56)
+    out = enc(x.to(dev)).float().cpu()
+    ref32, ref16 = torch.from_numpy(g[tag + ".fp32"]), torch.from_numpy(g[tag + ".bf16"])
+    assert out.shape == ref32.shape
+    sc = ref32.abs().max().item()
+    e32, eref = (out - ref32).abs().max().item() / sc, (ref16 - ref32).abs().max().item() / sc
+    c32 = torch.nn.functional.cosine_similarity(out.flatten(), ref32.flatten(), dim=0).item()
+    print(f"dinov2 {tag}: max|HIP - fp32| {e32:.2e} (the port's own bf16-vs-fp32 {eref:.2e}) of the output range; cosine {c32:.6f}")
+    assert e32 <= 2.0 * eref + 2e-3 and c32 > 0.9998
+
+
+def test_layerscale_residual_epilogue(dev):
+    """reed_gemm epilogue 12: C f32 = R f32 + gamma f32[n] * float(bf16(acc + bias)) on the 128^2 and 256^2 kernels."""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in ((257 * 3, 384, 384), (4112, 1024, 4096)):
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+        b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+        gamma = (torch.rand(N, generator=g) * 2).to(dev)
+        r = torch.randn(M, N, generator=g).to(dev)
+        ref = r + gamma * (x.float() @ w.float().t() + b.float()).to(torch.bfloat16).float()
+        for tile in (128, 256):
+            ops.gemm_force_tile(tile)
+            out = torch.full((M, N), float("nan"), device=dev)
+            ops.gemm(ops.NT, ops.EPI_LS_RES, x, w, M, N, K, out, K, K, N, R=r, ldr=N, bias=b, gate=gamma)
+            ops.gemm_force_tile(0)
+            torch.testing.assert_close(out, ref, atol=2e-2, rtol=1e-2)       # one bf16 rounding of the branch x gamma <= 2
+            assert (out - ref).abs().mean().item() < 2e-3
+
+
 def test_preprocess_raw_image_branches(dev):
     """preprocess_raw_image (image/train.py:53-74) as one HIP pass: every branch against the torch restatement
     (F.interpolate bicubic + Normalize) on random uint8 images and against the reference-generated ramp samples."""

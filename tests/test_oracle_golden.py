@@ -319,6 +319,28 @@ def test_vit_towers():
     assert ot.preprocess(raw, "mocov3").shape == (2, 3, 256, 256) and ot.preprocess(raw, "dinov2").shape == (2, 3, 224, 224)
 
 
+def test_dinov2_tower():
+    """oracle/vit_towers.py's DINOv2 restatement (class token, learned pos-embed, 0 / 4 register tokens behind the class
+    token, LayerScale, final norm, patch tokens out) against transformers' Dinov2Model / Dinov2WithRegistersModel
+    (tests/golden/dinov2.npz, tools/gen_golden.py:g_dinov2), and the pos-embed resampling of image/utils.py:99-101."""
+    from oracle import vit_towers as ot
+    g = load("dinov2")
+    for tag, E, H, depth, image, reg, B in (("plain", 128, 2, 2, 56, 0, 3), ("reg4", 256, 4, 3, 28, 4, 2)):
+        cfg = ot.make_config(E, depth, H, 14, image, True, True, "learned", ls=True, reg=reg)
+        P = ot.fill_params(cfg, base_seed=21)
+        x = detfill.normal((B, 3, image, image), 56)
+        with torch.no_grad():
+            o32 = ot.forward(P, cfg, x).numpy()
+            o16 = ot.forward(P, cfg, x, autocast_bf16=True).float().numpy()
+        assert o32.shape == g[tag + ".fp32"].shape == (B, (image // 14) ** 2, E)
+        np.testing.assert_allclose(o32, g[tag + ".fp32"], rtol=2e-5, atol=2e-5)
+        sc = np.abs(g[tag + ".fp32"]).max()
+        assert np.abs(o16 - g[tag + ".bf16"]).max() <= 2e-2 * sc, tag
+    pe = detfill.normal((1, 1 + 37 * 37, 64), 57)
+    np.testing.assert_allclose(ot.resample_abs_pos_embed(pe, (16, 16)).numpy(), g["pos_resample"], rtol=1e-6, atol=1e-6)
+    assert ot.resample_abs_pos_embed(pe, (37, 37)) is pe
+
+
 def test_fp16_autocast_and_grad_scaler():
     """--mixed-precision fp16 (fp16.npz: the reference under autocast(float16) + GradScaler): the oracle's tiny-case
     losses, two steps of the S/2 trajectory, and the skipped-step path (scale halves, weights stay)."""

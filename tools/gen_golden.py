@@ -639,6 +639,54 @@ def g_towers(ref_sit, ref_loss, ref_samplers):
     save("towers", **out)
 
 
+def g_dinov2(ref_sit, ref_loss, ref_samplers):
+    """DINOv2 (image/utils.py:92-104 loads it from torch.hub, which cannot be reached here; the class is not in the
+    reference tree).  The oracle restates the published model; these vectors come from transformers' Dinov2Model /
+    Dinov2WithRegistersModel — an independent port of the hub model installed in this image — loaded with the oracle's
+    parameters under the hub's names (qkv split into query / key / value).  fp32 and bf16-autocast patch tokens
+    (= forward_features(...)['x_norm_patchtokens'], train.py:356), without and with 4 register tokens; plus timm's
+    resample_abs_pos_embed geometry (utils.py:99-101: 37 x 37 -> 16 x 16, bicubic, antialias) on a fixed table, restated
+    from timm.layers.pos_embed (timm is not installed)."""
+    from transformers import Dinov2Config, Dinov2Model, Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    from oracle import vit_towers as ot
+    out = {}
+    for tag, E, H, depth, image, reg, B in (("plain", 128, 2, 2, 56, 0, 3), ("reg4", 256, 4, 3, 28, 4, 2)):
+        cfg = ot.make_config(E, depth, H, 14, image, True, True, "learned", ls=True, reg=reg)
+        P = ot.fill_params(cfg, base_seed=21)
+        kw = dict(hidden_size=E, num_hidden_layers=depth, num_attention_heads=H, mlp_ratio=4, image_size=image, patch_size=14,
+                  layer_norm_eps=1e-6, qkv_bias=True, hidden_act="gelu", use_swiglu_ffn=False)
+        m = (Dinov2WithRegistersModel(Dinov2WithRegistersConfig(num_register_tokens=reg, **kw)) if reg
+             else Dinov2Model(Dinov2Config(**kw)))
+        sd = {"embeddings.cls_token": P["cls_token"], "embeddings.mask_token": torch.zeros(1, E),
+              "embeddings.position_embeddings": P["pos_embed"],
+              "embeddings.patch_embeddings.projection.weight": P["patch_embed.proj.weight"],
+              "embeddings.patch_embeddings.projection.bias": P["patch_embed.proj.bias"],
+              "layernorm.weight": P["norm.weight"], "layernorm.bias": P["norm.bias"]}
+        if reg:
+            sd["embeddings.register_tokens"] = P["register_tokens"]
+        for i in range(depth):
+            b, h = f"blocks.{i}.", f"encoder.layer.{i}."
+            for j, nm in enumerate(("query", "key", "value")):
+                sd[h + f"attention.attention.{nm}.weight"] = P[b + "attn.qkv.weight"][j * E:(j + 1) * E]
+                sd[h + f"attention.attention.{nm}.bias"] = P[b + "attn.qkv.bias"][j * E:(j + 1) * E]
+            for src, dst in (("norm1", "norm1"), ("norm2", "norm2"), ("attn.proj", "attention.output.dense"), ("mlp.fc1", "mlp.fc1"),
+                             ("mlp.fc2", "mlp.fc2")):
+                sd[h + dst + ".weight"], sd[h + dst + ".bias"] = P[b + src + ".weight"], P[b + src + ".bias"]
+            sd[h + "layer_scale1.lambda1"], sd[h + "layer_scale2.lambda1"] = P[b + "ls1.gamma"], P[b + "ls2.gamma"]
+        r = m.load_state_dict(sd, strict=True)
+        m.eval()
+        x = detfill.normal((B, 3, image, image), 56)
+        with torch.no_grad():
+            out[tag + ".fp32"] = m(pixel_values=x).last_hidden_state[:, 1 + reg:].numpy()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out[tag + ".bf16"] = m(pixel_values=x).last_hidden_state[:, 1 + reg:].float().numpy()
+    pe = detfill.normal((1, 1 + 37 * 37, 64), 57)
+    g = pe[:, 1:].reshape(1, 37, 37, 64).permute(0, 3, 1, 2)
+    g = torch.nn.functional.interpolate(g, size=(16, 16), mode="bicubic", antialias=True).permute(0, 2, 3, 1).reshape(1, 256, 64)
+    out["pos_resample"] = torch.cat([pe[:, :1], g], 1).numpy()
+    save("dinov2", **out)
+
+
 def make_tiny_dataset(root, n=6, text_dim=16):
     """Deterministic tiny dataset in the reference's on-disk format (image/dataset.py:18-85; written by
     preprocessing/dataset_tools.py): images/XXXXX/imgNNNNNNNN.png, vae-sd/XXXXX/img-mean-std-NNNNNNNN.npy,
@@ -718,7 +766,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers, "dinov2": g_dinov2}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
