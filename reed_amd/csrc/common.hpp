@@ -12,10 +12,12 @@
 typedef _Float16 bf16;
 #define REED_HALF_KIND 1
 #define REED_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define REED_MFMA_MNEMONIC "v_mfma_f32_16x16x32_f16"
 #else
 typedef __bf16 bf16;
 #define REED_HALF_KIND 0
 #define REED_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define REED_MFMA_MNEMONIC "v_mfma_f32_16x16x32_bf16"
 #define REED_DS_READ_TR16_B64(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p)
 #endif
 typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
@@ -28,6 +30,11 @@ typedef __fp16 reed_tr16_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+// acc += a * b with the accumulator held IN PLACE in accumulation registers (AGPRs).  With the builtin the compiler selects
+// the untied early-clobber form (vdst != src C), which needs a spare register quad per instruction: a wave that keeps all
+// 256 AGPRs live as accumulators (csrc/gemm256w.hip) then gets part of them shuffled through VGPRs around every MFMA.
+// The asm is opaque to the hazard recognizer: no two consecutive uses of one accumulator, and s_nop before reading it back.
+#define REED_MFMA_ACC(acc, a, b) asm volatile(REED_MFMA_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 
 #define REED_OK 0
 #define REED_ERR_ARG 1001       // bad argument (shape/alignment/unsupported dim)

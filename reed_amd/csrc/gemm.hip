@@ -18,6 +18,8 @@
 // v_mfma_f32_16x16x32_bf16.  The MFMA is issued "swapped" (Q fragment as A operand, P fragment
 // as B operand) so each lane ends up holding 4 consecutive n for one m: 8-B bf16 / 16-B fp32
 // epilogue accesses.  LDS is double buffered (64 KiB), one barrier per K step.
+#include <stdlib.h>
+
 #include "gemm_common.hpp"
 
 int reed_gemm256_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);
@@ -26,6 +28,8 @@ bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits);
 bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits);              // gemm144.hip
 bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits);
 int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
+bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm256w.hip: 4 waves x 128x128
+int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 
 namespace {
 using namespace gemm_detail;
@@ -252,11 +256,18 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
+  if (g_force_tile == 257 && reed_gemm256w_eligible(layout, epi, a, splits)) return reed_gemm256w_launch(layout, epi, a, stream);
   if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits))))
     return reed_gemm144_launch(layout, epi, a, stream);
   if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, epi, a, splits)) &&
-      !(layout == LAY_TN && a.dbias))
+      !(layout == LAY_TN && a.dbias)) {
+    // the 256^2 tile: four waves of 128x128 (gemm256w.hip) where that kernel is built, else eight of 128x64 (gemm256.hip);
+    // REED_GEMM_W4=0 or force_tile 256 keep the 8-wave kernel (A/B timing)
+    static const bool w4 = !(getenv("REED_GEMM_W4") && atoi(getenv("REED_GEMM_W4")) == 0);
+    if (w4 && g_force_tile != 256 && reed_gemm256w_eligible(layout, epi, a, splits))
+      return reed_gemm256w_launch(layout, epi, a, stream);
     return reed_gemm256_launch(layout, epi, a, splits, stream);
+  }
   switch (layout) {
     case LAY_NT: return dispatch_epi<LAY_NT>(epi, a, splits, stream);
     case LAY_NN: return dispatch_epi<LAY_NN>(epi, a, splits, stream);

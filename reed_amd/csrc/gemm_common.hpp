@@ -110,7 +110,10 @@ __device__ __forceinline__ void tile_epilogue_ptr(const GemmArgs& a, const f32x4
                                                   int lane, int z);
 
 // stage: this wave's EPI_STAGE_BYTES of LDS (no other wave touches it; the caller made sure the K loop is done with it)
-template <int EPI, int NI>
+// PF > 0: the operand loads (residual stream / pre-activation) of PF row groups are kept in flight ahead of the one being
+// written — for the 4-wave kernel (gemm256w.hip), whose CU has half as many epilogue streams to hide a load round trip
+// behind (on the 8-wave kernels it measured a wash: DESIGN.md).  PF = 0: loads of group i right before its transpose.
+template <int EPI, int NI, int PF = 0>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&acc)[NI][4], int m0, int mw, int nbase,
                                               int lane, int z, char* stage) {
   if constexpr (EpiOps<EPI, NI>::value < 0) {
@@ -213,27 +216,33 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
       int grow = (m0 + mw) / a.rows_per_gate;
       int grem = (m0 + mw) - grow * a.rows_per_gate;
       const int og = cv ? col * 2 : EPI_OOB;
-#pragma unroll
-      for (int i = 0; i < NI; ++i, oc += 2 * s8, orr += 2 * r8, oy += 2 * y8) {
+      bf16x8 g[NI][2];
+      f32x4 xin[NI][2][2];
+      auto fetch = [&](int i) {   // operand loads of row group i (they do not depend on the accumulators)
         int gso = 0;
         if (gfast) {
           gso = grow * (int)a.ldgate * 2;
           grem += 16;
           if (grem >= a.rows_per_gate) { grem -= a.rows_per_gate; ++grow; }
         }
-        // operand loads first (they do not depend on the accumulators), then the LDS round trip
-        bf16x8 g[2];
-        f32x4 xin[2][2];
+        const int ro = orr + i * 2 * r8;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           int gvo = og;
           if (!gfast) gvo = cv ? (int)(((long)((m0 + rt + 16 * i + 8 * h) / a.rows_per_gate) * a.ldgate + col) * 2) : EPI_OOB;
-          g[h] = ld_bf16x8(rsG, gvo, gso);
-          xin[h][0] = ld_f32x4(rsR, orr + h * r8);
-          xin[h][1] = ld_f32x4(rsR, orr + h * r8 + 16);
+          g[i][h] = ld_bf16x8(rsG, gvo, gso);
+          xin[i][h][0] = ld_f32x4(rsR, ro + h * r8);
+          xin[i][h][1] = ld_f32x4(rsR, ro + h * r8 + 16);
         }
+      };
+#pragma unroll
+      for (int i = 0; i < PF && i < NI; ++i) fetch(i);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8, oy += 2 * y8) {
+        if constexpr (PF == 0) fetch(i);
         float v[2][8];
         transpose(i, v);
+        if (PF > 0 && i + PF < NI) fetch(i + PF);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bf16x8 y;
@@ -241,7 +250,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             y[e] = f2bf(v[h][e]);
-            xo[e >> 2][e & 3] = xin[h][e >> 2][e & 3] + bfround(bf2f(g[h][e]) * bf2f(y[e]));
+            xo[e >> 2][e & 3] = xin[i][h][e >> 2][e & 3] + bfround(bf2f(g[i][h][e]) * bf2f(y[e]));
           }
           st_bf16x8(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
           st_f32x4(xo[0], rsC, oc + h * s8);
@@ -280,20 +289,27 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsR = tile_rsrc(a.R, a.ldr, 2);
       int oc = lane_off(a.ldc, 2), orr = lane_off(a.ldr, 2);
       const int s8 = (int)(8 * a.ldc * 2), r8 = (int)(8 * a.ldr * 2);
+      bf16x8 pre[NI][2];
+      auto fetch = [&](int i) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i, oc += 2 * s8, orr += 2 * r8) {
-        bf16x8 pre[2];
+        for (int h = 0; h < 2; ++h) pre[i][h] = ld_bf16x8(rsR, orr + i * 2 * r8 + h * r8);
+      };
+      constexpr int PFD = 2 * PF;   // 8 registers per row group: twice the depth of the fp32 residual's
 #pragma unroll
-        for (int h = 0; h < 2; ++h) pre[h] = ld_bf16x8(rsR, orr + h * r8);
+      for (int i = 0; i < PFD && i < NI; ++i) fetch(i);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8) {
+        if constexpr (PF == 0) fetch(i);
         float v[2][8];
         transpose(i, v);
+        if (PF > 0 && i + PFD < NI) fetch(i + PFD);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float du = bfround(v[h][e]);
-            float x = bf2f(pre[h][e]);
+            float x = bf2f(pre[i][h][e]);
             if constexpr (EPI == EPI_RES_BF16) o[e] = f2bf(du + x);   // bf16 residual stream (frozen encoder)
             else o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
           }

@@ -6,10 +6,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 128, 256, 144], autouse=True)
+@pytest.fixture(params=[0, 128, 256, 144, 257], autouse=True)
 def force_tile(request):
-    """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined,
-    256x144 ring — the last only takes NT / NN shapes whose N is a multiple of 144, others fall to the heuristic)."""
+    """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined with eight
+    waves, 256x144 ring — only NT / NN shapes whose N is a multiple of 144 —, 257 = the 256^2 tile with four 128x128 waves —
+    NT / NN with K >= 128 and the epilogues it builds; what a kernel does not take falls to the heuristic)."""
     from reed_amd import ops
     ops.gemm_force_tile(request.param)
     yield request.param
