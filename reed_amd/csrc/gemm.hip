@@ -224,6 +224,7 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 / 144 = force where the shape allows (tests, A/B timing)
 extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
+int reed_gemm_forced_tile() { return g_force_tile; }
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
   REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);

@@ -15,6 +15,7 @@
 //            K-tile t just left) spread between them, one per 4 MFMAs
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "gemm_common.hpp"
 
@@ -43,111 +44,161 @@ __device__ __forceinline__ bf16x8 wtr2(const char* a0, const char* a1) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// RAGGED = a last column tile of which only the first 128 columns exist (N = 1152 = 4.5 x 256: every D-wide output of
-// SiT-XL/2).  The four waves then take 64 rows x 128 columns each (row quarter `wave`, B half-tile 0): 4 x 8 MFMA tiles, half
-// the MFMAs per phase, no DMA for the absent B half-tile — instead of two of the four waves multiplying zeros.
-template <int LAY, int EPI, bool RAGGED>
+// MODE bit 0 = ragged N: a last column tile of which only the first 128 columns exist (N = 1152 = 4.5 x 256: every D-wide
+// output of SiT-XL/2); bit 1 = ragged M: a last row tile with 128 rows (TN: weight gradients of the 1152- / 3456-row weights).
+// The four waves are re-dealt over what exists instead of multiplying zeros:
+//   MODE 0  256 x 256: wave (wr, wc) = A half-tile wr (8 row tiles) x B half-tile wc (8 column tiles)     64 MFMAs / k-step
+//   MODE 1  256 x 128: A half-tile wave>>1, 64-row quarter wave&1 (4 tiles) x B half-tile 0 (8 tiles)      32
+//   MODE 2  128 x 256: A half-tile 0 (8 tiles) x B half-tile wave>>1, 64-column quarter wave&1 (4 tiles)   32
+//   MODE 3  128 x 128: A half-tile 0 quarter wave>>1 (4) x B half-tile 0 quarter wave&1 (4)                16
+// and the half-tiles that do not exist are not staged.
+template <int LAY, int EPI, int MODE>
 __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, const int tm, const int tn) {
-  constexpr int NI = RAGGED ? 4 : 8;          // 16-row tiles per wave
-  constexpr int NCH = 2 * NI;                 // chunks of 4 MFMAs per phase
+  constexpr bool RN = (MODE & 1) != 0, RM = (MODE & 2) != 0;
+  constexpr int NA = RN ? 4 : 8;              // 16-row tiles per wave
+  constexpr int NB = RM ? 4 : 8;              // 16-column tiles per wave
+  constexpr int NCH = NA * NB / 4;            // chunks of 4 MFMAs per phase
+  constexpr int NF = NA + NB;                 // fragment reads per k-step
+  constexpr int ND = 4 * ((RM ? 1 : 2) + (RN ? 1 : 2));   // DMA instructions per K-tile per wave
+  constexpr bool A_TR = LAY == LAY_TN, B_TR = LAY != LAY_NT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = RAGGED ? 0 : (wave & 1);
+  const int aHalf = MODE == 0 ? (wave >> 1) : MODE == 1 ? (wave >> 1) : 0;
+  const int aQuart = MODE == 1 ? (wave & 1) : MODE == 3 ? (wave >> 1) : 0;
+  const int bHalf = MODE == 0 ? (wave & 1) : MODE == 2 ? (wave >> 1) : 0;
+  const int bQuart = (MODE == 2 || MODE == 3) ? (wave & 1) : 0;
+  const int mrow = aHalf * 128 + aQuart * 64, ncol = bHalf * 128 + bQuart * 64;
   const int m0 = tm * WBM, n0 = tn * WBN;
   const int nt = (a.K + WBK - 1) / WBK;
 
   __amdgpu_buffer_rsrc_t rsP, rsQ;
-  rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
-  if constexpr (LAY == LAY_NT) rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
-  else rsQ = make_rsrc(a.Q + n0, ((long)a.K * a.ldq - n0) * 2);
+  if constexpr (A_TR) rsP = make_rsrc(a.P + m0, ((long)a.K * a.ldp - m0) * 2);
+  else rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
+  if constexpr (B_TR) rsQ = make_rsrc(a.Q + n0, ((long)a.K * a.ldq - n0) * 2);
+  else rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
 
-  const int vA0 = wvoff_row(tid, a.ldp);
-  const int vB0 = (LAY == LAY_NT) ? wvoff_row(tid, a.ldq) : wvoff_tr(tid, a.ldq);
-  const int rsA = (int)(32 * a.ldp * 2);                                        // per staging round
-  const int rsB = (LAY == LAY_NT) ? (int)(32 * a.ldq * 2) : (int)(16 * a.ldq * 2);
-  const int kstepA = WBK * 2;
-  const int kstepB = (LAY == LAY_NT) ? WBK * 2 : (int)(WBK * a.ldq * 2);
-  const int halfA = (int)(128 * a.ldp * 2);
-  const int halfB = (LAY == LAY_NT) ? (int)(128 * a.ldq * 2) : 128 * 2;
-  // one of the 16 DMA instructions of a K-tile: d = 4 * half-tile (A0 A1 B0 B1) + round
-  auto dma = [&](int t, int cur, int d) {
-    const int h4 = d >> 2, i = d & 3;
-    if (h4 < 2) {
-      char* ht = smem + wslotA(h4, cur);
+  const int vA0 = A_TR ? wvoff_tr(tid, a.ldp) : wvoff_row(tid, a.ldp);
+  const int vB0 = B_TR ? wvoff_tr(tid, a.ldq) : wvoff_row(tid, a.ldq);
+  const int rsA = A_TR ? (int)(16 * a.ldp * 2) : (int)(32 * a.ldp * 2);        // per staging round
+  const int rsB = B_TR ? (int)(16 * a.ldq * 2) : (int)(32 * a.ldq * 2);
+  const int kstepA = A_TR ? (int)(WBK * a.ldp * 2) : WBK * 2;
+  const int kstepB = B_TR ? (int)(WBK * a.ldq * 2) : WBK * 2;
+  const int halfA = A_TR ? 128 * 2 : (int)(128 * a.ldp * 2);
+  const int halfB = B_TR ? 128 * 2 : (int)(128 * a.ldq * 2);
+  // DMA e of the K-tile's ND: the existing half-tiles in the order A0 [A1] B0 [B1], 4 staging rounds each
+  auto dma = [&](int t, int cur, int e) {
+    constexpr int NAH = RM ? 1 : 2;
+    const int hh = e >> 2, i = e & 3;
+    if (hh < NAH) {
+      char* ht = smem + wslotA(hh, cur);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vA0,
-                                               t * kstepA + h4 * halfA + i * rsA, 0, 0);
+                                               t * kstepA + hh * halfA + i * rsA, 0, 0);
     } else {
-      char* ht = smem + wslotB(h4 - 2, cur);
+      const int hb = hh - NAH;
+      char* ht = smem + wslotB(hb, cur);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vB0,
-                                               t * kstepB + (h4 - 2) * halfB + i * rsB, 0, 0);
+                                               t * kstepB + hb * halfB + i * rsB, 0, 0);
     }
   };
 
   // ---- fragment addressing (gemm256.hip's formats) ----------------------------------------------------------------
   const int li = lane & 15, lg = lane >> 4, lq = li >> 2, lp = li & 3;
   const int rsw = (li >> 1) & 7;
-  int rA = wslotA(wr, 0) + (RAGGED ? (wave & 1) * 8192 : 0) + li * 128 + ((lg ^ rsw) << 4);   // row-tile i -> + 2048 i, ks 1 -> ^ 64
-  int rB = wslotB(wc, 0) + li * 128 + ((lg ^ rsw) << 4);
-  // k-strided (transposing read): byte = row*256 + ((i' ^ xe)<<5) + (((p>>1)^hh)<<4) + ((p&1)<<3), row = ks*32 + 8g + q + 4hh
+  // k-contiguous: row tile i -> + 2048 i, k-step 1 -> ^ 64
+  int rA = wslotA(aHalf, 0) + aQuart * 8192 + li * 128 + ((lg ^ rsw) << 4);
+  int rB = wslotB(bHalf, 0) + bQuart * 8192 + li * 128 + ((lg ^ rsw) << 4);
+  // k-strided (transposing read): byte = row*256 + ((i' ^ xe)<<5) + (((p>>1)^hh)<<4) + ((p&1)<<3), row = ks*32 + 8g + q + 4hh,
+  // i' = 16-column tile index inside the half-tile (a quarter starts at i' = 4)
   const int xe = (lq << 1) | (lg & 1);
-  int tB0 = wslotB(wc, 0) + (8 * lg + lq) * 256 + ((lp >> 1) << 4) + ((lp & 1) << 3);
-  int tS = xe << 5;
+  const int trow = (8 * lg + lq) * 256 + ((lp >> 1) << 4) + ((lp & 1) << 3);
+  int tA0 = wslotA(aHalf, 0) + trow, tB0 = wslotB(bHalf, 0) + trow;
+  int tSA = (xe << 5) ^ (aQuart << 7), tSB = (xe << 5) ^ (bQuart << 7);
 
-  bf16x8 Af[2][NI], Bf[2][8];
+  bf16x8 Af[2][NA], Bf[2][NB];
   auto ldA = [&](int cur, int ks, int i) {
-    const char* q = smem + (ks ? (rA ^ 64) : rA) + cur * HTW;
-    Af[ks][i] = *(const bf16x8*)(q + i * 2048);
+    if constexpr (!A_TR) {
+      const char* q = smem + (ks ? (rA ^ 64) : rA) + cur * HTW;
+      Af[ks][i] = *(const bf16x8*)(q + i * 2048);
+    } else {
+      const int sl = tSA ^ (i << 5);
+      const char* p0 = smem + (tA0 + sl);
+      const char* p1 = smem + (((tA0 + 1024) ^ 16) + sl);
+      if (cur == 0) Af[ks][i] = ks ? wtr2<8192>(p0, p1) : wtr2<0>(p0, p1);
+      else Af[ks][i] = ks ? wtr2<HTW + 8192>(p0, p1) : wtr2<HTW>(p0, p1);
+    }
   };
   auto ldB = [&](int cur, int ks, int i) {
-    if constexpr (LAY == LAY_NT) {
+    if constexpr (!B_TR) {
       const char* q = smem + (ks ? (rB ^ 64) : rB) + cur * HTW;
       Bf[ks][i] = *(const bf16x8*)(q + i * 2048);
     } else {
-      const int sl = tS ^ (i << 5);
+      const int sl = tSB ^ (i << 5);
       const char* p0 = smem + (tB0 + sl);
       const char* p1 = smem + (((tB0 + 1024) ^ 16) + sl);
       if (cur == 0) Bf[ks][i] = ks ? wtr2<8192>(p0, p1) : wtr2<0>(p0, p1);
       else Bf[ks][i] = ks ? wtr2<HTW + 8192>(p0, p1) : wtr2<HTW>(p0, p1);
     }
   };
-  // the fragment reads of a k-step spread over the phase's chunks: regular 16 chunks x 1 (even: A tile c/2, odd: B tile c/2);
-  // ragged 8 chunks: B tile c, and A tile c for c < 4
+  // fragment f of a k-step's NF in the order A0 B0 A1 B1 ... (then what is left of the longer list)
+  auto ldf = [&](int cur, int ks, int f) {
+    constexpr int NMIN = NA < NB ? NA : NB;
+    if (f < 2 * NMIN) {
+      if (f & 1) ldB(cur, ks, f >> 1);
+      else ldA(cur, ks, f >> 1);
+    } else if constexpr (NA > NB) {
+      ldA(cur, ks, f - NMIN);
+    } else if constexpr (NB > NA) {
+      ldB(cur, ks, f - NMIN);
+    }
+  };
+  // the fragment reads / DMAs that ride in chunk c: entry e of N goes to chunk e * NCH / N
   auto ldfrag = [&](int cur, int ks, int c) {
-    if constexpr (RAGGED) {
-      ldB(cur, ks, c);
-      if (c < 4) ldA(cur, ks, c);
-    } else {
-      if (c & 1) ldB(cur, ks, c >> 1);
-      else ldA(cur, ks, c >> 1);
-    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+      if (f * NCH / NF == c) ldf(cur, ks, f);
   };
-  // the 16 (ragged: 12, B half-tile 1 does not exist) DMAs of a K-tile spread the same way
   auto dmas = [&](int t, int cur, int c) {
-    if constexpr (RAGGED) {
-      if (c < 6) { dma(t, cur, 2 * c); dma(t, cur, 2 * c + 1); }
-    } else {
-      dma(t, cur, c);
-    }
+#pragma unroll
+    for (int e = 0; e < ND; ++e)
+      if (e * NCH / ND == c) dma(t, cur, e);
   };
 
-  f32x4 acc[NI][8];
+  f32x4 acc[NA][NB];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // TN: bias gradient dbias[m] = sum_k P[k][m] as one more MFMA per row tile against a fragment of ones, in the waves that
+  // own the tile's first columns of the first column tile; these accumulators live in VGPRs (the AGPRs are full)
+  f32x4 accb[LAY == LAY_TN ? NA : 1];
+  bool do_dbias = false;
+  bf16x8 ones;
+  if constexpr (LAY == LAY_TN) {
+    do_dbias = a.dbias != nullptr && tn == 0 && ncol == 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+  }
 
-#define WMMA4(KS, I, J0)                                                                                 \
-  _Pragma("unroll") for (int j = (J0); j < (J0) + 4; ++j)                                                \
-      REED_MFMA_ACC(acc[(I)][j], Bf[(KS)][j], Af[(KS)][(I)]);
+  // chunk c = 4 MFMAs: row tile CI(c), column tiles CJ(c) .. + 3
+#define W_CI(c) (NB == 8 ? ((c) >> 1) : (c))
+#define W_CJ(c) (NB == 8 ? (((c) & 1) * 4) : 0)
+#define WMMA4(KS, C)                                                                                     \
+  _Pragma("unroll") for (int j = W_CJ(C); j < W_CJ(C) + 4; ++j)                                          \
+      REED_MFMA_ACC(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);                                    \
+  if constexpr (LAY == LAY_TN) {                                                                         \
+    if (W_CJ(C) == 0 && do_dbias) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]);               \
+  }
 
-  // One phase = 16 chunks of {one fragment read for the NEXT phase, [one DMA of K-tile DMA_T], 4 MFMAs of k-step KS}: a
-  // single wave feeds the matrix pipe, so everything else is issued in the shadow of the 4 x 16 clk a chunk's MFMAs take.
+  // One phase = NCH chunks of {fragment reads for the NEXT phase, [DMAs of K-tile DMA_T], 4 MFMAs of k-step KS}: a single
+  // wave feeds the matrix pipe, so everything else is issued in the shadow of the 4 x 16 clk a chunk's MFMAs take.
 #define WPHASE(KS, LD_CUR, LD_KS, DMA_ON, DMA_T, DMA_CUR)                            \
   do {                                                                               \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                \
       ldfrag((LD_CUR), (LD_KS), c);                                                  \
       if (DMA_ON) dmas((DMA_T), (DMA_CUR), c);                                       \
-      WMMA4(KS, c >> 1, (c & 1) * 4);                                                \
+      WMMA4(KS, c);                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                             \
     }                                                                                \
   } while (0)
@@ -172,7 +223,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #define WKTILE(T, CUR, PF)                                                                 \
   do {                                                                                     \
     const int t_ = (T);                                                                    \
-    asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tB0), "+v"(tS));                            \
+    asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));     \
     /* phase A: MFMAs of (t, ks0); reads of (t, ks1) */                                    \
     WLGKM0();                                                                              \
     WPHASE(0, (CUR), 1, false, 0, 0);                                                      \
@@ -186,15 +237,15 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     }                                                                                      \
   } while (0)
 
-  constexpr int ND = RAGGED ? 12 : 16;
   if (nt > 0) {
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma(0, 0, d);
     if (nt > 1) {
 #pragma unroll
       for (int d = 0; d < ND; ++d) dma(1, 1, d);
-      if constexpr (RAGGED) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -215,17 +266,31 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 
   // the MFMAs are inline asm: the compiler does not know the accumulators were just written by the matrix pipe
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  // epilogue: the wave's 128 (64) x 128 as two 64-column halves through gemm_common.hpp's tile_epilogue
+  // epilogue: the wave's piece in 64-column groups through gemm_common.hpp's tile_epilogue (fp32 outputs: its pointer path)
   char* stage = smem + 8 * HTW + wave * EPI_STAGE_BYTES;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    f32x4 part[NI][4];
+  for (int h = 0; h < NB / 4; ++h) {
+    f32x4 part[NA][4];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) part[i][j] = acc[i][h * 4 + j];
-    tile_epilogue<EPI, NI, 4>(a, part, m0, RAGGED ? wave * 64 : wr * 128, n0 + wc * 128 + h * 64, lane, 0, stage);
+    tile_epilogue<EPI, NA, 4>(a, part, m0, mrow, n0 + ncol + h * 64, lane, 0, stage);
   }
+  if constexpr (LAY == LAY_TN) {
+    if (do_dbias && (lane >> 4) == 0) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int m = m0 + mrow + i * 16 + (lane & 15);
+        if (m < a.M) {
+          if (a.accumulate) a.dbias[m] += accb[i][0];
+          else a.dbias[m] = accb[i][0];
+        }
+      }
+    }
+  }
+#undef W_CI
+#undef W_CJ
 #undef WMMA4
 #undef WPHASE
 #undef WBARRIER
@@ -252,8 +317,55 @@ __global__ __launch_bounds__(256, 1) void gemm256w_kernel(GemmArgs a) {
     tm = first_m + (bid % per_group) % gs;
     tn = (bid % per_group) / gs;
   }
-  if (a.N - tn * WBN <= 128) gemm256w_body<LAY, EPI, true>(a, smem, tm, tn);
-  else gemm256w_body<LAY, EPI, false>(a, smem, tm, tn);
+  if (a.N - tn * WBN <= 128) gemm256w_body<LAY, EPI, 1>(a, smem, tm, tn);
+  else gemm256w_body<LAY, EPI, 0>(a, smem, tm, tn);
+}
+
+// ---- the weight gradients of one transformer block in one launch: 256^2 tiles of all (<= 4) problems, one per CU ----------
+// SiT-XL/2: fc1 4608x1152, fc2 1152x4608, qkv 3456x1152, proj 1152x1152 = 212 full tiles + 63 ragged ones (half / quarter
+// tiles: 243 tile equivalents for 256 CUs).  Workgroup order: every XCD gets a contiguous run of the full tiles (shared
+// operand column blocks stay in its L2), then a run of the ragged ones — the hardware dispatches in blockIdx order, so the
+// 275 - 256 workgroups that do not fit at once are short ones and start when the first short ones finish, at half time.
+struct TnGroupW {
+  GemmArgs a[4];
+  int n;
+  int fm[4], fn[4], rm[4], rn[4];   // full tile rows / columns, ragged (128-wide) last row / column present
+  int nfull, nrag;
+};
+__global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int qf = g.nfull >> 3, rf = g.nfull & 7, qr = g.nrag >> 3, rr = g.nrag & 7;
+  const int cf = qf + (xcd < rf), sf = xcd * qf + min(xcd, rf);
+  const int cr = qr + (xcd < rr), sr = xcd * qr + min(xcd, rr);
+  int p = 0, tm, tn, mode;
+  if (j < cf) {
+    int F = sf + j;
+    while (p < g.n - 1 && F >= g.fm[p] * g.fn[p]) { F -= g.fm[p] * g.fn[p]; ++p; }
+    tm = F / g.fn[p];
+    tn = F - tm * g.fn[p];
+    mode = 0;
+  } else {
+    if (j - cf >= cr) return;
+    int R = sr + (j - cf);
+    for (;;) {
+      const int nr = g.rn[p] * g.fm[p] + g.rm[p] * g.fn[p] + g.rm[p] * g.rn[p];
+      if (p == g.n - 1 || R < nr) break;
+      R -= nr;
+      ++p;
+    }
+    if (R < g.rn[p] * g.fm[p]) { tm = R; tn = g.fn[p]; mode = 1; }
+    else {
+      R -= g.rn[p] * g.fm[p];
+      if (R < g.rm[p] * g.fn[p]) { tm = g.fm[p]; tn = R; mode = 2; }
+      else { tm = g.fm[p]; tn = g.fn[p]; mode = 3; }
+    }
+  }
+  const GemmArgs& a = g.a[p];
+  if (mode == 0) gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, tm, tn);
+  else if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
+  else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);
+  else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
 }
 
 template <int LAY, int EPI>
@@ -295,4 +407,47 @@ bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) 
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream) {
   if (layout == LAY_NT) return dispatch256w<LAY_NT>(epi, a, stream);
   return dispatch256w<LAY_NN>(epi, a, stream);
+}
+
+int reed_num_cus();         // gemm256.hip
+int reed_gemm_forced_tile();  // gemm.hip
+
+// 1 = launched; 0 = the problems do not suit this kernel (the caller falls back to gemm_tn.hip's grouped launch)
+int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream, int* launched) {
+  *launched = 0;
+  // Off by default.  Measured at b = 256 (tools/bench_wgrad_group.py): 2.70 ms against 2.00 ms for gemm_tn.hip's grouped launch.
+  // With both operands k-strided a K-tile costs this kernel 1.5 us whatever the MFMA count (64 transposing LDS reads per
+  // wave and K-tile: the LDS pipe, not the matrix pipe, paces it), so the 63 ragged tiles take ~0.8 of a full tile's time
+  // instead of half, and the 19 workgroups beyond the 256 CUs add that to the launch.  REED_WGRAD_W4=1 enables it.
+  static const bool on = getenv("REED_WGRAD_W4") && atoi(getenv("REED_WGRAD_W4")) == 1;
+  if (!on || reed_gemm_forced_tile() == 128) return REED_OK;   // force_tile 128: gemm_tn.hip's grouped kernel (tests, A/B)
+  TnGroupW g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  double equiv = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const GemmArgs& a = probs[i];
+    if (a.M % 128 || a.N % 128 || a.K < 2 * WBK) return REED_OK;
+    g.a[i] = a;
+    g.fm[i] = a.M / 256; g.fn[i] = a.N / 256;
+    g.rm[i] = (a.M % 256) != 0; g.rn[i] = (a.N % 256) != 0;
+    g.nfull += g.fm[i] * g.fn[i];
+    g.nrag += g.rn[i] * g.fm[i] + g.rm[i] * g.fn[i] + g.rm[i] * g.rn[i];
+    equiv += g.fm[i] * g.fn[i] + 0.5 * (g.rn[i] * g.fm[i] + g.rm[i] * g.fn[i]) + 0.25 * g.rm[i] * g.rn[i];
+  }
+  const int ncu = reed_num_cus();
+  // one round: every full tile gets a CU at once and the short tiles fill the rest; and the CUs should be mostly busy
+  static const double minfill = getenv("REED_WGRAD_W4_MINFILL") ? atof(getenv("REED_WGRAD_W4_MINFILL")) : 0.7;   // experiments
+  if (g.nfull > ncu || equiv > ncu || equiv < minfill * ncu) return REED_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W);
+    if (e != hipSuccess) { reed_set_error("gemm256w: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  const int grid = 8 * (cdiv(g.nfull, 8) + cdiv(g.nrag, 8));
+  REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(grid), dim3(256), LDS_W, stream, g);
+  REED_LAUNCH_CHECK();
+  *launched = 1;
+  return REED_OK;
 }

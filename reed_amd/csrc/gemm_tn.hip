@@ -195,11 +195,17 @@ int launch_tn(const GemmArgs& a, int splits, hipStream_t stream) {
 }  // namespace
 
 int reed_num_cus();   // gemm256.hip
+int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream, int* launched);   // gemm256w.hip
 
 // n <= 4 problems dw_i[M_i, N_i] f32 (+)= dy_i[K, M_i]^T x_i[K, N_i] (+ optional dbias_i) sharing the token count K.
 // Returns REED_ERR_UNSUPPORTED (nothing launched) when the tiles do not fit one round of workgroup slots.
 int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) {
   REED_CHECK_ARG(n >= 1 && n <= 4, "wgrad_group: 1..4 problems, got %d", n);
+  {   // 256^2 tiles with four 128x128 waves, one workgroup per CU, when the problems fill one round of those
+    int launched = 0;
+    const int rc = reed_gemm256w_tn_group_launch(n, probs, stream, &launched);
+    if (rc != REED_OK || launched) return rc;
+  }
   TnGroupArgs g;
   memset(&g, 0, sizeof(g));
   g.n = n;

@@ -195,8 +195,8 @@ def test_wgrad_group(dev, tokens, shapes, force_tile):
     """reed_wgrad_group (csrc/gemm_tn.hip): the weight + bias gradients of up to four linears in one launch without
     split-K, against fp32 torch and against the per-GEMM path; accumulate; run-to-run bit-identical; identity operand."""
     from reed_amd import ops
-    if force_tile != 0:
-        pytest.skip("one kernel: tile forcing does not apply")
+    if force_tile not in (0, 128):   # 0: with REED_WGRAD_W4=1 in the environment, 256^2 tiles with four 128x128 waves for the
+        pytest.skip("two kernels: force_tile 0 / 128")   # XL/2 block (off by default); 128: always gemm_tn.hip's grouped kernel
     g = torch.Generator().manual_seed(17)
     probs, refs = [], []
     for n_out, k_in in shapes:
@@ -211,7 +211,9 @@ def test_wgrad_group(dev, tokens, shapes, force_tile):
         torch.testing.assert_close(dw, rw, atol=1e-2, rtol=1e-3)
         torch.testing.assert_close(db, rb, atol=1e-2, rtol=1e-3)
         dw0, db0 = torch.zeros_like(dw), torch.zeros_like(db)
+        ops.gemm_force_tile(128)
         ops.linear_wgrad(q[0], q[1], dw0, dbias=db0, lay=ops.TN)
+        ops.gemm_force_tile(force_tile)
         torch.testing.assert_close(dw, dw0, atol=2e-3, rtol=1e-4)        # same products, different summation order
     for q in probs:
         q[2].fill_(float("nan"))

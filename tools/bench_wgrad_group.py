@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""The block's four weight gradients as one grouped launch: gemm_tn.hip's 256x128 / 128x256 tiles with two workgroups per CU
+(force_tile 128) against gemm256w.hip's 256^2 tiles with four 128x128 waves (default), ms per launch.
+usage: python tools/bench_wgrad_group.py [b ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reed_amd import ops  # noqa: E402
+
+dev = torch.device("cuda")
+D, Hm, T = 1152, 4608, 256
+shapes = [(D, Hm), (Hm, D), (D, D), (3 * D, D)]
+for b in [int(v) for v in sys.argv[1:]] or [256, 32]:
+    M = b * T
+    probs = []
+    for n_out, k_in in shapes:
+        dy = (torch.randn(M, n_out, device=dev) * 0.05).to(torch.bfloat16)
+        x = (torch.randn(M, k_in, device=dev) * 0.05).to(torch.bfloat16)
+        out = torch.zeros(n_out * k_in + n_out, device=dev)
+        probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:], n_out, k_in))
+    flop = sum(2.0 * M * n * k for n, k in shapes)
+    res = {}
+    for tile in (128, 0):
+        ops.gemm_force_tile(tile)
+        for _ in range(3):
+            ops.wgrad_group(probs, M)
+        torch.cuda.synchronize()
+        iters = int(os.environ.get("ITERS", "20"))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.wgrad_group(probs, M)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        res[tile] = (ms, [q[2].clone() for q in probs])
+    ops.gemm_force_tile(0)
+    d = max((a_ - b_).abs().max().item() for a_, b_ in zip(res[128][1], res[0][1]))
+    print(f"b={b}: 2 x 4-wave 256x128 tiles {res[128][0]:.4f} ms {flop / res[128][0] / 1e9:7.1f} TF | 4-wave 256^2 tiles {res[0][0]:.4f} ms "
+          f"{flop / res[0][0] / 1e9:7.1f} TF | max |diff| {d:.2e}", flush=True)
