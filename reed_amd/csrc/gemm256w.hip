@@ -10,6 +10,8 @@
 //
 // One K-tile = two phases of 64 MFMAs per wave (k-step 0, k-step 1):
 //   phase A  wait own reads;           issue the 16 fragment reads of (t, ks1);   64 MFMAs on (t, ks0)
+// (A BK = 32 variant with four 32 KiB stages and the DMA issued four stages = two K-tiles ahead behind counted vmcnt waits
+// was built and measured 7 % slower on the NN shapes: the K loop is not waiting for global memory, DESIGN.md.)
 //   phase B  K-tile t+1 landed (vmcnt) + barrier: every wave is done reading K-tile t;
 //            issue the 16 reads of (t+1, ks0); 64 MFMAs on (t, ks1) with the 16 DMAs of K-tile t+2 (into the buffer
 //            K-tile t just left) spread between them, one per 4 MFMAs
@@ -387,21 +389,35 @@ int launch256w(const GemmArgs& a, hipStream_t stream) {
 
 template <int LAY>
 int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
-  switch (epi) {
-    case EPI_BF16: return launch256w<LAY, EPI_BF16>(a, s);
-    case EPI_GELU: return launch256w<LAY, EPI_GELU>(a, s);
-    case EPI_GATE_RES: return launch256w<LAY, EPI_GATE_RES>(a, s);
-    case EPI_DGELU: return launch256w<LAY, EPI_DGELU>(a, s);
+  if constexpr (LAY == LAY_NT) {   // forward GEMMs: SiT blocks, the projector MLP, the frozen towers
+    switch (epi) {
+      case EPI_BF16: return launch256w<LAY, EPI_BF16>(a, s);
+      case EPI_GELU: return launch256w<LAY, EPI_GELU>(a, s);
+      case EPI_SILU: return launch256w<LAY, EPI_SILU>(a, s);
+      case EPI_GATE_RES: return launch256w<LAY, EPI_GATE_RES>(a, s);
+      case EPI_RES_BF16: return launch256w<LAY, EPI_RES_BF16>(a, s);
+      case EPI_LS_RES: return launch256w<LAY, EPI_LS_RES>(a, s);
+    }
+  } else {                         // input gradients
+    switch (epi) {
+      case EPI_BF16: return launch256w<LAY, EPI_BF16>(a, s);
+      case EPI_DGELU: return launch256w<LAY, EPI_DGELU>(a, s);
+      case EPI_DSILU: return launch256w<LAY, EPI_DSILU>(a, s);
+    }
   }
-  reed_set_error("reed_gemm(256w): epilogue %d not built", epi);
+  reed_set_error("reed_gemm(256w): epilogue %d not built for this layout", epi);
   return REED_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) {
-  return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 &&
-         (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GATE_RES || epi == EPI_DGELU);
+  // (QuickGELU / exact-GELU epilogues stay on the 8-wave kernel: their VALU work — erff, two roundings per element — needs two
+  // waves per SIMD to hide its own latency; measured 0.93 vs 0.64 ms on the ViT-L fc1 shape)
+  const bool epi_ok = layout == LAY_NT ? (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES ||
+                                          epi == EPI_RES_BF16 || epi == EPI_LS_RES)
+                                       : (epi == EPI_BF16 || epi == EPI_DGELU || epi == EPI_DSILU);
+  return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 && epi_ok;
 }
 
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream) {

@@ -175,7 +175,7 @@ def test_dinov2_tower_vs_hf_port(dev, tag, E, H, depth, image, reg, B):
 
 
 def test_layerscale_residual_epilogue(dev):
-    """reed_gemm epilogue 12: C f32 = R f32 + gamma f32[n] * float(bf16(acc + bias)) on the 128^2 and 256^2 kernels."""
+    """reed_gemm epilogue 12: C f32 = R f32 + gamma f32[n] * float(bf16(acc + bias)) on the 128^2 and both 256^2 kernels."""
     from reed_amd import ops
     g = torch.Generator().manual_seed(3)
     for M, N, K in ((257 * 3, 384, 384), (4112, 1024, 4096)):
@@ -185,7 +185,7 @@ def test_layerscale_residual_epilogue(dev):
         gamma = (torch.rand(N, generator=g) * 2).to(dev)
         r = torch.randn(M, N, generator=g).to(dev)
         ref = r + gamma * (x.float() @ w.float().t() + b.float()).to(torch.bfloat16).float()
-        for tile in (128, 256):
+        for tile in (128, 256, 257):
             ops.gemm_force_tile(tile)
             out = torch.full((M, N), float("nan"), device=dev)
             ops.gemm(ops.NT, ops.EPI_LS_RES, x, w, M, N, K, out, K, K, N, R=r, ldr=N, bias=b, gate=gamma)
