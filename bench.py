@@ -63,7 +63,7 @@ def random_fill(model, seed):
     A.shadow_version = -1
 
 
-# HBM-side bytes per launch of the dominant kernel's largest shape (fc1 dgrad, b = 256): NOT measured by this run — bench.py
+# HBM-side bytes per launch of the dominant kernel (the block's grouped weight gradients, b = 256): NOT measured by this run — bench.py
 # cannot read PMC counters. The number is the committed rocprofv3 --pmc pass named in TRAFFIC_SOURCE (separate FETCH_SIZE /
 # WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), of the same kernel build.
 TRAFFIC_B256 = None
@@ -71,7 +71,7 @@ TRAFFIC_SOURCE = None
 try:
     with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as _f:
         _t = json.load(_f)
-        TRAFFIC_B256, TRAFFIC_SOURCE = _t["fc1_dgrad_b256_bytes_per_launch"], _t["source"]
+        TRAFFIC_B256, TRAFFIC_SOURCE = _t["wgrad_group_b256_bytes_per_launch"], _t["source"]
 except Exception:
     pass
 
@@ -258,25 +258,25 @@ def main():
     from reed_amd import ops
     T_TOK = 256
 
-    def probe(layout, epi, M, N, K):
-        # the kernel with the largest share of the step (rocprofv3 --stats): the NN GEMM with the plain bf16 epilogue =
-        # the blocks' dgrads of fc1 / qkv / proj on the weight shadow (N = output width D, K = contraction)
-        if layout == ops.NN and epi == ops.EPI_BF16 and M == b * T_TOK and N == 1152 and K in (1152, 3456, 4608):
-            return K
+    def probe(tokens, shapes):
+        # the kernel with the largest share of the step (rocprofv3 --stats, profiles/): gemm_tn_group_kernel = the four weight
+        # gradients of a transformer block in one launch (csrc/gemm_tn.hip); key = its algorithmic flop
+        if tokens == b * T_TOK and len(shapes) == 4:
+            return 2.0 * tokens * sum(n * k for n, k in shapes)
         return None
 
     for _ in range(args.warmup):
         res = step(None, labels, zs, moments=moments)
     barrier()
     if rank == 0 and not args.no_kernel_table:
-        ops.gemm_probe = probe      # event pairs on the launch stream around every launch of the dominant kernel
+        ops.wgrad_group_probe = probe   # event pairs on the launch stream around every launch of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(None, labels, zs, moments=moments)
     t_enq = time.perf_counter() - t0    # host time to enqueue the K steps (the GPU runs behind; no sync inside a step)
     barrier()
     dt = time.perf_counter() - t0
-    ops.gemm_probe = None
+    ops.wgrad_group_probe = None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -346,23 +346,21 @@ def main():
         }
         if not args.no_kernel_table:
             # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region
-            M = b * T_TOK
             n_l = sum(len(v) for v in dom.values())
             tot_ms = sum(sum(v) for v in dom.values())
-            tot_fl = sum(2.0 * M * 1152 * K * len(v) for K, v in dom.items())
+            tot_fl = sum(fl * len(v) for fl, v in dom.items())
             ach = tot_fl / max(tot_ms, 1e-9) / 1e9
-            shapes = {f"K={K}": {"launches": len(v), "avg_ms": round(sum(v) / len(v), 4),
-                                 "tflops": round(2.0 * M * 1152 * K / (sum(v) / len(v)) / 1e9, 1)} for K, v in sorted(dom.items())}
-            kname = ("gemm144_kernel<NN, bf16>" if b <= 64 else "gemm256_kernel<NN, bf16>")
             out["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach * 1e12 / PEAK_BF16, 4),
                 "traffic": TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None,
                 "traffic_source": TRAFFIC_SOURCE if (b == 256 and args.model == "SiT-XL/2") else None,
-                "kernel": kname + " = the dgrads of fc1 (K=4608) / qkv (K=3456) / proj (K=1152) on the bf16 weight shadow, "
-                          "output [b*256, 1152]; algorithmic flop 2*M*1152*K per launch / event-timed duration of every such "
-                          "launch INSIDE the timed region (events on the launch stream)",
-                "launches_timed": n_l, "avg_ms_per_launch": round(tot_ms / max(n_l, 1), 4), "per_shape": shapes}
+                "kernel": "gemm_tn_group_kernel = the weight (+ bias) gradients of one transformer block's four linears (fc2, fc1, "
+                          "proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch of 256x128 / 128x256 tiles without split-K; "
+                          "algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration of every such launch "
+                          "INSIDE the timed region (events on the launch stream; the largest single share of the step)",
+                "launches_timed": n_l, "avg_ms_per_launch": round(tot_ms / max(n_l, 1), 4),
+                "flop_per_launch": (next(iter(dom)) if dom else None)}
             rows = time_gemms(b)
             tot = sum(r["ms"] for r in rows)
             agg = sum(r["tflops"] * r["ms"] for r in rows) / tot

@@ -66,6 +66,7 @@ def require_cuda(t, name="tensor"):
 # attribute test per launch.
 gemm_probe = None
 gemm_probe_log = []
+wgrad_group_probe = None   # the same for the grouped weight-gradient launch: wgrad_group_probe(tokens, [(n_out, k_in), ...])
 
 
 def gemm(layout, epi, P, Q, M, N, K, C, ldp, ldq, ldc, C2=None, ldc2=0, R=None, ldr=0, bias=None,
@@ -193,11 +194,18 @@ def wgrad_group(problems, tokens, accumulate=False):
     ki = ip(*[int(q[5]) for q in problems])
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)  # noqa: E731
     L = _lib.load(_PRECISION)
+    key = wgrad_group_probe(tokens, [(int(q[4]), int(q[5])) for q in problems]) if wgrad_group_probe is not None else None
+    if key is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = L.reed_wgrad_group(n, cast(dy), cast(x), cast(dw), cast(db), cast(no), cast(ki), int(tokens), int(accumulate),
                             _stream())
     if rc == 1002:
         return False
     _lib.check(rc, "reed_wgrad_group", L)
+    if key is not None:
+        e1.record()
+        gemm_probe_log.append((key, e0, e1))
     return True
 
 
