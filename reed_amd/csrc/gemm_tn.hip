@@ -12,6 +12,7 @@
 // for fc2 (1152x4608).  Ragged M needs no masking: rows >= M read whatever the descriptor returns and are never stored.
 // Operand tiles use gemm_common.hpp's k-strided format ([k][128 columns], 256-B rows, chunk swizzle tr_sw) at 32
 // k-rows per tile and are read with the transposing LDS read; staging is LDS-DMA as in gemm.hip.
+#include <stdlib.h>
 #include <string.h>
 
 #include "gemm_common.hpp"
@@ -36,9 +37,10 @@ __device__ __forceinline__ void stage_sub(__amdgpu_buffer_rsrc_t rs, char* tile,
   }
 }
 
-// bid: the workgroup's index among the problem's tiles; z / nz: K slice and slice count (1 = write C directly)
+// (tm, tn): the output tile; z / nz: K slice and slice count (1 = write C directly)
 template <bool WIDE>
-__device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, int bid, const int z, const int nz) {
+__device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, const int tm, const int tn, const int z,
+                                             const int nz) {
   constexpr int TM = WIDE ? 4 : 8, TNN = WIDE ? 8 : 4;        // 16x16 MFMA tiles per wave along M / N
   constexpr int PSUB = WIDE ? 1 : 2, QSUB = WIDE ? 2 : 1;     // 128-column sub-tiles of the P / Q operand tile
   constexpr int BMT = PSUB * 128, BNT = QSUB * 128;
@@ -47,18 +49,6 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, int 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int ntm = (a.M + BMT - 1) / BMT, ntn = a.N / BNT;
-  const int nwg = ntm * ntn;
-  {
-    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GM = 4;
-  const int per_group = GM * ntn;
-  const int group = bid / per_group, first_m = group * GM;
-  const int gs = min(ntm - first_m, GM);
-  const int tm = first_m + (bid % per_group) % gs;
-  const int tn = (bid % per_group) / gs;
   const int m0 = tm * BMT, n0 = tn * BNT;
   const int kbeg = z * a.ksplit_len;
   const int kend = min(a.K, kbeg + a.ksplit_len);
@@ -144,10 +134,30 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, int 
   }
 }
 
+// one problem's workgroup -> tile map: every XCD a contiguous run of tiles, walked in groups of 4 tile rows x all tile columns
+template <bool WIDE>
+__device__ __forceinline__ void tn_tile_of(const GemmArgs& a, int bid, int& tm, int& tn) {
+  constexpr int BMT = WIDE ? 128 : 256, BNT = WIDE ? 256 : 128;
+  const int ntm = (a.M + BMT - 1) / BMT, ntn = a.N / BNT;
+  const int nwg = ntm * ntn;
+  {
+    int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GM = 4;
+  const int per_group = GM * ntn;
+  const int group = bid / per_group, first_m = group * GM;
+  const int gs = min(ntm - first_m, GM);
+  tm = first_m + (bid % per_group) % gs;
+  tn = (bid % per_group) / gs;
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_tn_body<WIDE>(a, smem, blockIdx.x, blockIdx.y, gridDim.y);
+  int tm, tn;
+  tn_tile_of<WIDE>(a, blockIdx.x, tm, tn);
+  gemm_tn_body<WIDE>(a, smem, tm, tn, blockIdx.y, gridDim.y);
 }
 
 // The weight gradients of one transformer block in ONE launch, no split-K: at K = b x 256 tokens a single wgrad has too
@@ -156,25 +166,43 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs a) {
 // slowed the GEMMs to 490-870 TFLOP/s).  Together the four problems have 495 tiles, 512 with each problem's run padded to
 // a multiple of 8 (the XCD interleave): one full round of equal-length K loops writing the gradient arena directly —
 // deterministic, and the same at every batch size.
+// Workgroup -> tile map (compact = 1): the tiles of all problems form ONE sequence — a 256x128-tile problem row by row
+// (column tiles fastest), a 128x256-tile problem column by column — and XCD x (workgroups x, x + 8, ...: the hardware deals
+// workgroups round-robin to the 8 XCDs) takes a contiguous 1/8 of it: ~62 tiles = 7 operand blocks of the wide operand x all 9
+// blocks of the narrow one, so an operand block is fetched into one or two L2s instead of four or five (PMC).
 struct TnGroupArgs {
   GemmArgs a[4];
-  int first[5];   // first workgroup of each problem (multiples of 8); first[n] = grid size
+  int first[5];   // compact = 0: first workgroup of each problem (multiples of 8); compact = 1: first tile in the sequence
   int wide[4];
   int n;
+  int compact;
 };
 __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  int seq = blockIdx.x;
+  if (g.compact) {
+    seq = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (seq >= g.first[g.n]) return;
+  }
   int p = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i)
-    if (i < g.n && (int)blockIdx.x >= g.first[i]) p = i;
-  const int bid = blockIdx.x - g.first[p];
+    if (i < g.n && seq >= g.first[i]) p = i;
+  const int l = seq - g.first[p];
   const GemmArgs& a = g.a[p];
   const int wide = g.wide[p];
-  const int tiles = wide ? ((a.M + 127) / 128) * (a.N / 256) : ((a.M + 255) / 256) * (a.N / 128);
-  if (bid >= tiles) return;   // padding of the problem's run
-  if (wide) gemm_tn_body<true>(a, smem, bid, 0, 1);
-  else gemm_tn_body<false>(a, smem, bid, 0, 1);
+  int tm, tn;
+  if (g.compact) {
+    if (wide) { const int ntm = (a.M + 127) / 128; tn = l / ntm; tm = l - tn * ntm; }
+    else { const int ntn = a.N / 128; tm = l / ntn; tn = l - tm * ntn; }
+  } else {
+    const int tiles = wide ? ((a.M + 127) / 128) * (a.N / 256) : ((a.M + 255) / 256) * (a.N / 128);
+    if (l >= tiles) return;   // padding of the problem's run
+    if (wide) tn_tile_of<true>(a, l, tm, tn);
+    else tn_tile_of<false>(a, l, tm, tn);
+  }
+  if (wide) gemm_tn_body<true>(a, smem, tm, tn, 0, 1);
+  else gemm_tn_body<false>(a, smem, tm, tn, 0, 1);
 }
 
 template <bool WIDE>
@@ -209,7 +237,9 @@ int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) 
   TnGroupArgs g;
   memset(&g, 0, sizeof(g));
   g.n = n;
-  int at = 0;
+  static const int compact = getenv("REED_WGRAD_MAP") ? atoi(getenv("REED_WGRAD_MAP")) : 1;   // 0: per-problem runs (A/B)
+  g.compact = compact;
+  int at = 0, padded = 0;
   for (int i = 0; i < n; ++i) {
     const GemmArgs& a = probs[i];
     REED_CHECK_ARG(a.N % 128 == 0 && a.M % 16 == 0 && a.K == probs[0].K && a.K > 0,
@@ -220,13 +250,15 @@ int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) 
     g.a[i].ksplit_len = cdiv(a.K, TBK) * TBK;
     g.wide[i] = wid < tall;
     g.first[i] = at;
-    at += (min(tall, wid) + 7) & ~7;
+    at += compact ? min(tall, wid) : (min(tall, wid) + 7) & ~7;
+    padded += (min(tall, wid) + 7) & ~7;
   }
   g.first[n] = at;
-  if (at > 2 * reed_num_cus()) {
-    reed_set_error("wgrad_group: %d workgroups do not fit one round of %d slots", at, 2 * reed_num_cus());
+  if (padded > 2 * reed_num_cus()) {   // (the padded count: the planning side, ops.wgrad_group_blocks, counts the same way)
+    reed_set_error("wgrad_group: %d workgroups do not fit one round of %d slots", padded, 2 * reed_num_cus());
     return REED_ERR_UNSUPPORTED;
   }
+  if (compact) at = 8 * cdiv(at, 8);
   constexpr int LDS = 2 * 3 * SUB_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
