@@ -145,8 +145,10 @@ def colsum_bf16(x, ld, ws, out, M, N, accumulate=False):
 
 
 def gemm_force_tile(tile):
-    """0 = heuristic, 128 / 256 = force that GEMM kernel (tests and A/B timing)."""
-    _lib.load().reed_gemm_force_tile(int(tile))
+    """0 = heuristic; 128 / 256 (eight waves) / 257 (four 128x128 waves) / 144 = force that GEMM kernel where it applies
+    (tests and A/B timing).  Set in both builds of the library."""
+    for prec in ("bf16", "fp16"):
+        _lib.load(prec).reed_gemm_force_tile(int(tile))
 
 
 WGRAD_SLOTS = 512  # resident 128x128 blocks: 256 CUs x 2 (64 KiB LDS, <=128 VGPRs... see gemm.hip launch bounds)

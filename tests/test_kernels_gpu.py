@@ -492,3 +492,26 @@ def test_fp16_library_gemm_and_attention(dev):
         torch.testing.assert_close(lse, rl, atol=2e-3, rtol=1e-4)
     print("GEMM / attention max abs error vs fp32: bf16 build", errs["bf16"], " fp16 build", errs["fp16"])
     assert errs["fp16"][0] < 0.25 * errs["bf16"][0] and errs["fp16"][1] < 0.25 * errs["bf16"][1]
+    # the IEEE-half build of every 256-wide tile kernel (eight waves, four 128x128 waves with asm MFMAs, 256x144), forward
+    # and input-gradient layouts, ragged last column tile (N = 1152), against fp32 and against each other (bit-identical)
+    M, N, K = 1024, 1152, 1152
+    x = torch.randn(M, K, generator=g).to(torch.float16).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.float16).to(dev)
+    wn = (torch.randn(K, N, generator=g) / K ** 0.5).to(torch.float16).to(dev)
+    outs = {}
+    prev = ops.use("fp16")
+    try:
+        for tile in (256, 257, 144):
+            ops.gemm_force_tile(tile)
+            o1 = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+            o2 = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+            ops.linear_fwd(x, w, None, o1)
+            ops.gemm(ops.NN, ops.EPI_BF16, x, wn, M, N, K, o2, K, N, N)
+            outs[tile] = (o1, o2)
+    finally:
+        ops.gemm_force_tile(0)
+        ops.use(prev)
+    torch.testing.assert_close(outs[257][0].float(), x.float() @ w.float().t(), atol=4e-3, rtol=2e-3)
+    torch.testing.assert_close(outs[257][1].float(), x.float() @ wn.float(), atol=4e-3, rtol=2e-3)
+    assert torch.equal(outs[256][0], outs[257][0]) and torch.equal(outs[256][1], outs[257][1])
+    torch.testing.assert_close(outs[144][0].float(), outs[257][0].float(), atol=4e-3, rtol=2e-3)
