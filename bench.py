@@ -265,7 +265,9 @@ def main():
             return 2.0 * tokens * sum(n * k for n, k in shapes)
         return None
 
-    for _ in range(args.warmup):
+    # W untimed warm-up steps — more when the data-parallel step still measures its CU reserve (trainer.py): that
+    # measurement (two steps per candidate) stays out of the timed region
+    for _ in range(max(args.warmup, step.tune_steps_left() + 1 if step.tune_steps_left() else 0)):
         res = step(None, labels, zs, moments=moments)
     barrier()
     if rank == 0 and not args.no_kernel_table:
@@ -294,6 +296,8 @@ def main():
     bk = L.buckets()
     dp = {"world": world, "buckets": len(bk), "gradient_bytes": int(4 * L.n_train),
           "largest_bucket_bytes": int(4 * max(e - b0 for _, (b0, e) in bk)),
+          # CUs the GEMM grids leave to RCCL's channels: measured by the first steps (reserve -> ms per step, MAX over ranks)
+          "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning,
           "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}
     if reducer is not None:
         try:

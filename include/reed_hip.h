@@ -57,6 +57,11 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
 int reed_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* dw, float* const* dbias,
                      const int* n_out, const int* k_in, int tokens, int accumulate, void* stream);
 
+/* CUs the GEMM tile heuristics plan for: the device's count (or REED_GEMM_CUS) minus a reserve for kernels that hold CUs
+ * beside the GEMMs (RCCL channels during a gradient bucket).  reed_set_cu_reserve(n): n >= 0; reed_planning_cus(): the result. */
+int reed_set_cu_reserve(int n);
+int reed_planning_cus(void);
+
 /* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel, 144 = force
  * the 256x144 kernel wherever it applies (NT / NN, bf16-output epilogue, N % 144 == 0, no split-K) */
 int reed_gemm_force_tile(int tile);

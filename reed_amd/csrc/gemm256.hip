@@ -376,10 +376,12 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-// CUs the tile heuristics plan for.  REED_GEMM_CUS overrides the device's count: while a gradient bucket is in flight RCCL's
-// channels hold CUs, and a grid planned as exactly one round of 256 workgroups (the 256x144 tile at b = 32 per GPU) turns
-// into two rounds on what is left — set e.g. REED_GEMM_CUS=240 for the data-parallel run if the 8-GPU trace shows that
-// (bench.py reports the value under data_parallel.env).
+// CUs the tile heuristics plan for = the device's count (or REED_GEMM_CUS) minus a reserve (reed_set_cu_reserve).  While a
+// gradient bucket is in flight RCCL's channels hold CUs, and a grid planned as exactly one round of the 256 CUs — the 256x144
+// tile at b = 32 per GPU, the grouped weight gradients' 512 slots — turns into two rounds on what is left.  The data-parallel
+// train step measures a few reserves during its first steps and keeps the fastest (reed_amd/trainer.py).
+static int g_cu_reserve = 0;
+extern "C" int reed_set_cu_reserve(int n) { g_cu_reserve = n > 0 ? n : 0; return 0; }
 int reed_num_cus() {
   static int n = 0;
   if (!n) {
@@ -392,8 +394,9 @@ int reed_num_cus() {
     }
     if (n <= 0) n = 256;
   }
-  return n;
+  return n - g_cu_reserve > 32 ? n - g_cu_reserve : 32;
 }
+extern "C" int reed_planning_cus(void) { return reed_num_cus(); }
 
 // Kernel selection (NT forward / NN dgrad), a round-count model fitted to A/B timing at the SiT-XL/2 shapes for b = 64
 // and 256 per GPU (tools/stagger_sweep.py): the 256^2 kernel does one tile per CU at a time and is ~1.18x faster per

@@ -152,6 +152,22 @@ def gemm_force_tile(tile):
 
 
 WGRAD_SLOTS = 512  # resident 128x128 blocks: 256 CUs x 2 (64 KiB LDS, <=128 VGPRs... see gemm.hip launch bounds)
+_CU_RESERVE = 0
+
+
+def set_cu_reserve(n):
+    """Plan the GEMM grids for n fewer CUs (RCCL's channels hold CUs while a gradient bucket is in flight)."""
+    global _CU_RESERVE
+    _CU_RESERVE = max(0, int(n))
+    for prec in ("bf16", "fp16"):
+        _lib.load(prec).reed_set_cu_reserve(_CU_RESERVE)
+
+
+def wgrad_slots():
+    """Workgroup slots the weight-gradient planning fills: 2 per CU the heuristics plan for."""
+    if torch.cuda.is_available():
+        return 2 * int(_lib.load().reed_planning_cus())
+    return WGRAD_SLOTS - 2 * _CU_RESERVE
 WGRAD_SPLIT_MAX = int(__import__("os").environ.get("REED_WGRAD_SPLIT_MAX", "8"))  # experiments: cap the split count
 
 
@@ -178,7 +194,7 @@ def wgrad_group_fits(shapes, min_fill=0.75):
     if os.environ.get("REED_WGRAD_GROUP", "1") == "0":
         return False
     n = wgrad_group_blocks(shapes)
-    slots = 2 * int(os.environ.get("REED_GEMM_CUS", "0") or 0) or WGRAD_SLOTS
+    slots = wgrad_slots()
     return n is not None and len(shapes) <= 4 and min_fill * slots <= n <= slots
 
 
@@ -221,6 +237,7 @@ def plan_wgrad(Mtok, N, K):
     good choices the one whose K slice is closest to 256 K-tiles (16384 tokens) wins: long enough to amortise the
     prologue/epilogue + slab traffic, short enough that two rounds overlap their tails."""
     ktiles = (Mtok + 63) // 64
+    slots = wgrad_slots()
     best, best_key = (TN, 1), None
     for lay, bm, bn, rate in WGRAD_TILES:
         if K % bn or N % 128:
@@ -231,7 +248,7 @@ def plan_wgrad(Mtok, N, K):
             if s > 1 and ktiles // s < 32:
                 break
             blocks = tiles * s
-            eff = blocks / (((blocks + WGRAD_SLOTS - 1) // WGRAD_SLOTS) * WGRAD_SLOTS)
+            eff = blocks / (((blocks + slots - 1) // slots) * slots)
             dist = abs(math.log((ktiles / s) / 256.0))
             key = (-round(rate * fill * eff / 0.03), dist)   # 3 % buckets of estimated throughput, then slice length
             if best_key is None or key < best_key:

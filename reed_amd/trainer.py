@@ -66,6 +66,23 @@ class TrainStep:
         self.grad_accum = max(1, int(grad_accum))
         self.global_step = 0
         self._micro = 0
+        # CU reserve for the GEMM grids under data parallelism (csrc/gemm256.hip:reed_num_cus): RCCL's channels hold CUs while
+        # a bucket is in flight, and grids planned as exactly one round of all CUs then take two.  How many CUs RCCL takes
+        # depends on its version, topology and message size, so it is MEASURED: the first steps run with a reserve of
+        # 0 / 16 / 32 CUs (one settling step + one timed step each, events on the compute stream), the ranks agree on the
+        # fastest (MAX over ranks per candidate) and keep it.  REED_COMM_CUS=<n> fixes it, REED_COMM_CUS=off keeps 0.
+        self.cu_reserve = 0
+        self.cu_tuning = None
+        self._tune = []
+        mode = os.environ.get("REED_COMM_CUS", "auto")
+        if reducer is not None and reducer.active() and mode != "off":
+            if mode == "auto":
+                cands = [int(v) for v in os.environ.get("REED_COMM_CUS_CANDIDATES", "0,16,32").split(",")]
+                self._tune = [(c, timed) for c in cands for timed in (False, True)]
+                self._tune_times = {}
+            else:
+                self.cu_reserve = int(mode)
+                ops.set_cu_reserve(self.cu_reserve)
 
     def __call__(self, x, labels, zs, moments=None, **inject):
         """x: latents [b,4,32,32] (or pass moments=[b,8,32,32] to run sample_posterior). Returns device scalars."""
@@ -76,6 +93,12 @@ class TrainStep:
             x = sample_posterior(moments, self.latents_scale, self.latents_bias)
         self._micro += 1
         syncing = self._micro % self.grad_accum == 0
+        tune = self._tune[0] if self._tune and self._micro % self.grad_accum == 1 % self.grad_accum else None
+        if tune is not None:
+            ops.set_cu_reserve(tune[0])
+            if tune[1]:
+                self._tune_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                self._tune_ev[0].record()
         if self.reducer is not None:
             self.reducer.enabled = syncing  # DDP no_sync on non-final micro-steps (accelerate accumulate())
         out = self.loss_fn(self.model, x, dict(y=labels), zs=zs, **inject)
@@ -97,4 +120,31 @@ class TrainStep:
             self.opt.zero_grad()
             self.global_step += 1
             res["grad_norm"] = self.opt.grad_norm.clone()   # opt.grad_norm is a view the next step overwrites
+            if self._tune:
+                self._tune_step()
         return res
+
+    def tune_steps_left(self):
+        """Optimiser steps the CU-reserve measurement still needs (bench.py keeps them out of its timed region)."""
+        return len(self._tune)
+
+    def _tune_step(self):
+        cand, timed = self._tune.pop(0)
+        if timed:
+            self._tune_ev[1].record()
+            self._tune_times[cand] = self._tune_ev
+        if self._tune:
+            return
+        import torch.distributed as dist
+        cands = sorted(self._tune_times)
+        for c in cands:
+            self._tune_times[c][1].synchronize()
+        t = torch.tensor([self._tune_times[c][0].elapsed_time(self._tune_times[c][1]) for c in cands], dtype=torch.float64,
+                         device=self.opt.grad_norm.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = t.tolist()
+        best = cands[min(range(len(cands)), key=lambda i: t[i])]
+        self.cu_reserve = best
+        self.cu_tuning = {str(c): round(v, 3) for c, v in zip(cands, t)}
+        ops.set_cu_reserve(best)

@@ -80,6 +80,61 @@ def test_train_default_mixed_precision_is_fp16(dev, tmp_path):
         train.main(train.parse_args(["--exp-name", "n", "--max-train-steps", "1", "--mixed-precision", "no"] + common))
 
 
+def test_cu_reserve_is_measured_under_a_reducer(dev):
+    """Data-parallel TrainStep (RCCL process group at world 1, forced): the first six optimiser steps run with a CU reserve of
+    0 / 16 / 32 for the GEMM grids (one settling + one timed step each), the fastest is kept and reported; without a reducer
+    nothing is tuned; REED_COMM_CUS=<n> fixes the reserve."""
+    import copy
+    import torch.distributed as dist
+    from oracle import detfill
+    from reed_amd import _lib, ops
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT
+    from reed_amd.optim import FusedAdamWEMA
+    from reed_amd.parallel import GradReducer
+    from reed_amd.trainer import TrainStep
+    os.environ["REED_COMM"] = "torch"
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29741")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    os.environ["REED_FORCE_REDUCER"] = "1"
+    try:
+        m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10, z_dims=[128],
+                z_types=["i"], encoder_depth=2, projector_dim=128)
+        detfill.fill_state_dict(m.state_dict(), base_seed=5)
+        m = m.to(dev).train()
+        lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+        x = detfill.normal((4, 4, 8, 8), 1).to(dev)
+        y = torch.tensor([1, 5, 9, 0], device=dev)
+        zs = [detfill.normal((4, 16, 128), 4).to(dev)]
+        plain = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), None, diffusion_warm_up_steps=0)
+        assert plain.tune_steps_left() == 0 and plain.cu_reserve == 0
+        red = GradReducer(m)
+        ts = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red, diffusion_warm_up_steps=0)
+        assert ts.tune_steps_left() == 6
+        full = _lib.load().reed_planning_cus()
+        seen = []
+        for _ in range(7):
+            r = ts(x, y, zs)
+            seen.append(_lib.load().reed_planning_cus())
+        torch.cuda.synchronize()
+        assert torch.isfinite(r["loss"]).item()
+        assert seen[:6] == [full, full, full - 16, full - 16, full - 32, full - 32]
+        assert ts.tune_steps_left() == 0 and set(ts.cu_tuning) == {"0", "16", "32"} and ts.cu_reserve in (0, 16, 32)
+        assert seen[6] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
+        red.close()
+        os.environ["REED_COMM_CUS"] = "24"
+        red2 = GradReducer(m)
+        ts2 = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red2, diffusion_warm_up_steps=0)
+        assert ts2.tune_steps_left() == 0 and ts2.cu_reserve == 24 and _lib.load().reed_planning_cus() == full - 24
+        red2.close()
+    finally:
+        os.environ.pop("REED_FORCE_REDUCER", None)
+        os.environ.pop("REED_COMM_CUS", None)
+        ops.set_cu_reserve(0)
+
+
 @pytest.mark.parametrize("algo", ["allreduce", "rsag"])
 @pytest.mark.parametrize("ada_gather", ["1", "0"])
 @pytest.mark.parametrize("binding", ["native", "torch"])
