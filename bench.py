@@ -297,7 +297,7 @@ def main():
     dp = {"world": world, "buckets": len(bk), "gradient_bytes": int(4 * L.n_train),
           "largest_bucket_bytes": int(4 * max(e - b0 for _, (b0, e) in bk)),
           # CUs the GEMM grids leave to RCCL's channels: measured by the first steps (reserve -> ms per step, MAX over ranks)
-          "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning,
+          "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning, "algo_in_use": getattr(reducer, "algo", None),
           "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}
     if reducer is not None:
         try:

@@ -71,15 +71,21 @@ class TrainStep:
         # depends on its version, topology and message size, so it is MEASURED: the first steps run with a reserve of
         # 0 / 16 / 32 CUs (one settling step + one timed step each, events on the compute stream), the ranks agree on the
         # fastest (MAX over ranks per candidate) and keep it.  REED_COMM_CUS=<n> fixes it, REED_COMM_CUS=off keeps 0.
+        # The same measurement then decides how a bucket is reduced when REED_COMM_ALGO is not set: one ncclAllReduce, or
+        # ncclReduceScatter + ncclAllGather (parallel.py) — two more steps at the reserve just chosen.
         self.cu_reserve = 0
         self.cu_tuning = None
         self._tune = []
+        self._tune_algo = False
         mode = os.environ.get("REED_COMM_CUS", "auto")
         if reducer is not None and reducer.active() and mode != "off":
             if mode == "auto":
                 cands = [int(v) for v in os.environ.get("REED_COMM_CUS_CANDIDATES", "0,16,32").split(",")]
                 self._tune = [(c, timed) for c in cands for timed in (False, True)]
                 self._tune_times = {}
+                self._tune_algo = "REED_COMM_ALGO" not in os.environ and hasattr(reducer, "algo")
+                if self._tune_algo:
+                    self._tune += [("rsag", False), ("rsag", True)]
             else:
                 self.cu_reserve = int(mode)
                 ops.set_cu_reserve(self.cu_reserve)
@@ -95,7 +101,10 @@ class TrainStep:
         syncing = self._micro % self.grad_accum == 0
         tune = self._tune[0] if self._tune and self._micro % self.grad_accum == 1 % self.grad_accum else None
         if tune is not None:
-            ops.set_cu_reserve(tune[0])
+            if tune[0] == "rsag":
+                self.reducer.algo = "rsag"
+            else:
+                ops.set_cu_reserve(tune[0])
             if tune[1]:
                 self._tune_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 self._tune_ev[0].record()
@@ -128,23 +137,29 @@ class TrainStep:
         """Optimiser steps the CU-reserve measurement still needs (bench.py keeps them out of its timed region)."""
         return len(self._tune)
 
+    def _agree(self, times):
+        import torch.distributed as dist
+        t = torch.tensor(times, dtype=torch.float64, device=self.opt.grad_norm.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
     def _tune_step(self):
         cand, timed = self._tune.pop(0)
         if timed:
             self._tune_ev[1].record()
             self._tune_times[cand] = self._tune_ev
-        if self._tune:
-            return
-        import torch.distributed as dist
-        cands = sorted(self._tune_times)
-        for c in cands:
-            self._tune_times[c][1].synchronize()
-        t = torch.tensor([self._tune_times[c][0].elapsed_time(self._tune_times[c][1]) for c in cands], dtype=torch.float64,
-                         device=self.opt.grad_norm.device)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t = t.tolist()
-        best = cands[min(range(len(cands)), key=lambda i: t[i])]
-        self.cu_reserve = best
-        self.cu_tuning = {str(c): round(v, 3) for c, v in zip(cands, t)}
-        ops.set_cu_reserve(best)
+        ms = lambda c: (self._tune_times[c][1].synchronize(), self._tune_times[c][0].elapsed_time(self._tune_times[c][1]))[1]  # noqa: E731
+        nxt = self._tune[0][0] if self._tune else None
+        if self.cu_tuning is None and (nxt is None or nxt == "rsag"):   # every reserve candidate is timed: keep the fastest
+            cands = sorted(c for c in self._tune_times if c != "rsag")
+            t = self._agree([ms(c) for c in cands])
+            best = min(range(len(cands)), key=lambda i: t[i])
+            self.cu_reserve = cands[best]
+            self.cu_tuning = {str(c): round(v, 3) for c, v in zip(cands, t)}
+            self._best_ms = t[best]
+            ops.set_cu_reserve(self.cu_reserve)
+        if not self._tune and self._tune_algo:                           # the bucket form at that reserve
+            t = self._agree([ms("rsag")])[0]
+            self.cu_tuning["rsag"] = round(t, 3)
+            self.reducer.algo = "rsag" if t < self._best_ms else "allreduce"

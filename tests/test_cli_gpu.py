@@ -112,17 +112,20 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
         assert plain.tune_steps_left() == 0 and plain.cu_reserve == 0
         red = GradReducer(m)
         ts = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red, diffusion_warm_up_steps=0)
-        assert ts.tune_steps_left() == 6
+        assert ts.tune_steps_left() == 8          # 3 reserves + the reduce-scatter / all-gather bucket form, 2 steps each
         full = _lib.load().reed_planning_cus()
-        seen = []
-        for _ in range(7):
+        seen, algos = [], []
+        for _ in range(9):
+            algos.append(red.algo)
             r = ts(x, y, zs)
             seen.append(_lib.load().reed_planning_cus())
         torch.cuda.synchronize()
         assert torch.isfinite(r["loss"]).item()
         assert seen[:6] == [full, full, full - 16, full - 16, full - 32, full - 32]
-        assert ts.tune_steps_left() == 0 and set(ts.cu_tuning) == {"0", "16", "32"} and ts.cu_reserve in (0, 16, 32)
-        assert seen[6] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
+        assert ts.tune_steps_left() == 0 and set(ts.cu_tuning) == {"0", "16", "32", "rsag"} and ts.cu_reserve in (0, 16, 32)
+        assert seen[6] == seen[8] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
+        assert algos[:6] == ["allreduce"] * 6 and algos[6] == "allreduce" and algos[7] == "rsag" and red.algo in ("allreduce", "rsag")
+        assert red.algo == ("rsag" if ts.cu_tuning["rsag"] < ts.cu_tuning[str(ts.cu_reserve)] else "allreduce")
         red.close()
         os.environ["REED_COMM_CUS"] = "24"
         red2 = GradReducer(m)
