@@ -621,8 +621,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(const bf16* __restr
 // four 80-KiB workgroups per item with 16-row waves, two per CU (dQ / dK,dV roles; each role re-reads all operands:
 // 2.7 GB per launch against 1.2 GB, 600 us), and this kernel with 16 waves of 16 rows at 128 VGPRs (every fragment read
 // feeds one MFMA instead of two: LDS traffic doubles, 630 us).  This form: 575 us at b = 256.
-template <int HD>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+// QT = 16-row tiles per wave: 2 = eight waves of 32 rows (two per SIMD, 256 registers each); 4 = four waves of 64 rows, one per
+// SIMD with the 512-register file: a K / V (Q / dO) fragment read then feeds four MFMAs instead of two — half the LDS traffic.
+template <int HD, int QT>
+__global__ __launch_bounds__(1024 / QT, QT == 4 ? 1 : 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                        const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                        bf16* __restrict__ dqkv, int B, int T, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -650,13 +652,14 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   // and pair: K, V first — phase 1 (dQ) reads them — then this wave's own query rows straight into registers (Q and dO
   // fragments, the O rows of its delta = rowsum(dO * O), the log-sum-exp), then Q, dO, which only phase 2 needs: they
   // land while phase 1 computes.  The wait before phase 1 is counted (the Q / dO pieces stay in flight).
-  const int r0 = wave * 32;  // this wave's 32 rows (queries in phase 1, keys in phase 2)
+  constexpr int NWV = 16 / QT, WR = 16 * QT;   // waves, rows per wave
+  const int r0 = wave * WR;  // this wave's rows (queries in phase 1, keys in phase 2)
   const bf16* gbase = d_o + (long)b * T * D + h * HD;
   auto issue_pair = [&](char* t0, const bf16* s0, int sb0, char* t1, const bf16* s1, int sb1) {
     const __amdgpu_buffer_rsrc_t rs0 = mk_rsrc(s0, tile_window<HD>(T, sb0)), rs1 = mk_rsrc(s1, tile_window<HD>(T, sb1));
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int pp = 9 * wave + j;              // 72 pieces of 1 KiB: 36 per tile (256 rows x 9 chunks / 64 lanes)
+    for (int j = 0; j < 72 / NWV; ++j) {
+      const int pp = (72 / NWV) * wave + j;     // 72 pieces of 1 KiB: 36 per tile (256 rows x 9 chunks / 64 lanes)
       const bool second = pp >= 36;
       const int I = second ? pp - 36 : pp;
       const int vo = dma_voff<HD, ROWB>(I * 64 + lane, second ? sb1 : sb0);
@@ -664,12 +667,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
     }
   };
   issue_pair(Kt, base + D, (int)(tok * 2), Vt, base + 2 * D, (int)(tok * 2));
-  bf16x8 qf[2][KS], gf[2][KS], of[2][KS];
-  float lq[2], dq_[2];
+  bf16x8 qf[QT][KS], gf[QT][KS], of[QT][KS];
+  float lq[QT], dq_[QT];
   // every register load of the wave's own rows is issued before anything consumes one, and the Q / dO pieces behind them:
   // the compiler's wait for the fragments is then a counted vmcnt(9), not a drain per use
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int row = r0 + 16 * qt + i;
     const bool ok = row < T;
 #pragma unroll
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   }
   issue_pair(Qt, base, (int)(tok * 2), Gt, gbase, D * 2);
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float acc = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -695,18 +698,19 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   }
   if (g == 0) {   // phase 2 reads the 256 deltas and log-sum-exps from LDS: every wave contributes its 32 rows
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) { dlt[r0 + 16 * qt + i] = dq_[qt]; lse2[r0 + 16 * qt + i] = lq[qt]; }
+    for (int qt = 0; qt < QT; ++qt) { dlt[r0 + 16 * qt + i] = dq_[qt]; lse2[r0 + 16 * qt + i] = lq[qt]; }
   }
-  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // K, V (and the register loads) landed; younger: the 9 Q / dO pieces
+  if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // K, V (and the register loads) landed;
+  else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                       // younger: the wave's Q / dO pieces
   ATTN_BARRIER();
 
-  f32x4 dq[2][DT];
+  f32x4 dq[QT][DT];
   // A wave's 32 finished rows leave through LDS: the MFMA layout gives a lane 4 consecutive columns of one row, i.e. a
   // wave-level store of sixteen 32-byte pieces — the pattern that cost the GEMM epilogues their HBM time.
   // Staged in the wave's OWN 32 rows of the K / V tiles (dead once phase 2 has its key fragments in registers, see the
   // barrier below) they go out as whole 144-byte row pieces, 16 bytes per lane.
   auto store_rows = [&](const char* tile, bf16* gbase) {
-    constexpr int NQ = 32 * NCH;
+    constexpr int NQ = WR * NCH;
 #pragma unroll
     for (int k = 0; k < (NQ + 63) / 64; ++k) {
       const int qi = lane + 64 * k;
@@ -718,15 +722,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   if (r0 < T) {
     // ---------------- phase 1: dQ for queries [r0, r0+32) ----------------
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = zero4();
     const int nblk = (T + 31) >> 5;
     for (int kb = 0; kb < nblk; ++kb) {
       const int kv0 = kb * 32;
-      f32x4 st[2][2], dp[2][2];
+      f32x4 st[QT][2], dp[QT][2];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) { st[qt][kt] = zero4(); dp[qt][kt] = zero4(); }
 #pragma unroll
@@ -735,14 +739,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         for (int ks = 0; ks < KS; ++ks) {
           bf16x8 kf = frag_rows(Kt, kv0 + 16 * kt, ks, lane);
           bf16x8 vf = frag_rows(Vt, kv0 + 16 * kt, ks, lane);
-          st[0][kt] = MFMA(kf, qf[0][ks], st[0][kt]);
-          st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
-          dp[0][kt] = MFMA(vf, gf[0][ks], dp[0][kt]);
-          dp[1][kt] = MFMA(vf, gf[1][ks], dp[1][kt]);
-        }
-      bf16x8 dsb[2];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+          for (int qt = 0; qt < QT; ++qt) {
+            st[qt][kt] = MFMA(kf, qf[qt][ks], st[qt][kt]);
+            dp[qt][kt] = MFMA(vf, gf[qt][ks], dp[qt][kt]);
+          }
+        }
+      bf16x8 dsb[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
       if (kv0 + 32 > T) {   // keys past T exist only in a ragged last key block
         asm volatile("; ragged key block" ::);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
               if (kv0 + 16 * kt + 4 * g + r >= T) st[qt][kt][r] = 0.f;
       }
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) dsb[qt] = pack2(st[qt][0], st[qt][1]);
+      for (int qt = 0; qt < QT; ++qt) dsb[qt] = pack2(st[qt][0], st[qt][1]);
       {
         // (asm reads: with the builtin the compiler would drain the Q / dO pieces still in flight before every read)
         bf16x8 ktf[DT];
@@ -771,8 +776,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         ATTN_LDS_WAIT();
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          dq[0][dt] = MFMA(ktf[dt], dsb[0], dq[0][dt]);
-          dq[1][dt] = MFMA(ktf[dt], dsb[1], dq[1][dt]);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) dq[qt][dt] = MFMA(ktf[dt], dsb[qt], dq[qt][dt]);
         }
       }
     }
@@ -781,9 +786,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
   __syncthreads();   // phase 1 (every wave reads all of K and V) is over: rows [r0, r0+32) of Kt / Vt are this wave's alone
   if (r0 < T) {
     // ---------------- phase 2: dK, dV for keys [r0, r0+32) ----------------
-    bf16x8 kf[2][KS], vf[2][KS];
+    bf16x8 kf[QT][KS], vf[QT][KS];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < QT; ++ct)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
       }
     // dQ of phase 1 leaves now, staged in the K rows whose fragments were just taken; its stores drain under phase 2
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int d = 16 * dt + 4 * g;
@@ -803,29 +808,30 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         }
       }
     store_rows(Kt, dbase);
-    f32x4 dk[2][DT], dv[2][DT];
+    f32x4 dk[QT][DT], dv[QT][DT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < QT; ++ct)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
     const int nblk = (T + 31) >> 5;
     for (int qb = 0; qb < nblk; ++qb) {
       const int qq0 = qb * 32;
-      f32x4 st[2][2], dp[2][2];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
+      f32x4 st[2][QT], dp[2][QT];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
+        for (int ct = 0; ct < QT; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           bf16x8 qa = frag_rows(Qt, qq0 + 16 * qt, ks, lane);
           bf16x8 ga = frag_rows(Gt, qq0 + 16 * qt, ks, lane);
-          st[qt][0] = MFMA(qa, kf[0][ks], st[qt][0]);
-          st[qt][1] = MFMA(qa, kf[1][ks], st[qt][1]);
-          dp[qt][0] = MFMA(ga, vf[0][ks], dp[qt][0]);
-          dp[qt][1] = MFMA(ga, vf[1][ks], dp[qt][1]);
+#pragma unroll
+          for (int ct = 0; ct < QT; ++ct) {
+            st[qt][ct] = MFMA(qa, kf[ct][ks], st[qt][ct]);
+            dp[qt][ct] = MFMA(ga, vf[ct][ks], dp[qt][ct]);
+          }
         }
       f32x4 lq4[2], dl4[2];
 #pragma unroll
@@ -833,9 +839,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
         lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
         dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
       }
-      bf16x8 pb[2], dsb[2];
+      bf16x8 pb[QT], dsb[QT];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < QT; ++ct) {
         f32x4 p0, p1, s0, s1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -851,14 +857,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16* __restrict__ 
       for (int dt = 0; dt < DT; ++dt) {
         bf16x8 gtf = frag_trT(Gt, qq0, 16 * dt, lane);
         bf16x8 qtf = frag_trT(Qt, qq0, 16 * dt, lane);
-        dv[0][dt] = MFMA(gtf, pb[0], dv[0][dt]);
-        dv[1][dt] = MFMA(gtf, pb[1], dv[1][dt]);
-        dk[0][dt] = MFMA(qtf, dsb[0], dk[0][dt]);
-        dk[1][dt] = MFMA(qtf, dsb[1], dk[1][dt]);
+#pragma unroll
+        for (int ct = 0; ct < QT; ++ct) {
+          dv[ct][dt] = MFMA(gtf, pb[ct], dv[ct][dt]);
+          dk[ct][dt] = MFMA(qtf, dsb[ct], dk[ct][dt]);
+        }
       }
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < QT; ++ct)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int d = 16 * dt + 4 * g;
@@ -948,15 +955,21 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
   REED_CHECK_ARG(T > 0 && T <= 256, "attention_bwd: T=%d unsupported (training path is T <= 256)", T);
   const int lds = 4 * TILE_B + 256 + 2048;
   dim3 grid(B * H);
-  if (hd == 64) {
-    static int once = set_lds(attn_bwd_kernel<64>, lds);
+  static const bool w4 = getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1;   // experiment: 4 waves x 64 rows
+  if (w4 && hd == 72) {
+    static int once = set_lds(attn_bwd_kernel<72, 4>, lds);
     if (once) return once;
-    REED_KLAUNCH(attn_bwd_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+    REED_KLAUNCH((attn_bwd_kernel<72, 4>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+                 (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+  } else if (hd == 64) {
+    static int once = set_lds(attn_bwd_kernel<64, 2>, lds);
+    if (once) return once;
+    REED_KLAUNCH((attn_bwd_kernel<64, 2>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
                  (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   } else {
-    static int once = set_lds(attn_bwd_kernel<72>, lds);
+    static int once = set_lds(attn_bwd_kernel<72, 2>, lds);
     if (once) return once;
-    REED_KLAUNCH(attn_bwd_kernel<72>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+    REED_KLAUNCH((attn_bwd_kernel<72, 2>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
                  (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   }
   REED_LAUNCH_CHECK();
