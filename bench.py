@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--model", type=str, default="SiT-XL/2")
     ap.add_argument("--z-dim", type=int, default=1024)
+    ap.add_argument("--mixed-precision", choices=["bf16", "fp16"], default="bf16",
+                    help="operand type of the step (BASELINE's configuration is bf16; fp16 = the reference CLI's default, IEEE-half "
+                         "operands with dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     return ap.parse_args()
@@ -233,6 +236,7 @@ def main():
     b = shard_batch(args.global_batch, world)
     torch.manual_seed(rank_seed(0, rank))
     model = SiT_models[args.model](z_dims=[args.z_dim], z_types=["i"], encoder_depth=8).to(dev).train()
+    model.precision = args.mixed_precision
     random_fill(model, 1234)  # identical on every rank (same seed); broadcast below anyway
     ema = copy.deepcopy(model).requires_grad_(False).eval()
     opt = FusedAdamWEMA(model, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
@@ -336,7 +340,7 @@ def main():
         out = {
             "metric": "SiT-XL/2 ImageNet-256 train images/sec", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.mixed_precision == "bf16" else "f16",
             "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)",
             "config": {"workload": f"C{'2' if world == 1 else '3'}: {args.model} + {args.z_dim}-d alignment projector (REED loss), "
                                    f"global batch {args.global_batch} (b={b}/GPU), full train step "
