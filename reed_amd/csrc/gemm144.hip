@@ -458,6 +458,7 @@ bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits) {
 }
 
 int reed_num_cus();   // gemm256.hip
+double reed_gemm256_rate();
 
 // Kernel selection against the 256^2 / 128^2 kernels, in gemm256.hip's units (one CU x one 128^2 tile; 256^2 tile = 4 /
 // 1.18).  A 256x144 tile is 0.5625 of a 256^2 tile; with the loader waves its main loop runs at the chip's dense-MFMA
@@ -481,7 +482,7 @@ bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits) 
     if (w >= 2.0 * ncu) r256 = ceil(2.0 * w / ncu) / 2.0;
   }
   const double c144 = (double)((t144 + ncu - 1) / ncu) * 2.25 / eta;
-  const double c256 = r256 * 4.0 / 1.18;
+  const double c256 = r256 * 4.0 / reed_gemm256_rate();
   const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
   return c144 < c256 && c144 < c128;
 }

@@ -405,6 +405,12 @@ extern "C" int reed_planning_cus(void) { return reed_num_cus(); }
 //   t256 = ceil(tiles256 / CUs) * 4 / 1.18        t128 = ceil(tiles128 / (2 CUs)) * 2
 // TN (wgrad) stays on the 128^2 kernel with wave-quantised split-K (ops.plan_wgrad); its 256^2 variant is reachable
 // through reed_gemm_force_tile only.
+// speed of the 256^2 kernel per flop relative to the 128^2 one in the round-count models (REED_GEMM256_RATE: experiments)
+double reed_gemm256_rate() {
+  static const double r = getenv("REED_GEMM256_RATE") ? atof(getenv("REED_GEMM256_RATE")) : 1.18;
+  return r;
+}
+
 bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits) {
   if (layout == LAY_TN || splits > 1 || a.K < 256) return false;
   const int ncu = reed_num_cus();
@@ -423,7 +429,7 @@ bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits) 
     rounds256 = (double)((tm * tn + ncu - 1) / ncu);
   }
   const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-  const double c256 = rounds256 * 4.0 / 1.18;
+  const double c256 = rounds256 * 4.0 / reed_gemm256_rate();
   const double c128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * 2.0;
   return c256 < c128;
 }
