@@ -370,6 +370,19 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
 }
 
+// Tile rows per XCD-local group of the workgroup -> tile map (as gemm256.hip; REED_GEMM256_GM overrides for A/B timing).
+// Measured at b = 256 (tools/_ab/gm_w4.sh): the 1152-wide outputs (4.5 column tiles) prefer groups of 2 rows — fc2 forward
+// 0.637 -> 0.618 ms, fc1 / qkv dgrads 0.564 -> 0.546 / 0.430 -> 0.417 —, the 3456- / 4608-wide ones groups of 4 (fc1 forward
+// 0.684 vs 0.720 with 2).
+int w_tile_group_rows(const GemmArgs& a) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("REED_GEMM256_GM"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced;
+  if (cdiv(a.M, WBM) < 192) return 4;   // b = 128: 1157 (4 everywhere) vs 1151 images/s with the per-shape choice
+  const int ntn = cdiv(a.N, WBN);
+  return ntn <= 6 ? 2 : ntn >= 16 ? 5 : 4;   // (4608-wide: fc1 forward 0.688 -> 0.675, fc2 dgrad 0.727 -> 0.721 with 5)
+}
+
 template <int LAY, int EPI>
 int launch256w(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
@@ -381,7 +394,7 @@ int launch256w(const GemmArgs& a, hipStream_t stream) {
   }
   dim3 grid(cdiv(a.M, WBM) * cdiv(a.N, WBN), 1, 1);
   GemmArgs b = a;
-  b.tile_gm = 4;
+  b.tile_gm = w_tile_group_rows(a);
   REED_KLAUNCH((gemm256w_kernel<LAY, EPI>), grid, dim3(256), LDS_W, stream, b);
   REED_LAUNCH_CHECK();
   return REED_OK;
