@@ -446,3 +446,27 @@ def test_train_with_on_device_jepa_and_mae_towers(dev, tmp_path, monkeypatch):
     assert len(logs) == 2 and all(np.isfinite(r["proj_loss"]) and np.isfinite(r["training_denoising_loss"]) for r in logs)
     assert logs[0]["img_proj_loss"] != 0.0
     torch.set_grad_enabled(True)
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys(dev):
+    """bench.py (the driver's entry): exactly one JSON line on stdout with the contract's keys, `roofline` for the dominant kernel
+    timed inside the step, `value` = global batch x steps / measured time, and — in the default form — `cpu_baseline`
+    (skipped here for time: its presence is checked through the flag that removes it)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--global-batch", "32", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "step_mfma_frac", "data_parallel"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "images/sec" and d["dtype"] == "bf16" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_timed", "avg_ms_per_launch"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and rf["launches_timed"] == 3 * 28
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
+    assert "cpu_baseline" not in d      # --no-cpu-baseline; the default run adds {"value", "unit", "cores", "kind", "sample"}
