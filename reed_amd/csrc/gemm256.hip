@@ -354,23 +354,31 @@ int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
 
 template <int LAY>
 int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
-  switch (epi) {
-    case EPI_BF16: return launch256<LAY, EPI_BF16>(a, splits, s);
-    case EPI_GELU: return launch256<LAY, EPI_GELU>(a, splits, s);
-    case EPI_SILU: return launch256<LAY, EPI_SILU>(a, splits, s);
-    case EPI_GATE_RES: return launch256<LAY, EPI_GATE_RES>(a, splits, s);
-    case EPI_DGELU: return launch256<LAY, EPI_DGELU>(a, splits, s);
-    case EPI_DSILU: return launch256<LAY, EPI_DSILU>(a, splits, s);
-    case EPI_F32: return launch256<LAY, EPI_F32>(a, splits, s);
-    case EPI_ADDF32_RB: return launch256<LAY, EPI_ADDF32_RB>(a, splits, s);
-    case EPI_ATOMIC_F32: return launch256<LAY, EPI_ATOMIC_F32>(a, splits, s);
-    case EPI_QGELU: return launch256<LAY, EPI_QGELU>(a, splits, s);
-    case EPI_RES_BF16: return launch256<LAY, EPI_RES_BF16>(a, splits, s);
-    case EPI_LS_RES:
-      if constexpr (LAY == LAY_NT) return launch256<LAY, EPI_LS_RES>(a, splits, s);
-      break;
+  if constexpr (LAY == LAY_TN) {   // weight gradients: fp32 outputs only (the bf16-output epilogues are never launched on TN)
+    switch (epi) {
+      case EPI_F32: return launch256<LAY, EPI_F32>(a, splits, s);
+      case EPI_ADDF32_RB: return launch256<LAY, EPI_ADDF32_RB>(a, splits, s);
+      case EPI_ATOMIC_F32: return launch256<LAY, EPI_ATOMIC_F32>(a, splits, s);
+    }
+  } else {
+    switch (epi) {
+      case EPI_BF16: return launch256<LAY, EPI_BF16>(a, splits, s);
+      case EPI_GELU: return launch256<LAY, EPI_GELU>(a, splits, s);
+      case EPI_SILU: return launch256<LAY, EPI_SILU>(a, splits, s);
+      case EPI_GATE_RES: return launch256<LAY, EPI_GATE_RES>(a, splits, s);
+      case EPI_DGELU: return launch256<LAY, EPI_DGELU>(a, splits, s);
+      case EPI_DSILU: return launch256<LAY, EPI_DSILU>(a, splits, s);
+      case EPI_F32: return launch256<LAY, EPI_F32>(a, splits, s);
+      case EPI_ADDF32_RB: return launch256<LAY, EPI_ADDF32_RB>(a, splits, s);
+      case EPI_ATOMIC_F32: return launch256<LAY, EPI_ATOMIC_F32>(a, splits, s);
+      case EPI_QGELU: return launch256<LAY, EPI_QGELU>(a, splits, s);
+      case EPI_RES_BF16: return launch256<LAY, EPI_RES_BF16>(a, splits, s);
+      case EPI_LS_RES:
+        if constexpr (LAY == LAY_NT) return launch256<LAY, EPI_LS_RES>(a, splits, s);
+        break;
+    }
   }
-  reed_set_error("reed_gemm: unknown epilogue %d", epi);
+  reed_set_error("reed_gemm(256^2): epilogue %d is not built for layout %d", epi, LAY);
   return REED_ERR_ARG;
 }
 
