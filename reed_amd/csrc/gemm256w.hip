@@ -21,6 +21,14 @@
 
 #include "gemm_common.hpp"
 
+#ifdef REED_CLK_PROBE
+// diagnostic build only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, read by tools/clk_probe.py): shader-clock and
+// 100 MHz stamps around the K loop of every workgroup; the product build has no stamp
+__device__ unsigned long long reed_clk_buf[8 * 8192];
+extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(reed_clk_buf), sizeof(unsigned long long) * n);
+}
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -255,6 +263,10 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #pragma unroll
     for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
   }
+#ifdef REED_CLK_PROBE
+  unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   int t = 0;
   for (; t + 3 < nt; t += 2) {
     WKTILE(t, 0, true);
@@ -268,6 +280,20 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 
   // the MFMAs are inline asm: the compiler does not know the accumulators were just written by the matrix pipe
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef REED_CLK_PROBE
+  {
+    unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (tid == 0 && blockIdx.x < 8192) {
+      reed_clk_buf[8 * blockIdx.x + 0] = ck1 - ck0;
+      reed_clk_buf[8 * blockIdx.x + 1] = cr1 - cr0;
+      reed_clk_buf[8 * blockIdx.x + 2] = nt;
+      reed_clk_buf[8 * blockIdx.x + 3] = MODE;
+      reed_clk_buf[8 * blockIdx.x + 4] = cr0;   // K loop start / end on the 100 MHz clock (the kernel stamps entry and exit)
+      reed_clk_buf[8 * blockIdx.x + 5] = cr1;
+    }
+  }
+#endif
   // epilogue: the wave's piece in 64-column groups through gemm_common.hpp's tile_epilogue (fp32 outputs: its pointer path)
   char* stage = smem + 8 * HTW + wave * EPI_STAGE_BYTES;
 #pragma unroll
@@ -319,8 +345,28 @@ __global__ __launch_bounds__(256, 1) void gemm256w_kernel(GemmArgs a) {
     tm = first_m + (bid % per_group) % gs;
     tn = (bid % per_group) / gs;
   }
+  // (Tried: all full tiles first, then the half-width tiles of a ragged last column as one short round, to remove the tail a
+  // mixed list leaves — simulated 9 % for fc2 forward. Measured WORSE, fc2 forward 0.621 -> 0.700 ms, fc1 dgrad 0.55 -> 0.60:
+  // the 256 ragged tiles then stream the whole A operand again with no full tile of their rows beside them in L2.)
+#ifdef REED_CLK_PROBE
+  const unsigned long long en0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   if (a.N - tn * WBN <= 128) gemm256w_body<LAY, EPI, 1>(a, smem, tm, tn);
   else gemm256w_body<LAY, EPI, 0>(a, smem, tm, tn);
+#ifdef REED_CLK_PROBE
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the wave
+    const unsigned long long en1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+      // physical CU: HW_ID (se_id[15:13] sh_id[12] cu_id[11:8]) and XCC_ID[3:0]
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      reed_clk_buf[8 * blockIdx.x + 6] = en0;
+      reed_clk_buf[8 * blockIdx.x + 7] = (en1 << 16) | ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
+    }
+  }
+#endif
 }
 
 // ---- the weight gradients of one transformer block in one launch: 256^2 tiles of all (<= 4) problems, one per CU ----------

@@ -49,6 +49,8 @@ class Engine:
                           for zt in model.z_types]
         self.reducer = None      # set by reed_amd.parallel.GradReducer
         self._ws = None
+        self._named = None       # [(name, parameter)] and the first trainable parameter, cached for backward
+        self._sentinel = None
         self._ws_side = None
         self.split_ada_wgrad = None   # None: per-block adaLN weight gradients iff a reducer is attached (see backward)
         self._side = None        # second HIP stream: the blocks' weight-gradient GEMMs run beside the dgrad chain
@@ -611,7 +613,9 @@ class Engine:
     def _attach_grads(self):
         """Expose the grad arena through param.grad (views), for torch.optim / clip_grad_norm_ compatibility."""
         g = self.A.grad
-        for name, p in self.m.named_parameters():
+        if self._named is None:   # named_parameters() walks the module tree (1 ms per call on SiT-XL/2): once
+            self._named = [(name, p) for name, p in self.m.named_parameters()]
+        for name, p in self._named:
             if p.requires_grad and p.grad is None:
                 p.grad = self.A.view(g, name)
 
@@ -639,8 +643,9 @@ class _SiTFunction(torch.autograd.Function):
         if dout is None:
             dout = torch.zeros_like(tape.x)
         # the user may have dropped p.grad (zero_grad(set_to_none=True)) -> overwrite semantics
-        sentinel = next(p for p in eng.m.parameters() if p.requires_grad)
-        if sentinel.grad is None:
+        if eng._sentinel is None:
+            eng._sentinel = next(p for p in eng.m.parameters() if p.requires_grad)
+        if eng._sentinel.grad is None:
             eng.grad_live = False
         eng.backward(tape, dout, list(dzs) if ctx.nz else None)
         return (None,) * 7

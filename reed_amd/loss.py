@@ -17,6 +17,17 @@ from . import ops
 IMAGE_ENCODERS = ["dinov2", "mocov3", "clip", "mae", "jepa"]
 
 
+def _to_device_async(t, device):
+    """fp32 copy of `t` on `device` without stalling the host.  The reference draws the time steps with the HOST generator
+    (loss.py:159-170) and so do we — but a pageable host-to-device copy blocks the host until the stream has drained, i.e. one
+    full host/GPU synchronisation per training step (measured: the forward then starts with an empty queue every step and is
+    enqueue-bound at b <= 64).  Through pinned staging memory (torch's caching host allocator) the copy is asynchronous."""
+    t = t.to(torch.float32)
+    if t.device.type == "cpu":
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 def mean_flat(x):
     return torch.mean(x, dim=list(range(1, len(x.size()))))
 
@@ -138,12 +149,12 @@ class SILoss:
                 time_input = sigma / (1 + sigma) if self.path_type == "linear" else 2 / np.pi * torch.atan(sigma)
             else:
                 raise ValueError(self.weighting)
-        time_input = time_input.reshape(B, 1, 1, 1).to(device=images.device, dtype=torch.float32)
+        time_input = _to_device_async(time_input.reshape(B, 1, 1, 1), images.device)
         noises = kwargs.get("noises")
         images = images.contiguous().float()
         if noises is None:
             noises = torch.randn_like(images)
-        noises = noises.to(images.device).contiguous().float()
+        noises = _to_device_async(noises, images.device).contiguous()
 
         model_input = torch.empty_like(images)
         model_target = torch.empty_like(images)

@@ -27,7 +27,9 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw hipStream_t of torch's current stream: the C entry point, not torch.cuda.current_stream() (which builds a
+    # Stream object through several Python layers: ~8 us x 500 launches per step of host time)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 # Which build of the library the calls go to: "bf16" (libreed_hip.so) or "fp16" (libreed_hip_f16.so, the same sources with

@@ -1,0 +1,7 @@
+cd /root/repo
+for rep in 1 2; do
+for lib in "" tools/_ab/libreed_epi1.so; do
+  echo "== lib=${lib:-current}"
+  REED_HIP_LIB=$lib timeout -k 10 200 python tools/gemm_table.py 256 20 || exit 1
+done
+done
