@@ -35,6 +35,8 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // 256 AGPRs live as accumulators (csrc/gemm256w.hip) then gets part of them shuffled through VGPRs around every MFMA.
 // The asm is opaque to the hazard recognizer: no two consecutive uses of one accumulator, and s_nop before reading it back.
 #define REED_MFMA_ACC(acc, a, b) asm volatile(REED_MFMA_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+// first MFMA of an accumulation: C = 0 as the inline constant (no zeroing pass over the accumulation registers)
+#define REED_MFMA_ACC_Z(acc, a, b) asm volatile(REED_MFMA_MNEMONIC " %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
 // the same with the accumulator in VGPRs, for operands the compiler may have just (re)materialised with VALU moves — e.g. a
 // fragment of ones: the matrix pipe reads its sources too early for a VALU write in the previous cycles (measured: stale
 // reads), and the hazard recognizer does not look into asm — hence the wait states in front

@@ -19,7 +19,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "gemm_common.hpp"
+
+int reed_num_cus();   // gemm256.hip
 
 #ifdef REED_CLK_PROBE
 // diagnostic build only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, read by tools/clk_probe.py): shader-clock and
@@ -62,8 +67,13 @@ __device__ __forceinline__ bf16x8 wtr2(const char* a0, const char* a1) {
 //   MODE 2  128 x 256: A half-tile 0 (8 tiles) x B half-tile wave>>1, 64-column quarter wave&1 (4 tiles)   32
 //   MODE 3  128 x 128: A half-tile 0 quarter wave>>1 (4) x B half-tile 0 quarter wave&1 (4)                16
 // and the half-tiles that do not exist are not staged.
-template <int LAY, int EPI, int MODE>
-__device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, const int tm, const int tn) {
+// PM = 1: the persistent form (gemm256wp_kernel): the workgroup walks a list of tiles; `first` = this is its first tile (it
+// stages its own first two K-tiles), otherwise they were staged by the previous tile's last two K-tiles; nx_mode >= 0: a
+// next tile (nx_tm, nx_tn) of MODE nx_mode (0 / 1) follows, and this tile's last two K-tiles stage ITS first two.
+template <int LAY, int EPI, int MODE, int PM = 0>
+__device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, const int tm, const int tn,
+                                              const bool first = true, const int nx_mode = -1, const int nx_tm = 0,
+                                              const int nx_tn = 0) {
   constexpr bool RN = (MODE & 1) != 0, RM = (MODE & 2) != 0;
   constexpr int NA = RN ? 4 : 8;              // 16-row tiles per wave
   constexpr int NB = RM ? 4 : 8;              // 16-column tiles per wave
@@ -108,6 +118,39 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       char* ht = smem + wslotB(hb, cur);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vB0,
                                                t * kstepB + hb * halfB + i * rsB, 0, 0);
+    }
+  };
+
+  // the next tile's first two K-tiles (PM): its own descriptors, its own list of half-tiles (MODE NM: A0 A1 B0 [B1])
+  __amdgpu_buffer_rsrc_t rsPn = rsP, rsQn = rsQ;
+  if constexpr (PM != 0) {
+    if (nx_mode >= 0) {
+      const int m0n = nx_tm * WBM, n0n = nx_tn * WBN;
+      if constexpr (A_TR) rsPn = make_rsrc(a.P + m0n, ((long)a.K * a.ldp - m0n) * 2);
+      else rsPn = make_rsrc(a.P + (long)m0n * a.ldp, ((long)(a.M - m0n) * a.ldp) * 2);
+      if constexpr (B_TR) rsQn = make_rsrc(a.Q + n0n, ((long)a.K * a.ldq - n0n) * 2);
+      else rsQn = make_rsrc(a.Q + (long)n0n * a.ldq, ((long)(a.N - n0n) * a.ldq) * 2);
+    }
+  }
+  // always the full list A0 A1 B0 B1: for a ragged next tile the B1 pieces read beyond its columns (zeros from the range check
+  // or the next row's first columns: staged, never read) — one form of the tail instead of one per next-tile MODE keeps the
+  // control flow, and with it the allocation of the 256 accumulation registers, as simple as the one-shot kernel's
+  auto dmas_next = [&](int kt, int cur, int c) {
+    constexpr int NDN = 16;
+#pragma unroll
+    for (int e = 0; e < NDN; ++e) {
+      if (e * NCH / NDN != c) continue;
+      const int hh = e >> 2, i = e & 3;
+      if (hh < 2) {
+        char* ht = smem + wslotA(hh, cur);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsPn, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vA0,
+                                                 kt * kstepA + hh * halfA + i * rsA, 0, 0);
+      } else {
+        const int hb = hh - 2;
+        char* ht = smem + wslotB(hb, cur);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQn, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vB0,
+                                                 kt * kstepB + hb * halfB + i * rsB, 0, 0);
+      }
     }
   };
 
@@ -174,10 +217,12 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   };
 
   f32x4 acc[NA][NB];
+  if constexpr (PM == 0) {   // (PM: the first k-step's MFMAs take C = 0 — a zeroing pass here is loop-invariant in the
+#pragma unroll               //  persistent kernel's tile loop and the compiler hoists it into 256 live VGPRs)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-  for (int i = 0; i < NA; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // TN: bias gradient dbias[m] = sum_k P[k][m] as one more MFMA per row tile against a fragment of ones, in the waves that
   // own the tile's first columns of the first column tile; these accumulators live in VGPRs (the AGPRs are full)
   f32x4 accb[LAY == LAY_TN ? NA : 1];
@@ -194,21 +239,27 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   // chunk c = 4 MFMAs: row tile CI(c), column tiles CJ(c) .. + 3
 #define W_CI(c) (NB == 8 ? ((c) >> 1) : (c))
 #define W_CJ(c) (NB == 8 ? (((c) & 1) * 4) : 0)
-#define WMMA4(KS, C)                                                                                     \
-  _Pragma("unroll") for (int j = W_CJ(C); j < W_CJ(C) + 4; ++j)                                          \
-      REED_MFMA_ACC(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);                                    \
+#define WMMA4(KS, C, Z)                                                                                  \
+  _Pragma("unroll") for (int j = W_CJ(C); j < W_CJ(C) + 4; ++j) {                                        \
+    if constexpr ((Z) != 0) REED_MFMA_ACC_Z(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);            \
+    else REED_MFMA_ACC(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);                                 \
+  }                                                                                                      \
   if constexpr (LAY == LAY_TN) {                                                                         \
     if (W_CJ(C) == 0 && do_dbias) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]);               \
   }
 
   // One phase = NCH chunks of {fragment reads for the NEXT phase, [DMAs of K-tile DMA_T], 4 MFMAs of k-step KS}: a single
   // wave feeds the matrix pipe, so everything else is issued in the shadow of the 4 x 16 clk a chunk's MFMAs take.
-#define WPHASE(KS, LD_CUR, LD_KS, DMA_ON, DMA_T, DMA_CUR)                            \
+// KIND 0: the DMAs are this tile's K-tile DMA_T; 1: the NEXT tile's K-tile DMA_T (PM)
+#define WPHASE(KS, LD_CUR, LD_KS, DMA_ON, DMA_T, DMA_CUR, KIND, Z)                   \
   do {                                                                               \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                \
       ldfrag((LD_CUR), (LD_KS), c);                                                  \
-      if (DMA_ON) dmas((DMA_T), (DMA_CUR), c);                                       \
-      WMMA4(KS, c);                                                                  \
+      if (DMA_ON) {                                                                  \
+        if constexpr ((KIND) == 0) dmas((DMA_T), (DMA_CUR), c);                      \
+        else dmas_next((DMA_T), (DMA_CUR), c);                                       \
+      }                                                                              \
+      WMMA4(KS, c, Z);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                             \
     }                                                                                \
   } while (0)
@@ -230,24 +281,32 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   } while (0)
 
   // PF: K-tile t+2 exists (literal true in the steady-state loop: no branch around the DMAs)
-#define WKTILE(T, CUR, PF)                                                                 \
+#define WKTILE(T, CUR, PF, KIND, KT) WKTILE_(T, CUR, PF, KIND, KT, 0)
+#define WKTILE_(T, CUR, PF, KIND, KT, Z)                                                    \
   do {                                                                                     \
     const int t_ = (T);                                                                    \
     asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));     \
     /* phase A: MFMAs of (t, ks0); reads of (t, ks1) */                                    \
     WLGKM0();                                                                              \
-    WPHASE(0, (CUR), 1, false, 0, 0);                                                      \
+    WPHASE(0, (CUR), 1, false, 0, 0, 0, Z);                                                \
     /* phase B: K-tile t+1 landed, every wave done with K-tile t; MFMAs of (t, ks1); reads of (t+1, ks0); DMAs of t+2 */ \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
     WLGKM0();                                                                              \
     WBARRIER();                                                                            \
     {                                                                                      \
       const bool pf_ = (PF);                                                               \
-      WPHASE(1, 1 - (CUR), 0, pf_, t_ + 2, (CUR));                                         \
+      WPHASE(1, 1 - (CUR), 0, pf_, ((KIND) == 0 ? t_ + 2 : (KT)), (CUR), KIND, 0);         \
     }                                                                                      \
   } while (0)
 
-  if (nt > 0) {
+  if (PM != 0 && !first) {
+    // the previous tile staged K-tiles 0 and 1 beside its last two K-tiles; its epilogue's stores are younger than those
+    // DMAs and counted in the same vmcnt (more than the 63 a counted wait can leave outstanding for the fused epilogues)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WBARRIER();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
+  } else if (nt > 0) {
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma(0, 0, d);
     if (nt > 1) {
@@ -268,15 +327,28 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
   int t = 0;
+  if constexpr (PM != 0) {   // nt >= 4 (the host checked): K-tile 0's first k-step starts the accumulation
+    WKTILE_(0, 0, true, 0, 0, 1);
+    WKTILE(1, 1, true, 0, 0);
+    t = 2;
+  }
   for (; t + 3 < nt; t += 2) {
-    WKTILE(t, 0, true);
-    WKTILE(t + 1, 1, true);
+    WKTILE(t, 0, true, 0, 0);
+    WKTILE(t + 1, 1, true, 0, 0);
   }
-  for (; t + 1 < nt; t += 2) {
-    WKTILE(t, 0, t_ + 2 < nt);
-    WKTILE(t + 1, 1, t_ + 2 < nt);
+  if constexpr (PM != 0) {   // nt is even (the host checked): the last two K-tiles stage the next tile's first two
+    const bool has_next = nx_mode >= 0;
+    for (; t + 1 < nt; t += 2) {
+      WKTILE(t, 0, has_next, 1, 0);
+      WKTILE(t + 1, 1, has_next, 1, 1);
+    }
+  } else {
+    for (; t + 1 < nt; t += 2) {
+      WKTILE(t, 0, t_ + 2 < nt, 0, 0);
+      WKTILE(t + 1, 1, t_ + 2 < nt, 0, 0);
+    }
+    if (t < nt) WKTILE(t, 0, false, 0, 0);
   }
-  if (t < nt) WKTILE(t, 0, false);
 
   // the MFMAs are inline asm: the compiler does not know the accumulators were just written by the matrix pipe
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -284,13 +356,14 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   {
     unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (tid == 0 && blockIdx.x < 8192) {
-      reed_clk_buf[8 * blockIdx.x + 0] = ck1 - ck0;
-      reed_clk_buf[8 * blockIdx.x + 1] = cr1 - cr0;
-      reed_clk_buf[8 * blockIdx.x + 2] = nt;
-      reed_clk_buf[8 * blockIdx.x + 3] = MODE;
-      reed_clk_buf[8 * blockIdx.x + 4] = cr0;   // K loop start / end on the 100 MHz clock (the kernel stamps entry and exit)
-      reed_clk_buf[8 * blockIdx.x + 5] = cr1;
+    const int pidx = tm * ((a.N + WBN - 1) / WBN) + tn;   // one record per tile
+    if (tid == 0 && pidx < 8192) {
+      reed_clk_buf[8 * pidx + 0] = ck1 - ck0;
+      reed_clk_buf[8 * pidx + 1] = cr1 - cr0;
+      reed_clk_buf[8 * pidx + 2] = nt;
+      reed_clk_buf[8 * pidx + 3] = MODE;
+      reed_clk_buf[8 * pidx + 4] = cr0;   // K loop start / end on the 100 MHz clock (the kernel stamps entry and exit)
+      reed_clk_buf[8 * pidx + 5] = cr1;
     }
   }
 #endif
@@ -324,6 +397,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #undef WBARRIER
 #undef WLGKM0
 #undef WKTILE
+#undef WKTILE_
 }
 
 template <int LAY, int EPI>
@@ -359,14 +433,76 @@ __global__ __launch_bounds__(256, 1) void gemm256w_kernel(GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the wave
     const unsigned long long en1 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    const int pidx = tm * ntn + tn;
+    if (threadIdx.x == 0 && pidx < 8192) {
       // physical CU: HW_ID (se_id[15:13] sh_id[12] cu_id[11:8]) and XCC_ID[3:0]
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-      reed_clk_buf[8 * blockIdx.x + 6] = en0;
-      reed_clk_buf[8 * blockIdx.x + 7] = (en1 << 16) | ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
+      reed_clk_buf[8 * pidx + 6] = en0;
+      reed_clk_buf[8 * pidx + 7] = (en1 << 16) | ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
     }
   }
 #endif
+}
+
+// ---- persistent form: one workgroup per CU walks every (workgroups per XCD)-th tile of its XCD's run ----------------------
+// Why (tools/clk_probe.py, b = 256, K = 1152): a 256^2 tile spends 1.8 us before its K loop (launch, address set-up, the first
+// two K-tiles' DMA round trip), 24.6 us in it, 4.3 us in the epilogue, and the CU then waits 0.6 us for its next workgroup:
+// here the next tile's first two K-tiles are staged beside the last two of the current one, so a tile starts with its
+// operands in LDS.  And the STATIC deal removes the tail a greedy dispatch leaves with ragged tiles: for the 1152-wide
+// outputs (4.5 tile columns) every workgroup gets exactly 4 full tiles + 1 half tile (positions s + 32 k of a run that
+// repeats with period 10: two rows x five columns), where the hardware's greedy hand-out took 5.0-5.1 tile times for
+// 4.5 tiles of work per CU.  The host uses this form only where its static deal is balanced (launch256wp).
+__device__ __forceinline__ void w_tile_of(int b, int ntm, int ntn, int GM, int& tm, int& tn) {
+  const int per_group = GM * ntn;
+  const int group = b / per_group, first_m = group * GM;
+  const int gs = min(ntm - first_m, GM);
+  tm = first_m + (b % per_group) % gs;
+  tn = (b % per_group) / gs;
+}
+template <int LAY, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntm = (a.M + WBM - 1) / WBM, ntn = (a.N + WBN - 1) / WBN;
+  const int nwg = ntm * ntn;
+  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, runlen = q + (xcd < r ? 1 : 0);
+  int p = s;
+  if (p >= runlen) return;
+  int tm, tn;
+  w_tile_of(run0 + p, ntm, ntn, a.tile_gm, tm, tn);
+  bool first = true;
+  for (;;) {
+    const int pn = p + wpx;
+    int nmode = -1, tmn = 0, tnn = 0;
+    if (pn < runlen) {
+      w_tile_of(run0 + pn, ntm, ntn, a.tile_gm, tmn, tnn);
+      nmode = (a.N - tnn * WBN <= 128) ? 1 : 0;
+    }
+#ifdef REED_CLK_PROBE
+    const unsigned long long en0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    if (a.N - tn * WBN <= 128) gemm256w_body<LAY, EPI, 1, 1>(a, smem, tm, tn, first, nmode, tmn, tnn);
+    else gemm256w_body<LAY, EPI, 0, 1>(a, smem, tm, tn, first, nmode, tmn, tnn);
+#ifdef REED_CLK_PROBE
+    {
+      const unsigned long long en1 = __builtin_amdgcn_s_memrealtime();   // stores issued (not waited for, as the kernel runs)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      const int pidx = tm * ntn + tn;
+      if (threadIdx.x == 0 && pidx < 8192) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        reed_clk_buf[8 * pidx + 6] = en0;
+        reed_clk_buf[8 * pidx + 7] = (en1 << 16) | ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);
+      }
+    }
+#endif
+    if (nmode < 0) break;
+    p = pn;
+    tm = tmn;
+    tn = tnn;
+    first = false;
+  }
 }
 
 // ---- the weight gradients of one transformer block in one launch: 256^2 tiles of all (<= 4) problems, one per CU ----------
@@ -429,8 +565,69 @@ int w_tile_group_rows(const GemmArgs& a) {
   return ntn <= 6 ? 2 : ntn >= 16 ? 5 : 4;   // (4608-wide: fc1 forward 0.688 -> 0.675, fc2 dgrad 0.727 -> 0.721 with 5)
 }
 
+// Static deal of the persistent form: the heaviest workgroup's load in full-tile units (a ragged tile counts RAG_COST) when
+// wpx workgroups per XCD take positions s, s + wpx, ... of their XCD's run.
+constexpr double RAG_COST = 0.58;
+double w_static_max_load(int ntm, int ntn, bool rag, int GM, int wpx) {
+  const int nwg = ntm * ntn, q = nwg >> 3, r = nwg & 7;
+  double worst = 0;
+  for (int xcd = 0; xcd < 8; ++xcd) {
+    const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, runlen = q + (xcd < r ? 1 : 0);
+    for (int s = 0; s < wpx && s < runlen; ++s) {
+      double load = 0;
+      for (int p = s; p < runlen; p += wpx) {
+        const int b = run0 + p, per_group = GM * ntn, group = b / per_group, first_m = group * GM;
+        const int gs = std::min(ntm - first_m, GM), tn = (b % per_group) / gs;
+        load += (rag && tn == ntn - 1) ? RAG_COST : 1.0;
+      }
+      worst = std::max(worst, load);
+    }
+  }
+  return worst;
+}
+
+// REED_GEMM_PERSIST: 0 never, 1 where the static deal is balanced (default), 2 wherever the form applies (A/B)
+template <int LAY, int EPI>
+int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("REED_GEMM_PERSIST"); mode = e ? atoi(e) : 1; }
+  *used = false;
+  const int nt = cdiv(a.K, WBK), ntm = cdiv(a.M, WBM), ntn = cdiv(a.N, WBN);
+  const int wpx = reed_num_cus() / 8;
+  if (mode == 0 || (nt & 1) || nt < 4 || wpx < 1 || (a.K % WBK) != 0) return REED_OK;
+  const bool rag = (a.N % WBN) != 0;
+  const int GM = w_tile_group_rows(a);
+  const double total = (double)ntm * ((ntn - (rag ? 1 : 0)) + (rag ? RAG_COST : 0.0));
+  const double ideal = total / (8.0 * wpx);
+  if (mode == 1 && ideal < 3.0) return REED_OK;       // too few tiles per workgroup for the hand-over to matter
+  if (mode == 1) {
+    const double worst = w_static_max_load(ntm, ntn, rag, GM, wpx);
+    // the greedy hand-out of the one-shot kernel ends about half a tile after the balanced time when ragged tiles are mixed in
+    const double greedy = ideal + (rag ? 0.45 : 0.0);
+    if (worst > greedy + 0.05) return REED_OK;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256wp_kernel<LAY, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LDS_W);
+    if (e != hipSuccess) { reed_set_error("gemm256wp: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  GemmArgs b = a;
+  b.tile_gm = GM;
+  REED_KLAUNCH((gemm256wp_kernel<LAY, EPI>), dim3(8 * wpx), dim3(256), LDS_W, stream, b);
+  REED_LAUNCH_CHECK();
+  *used = true;
+  return REED_OK;
+}
+
 template <int LAY, int EPI>
 int launch256w(const GemmArgs& a, hipStream_t stream) {
+  {
+    bool used = false;
+    const int rc = launch256wp<LAY, EPI>(a, stream, &used);
+    if (rc != REED_OK || used) return rc;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm256w_kernel<LAY, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -484,7 +681,6 @@ int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream) {
   return dispatch256w<LAY_NN>(epi, a, stream);
 }
 
-int reed_num_cus();         // gemm256.hip
 int reed_gemm_forced_tile();  // gemm.hip
 
 // 1 = launched; 0 = the problems do not suit this kernel (the caller falls back to gemm_tn.hip's grouped launch)
