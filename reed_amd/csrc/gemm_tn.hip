@@ -17,6 +17,13 @@
 
 #include "gemm_common.hpp"
 
+#ifdef REED_CLK_PROBE
+// diagnostic build only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, tools/clk_probe_tn.py): stamps around the K loop
+__device__ unsigned long long reed_clk_buf_tn[4 * 1024];
+extern "C" int reed_clk_probe_read_tn(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(reed_clk_buf_tn), sizeof(unsigned long long) * n);
+}
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -82,6 +89,10 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, cons
 
   if (nt > 0) stage(0, 0);
   __syncthreads();
+#ifdef REED_CLK_PROBE
+  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
@@ -111,6 +122,18 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, cons
     __syncthreads();
   }
 
+#ifdef REED_CLK_PROBE
+  {
+    const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (tid == 0 && blockIdx.x < 1024) {
+      reed_clk_buf_tn[4 * blockIdx.x + 0] = ck1 - ck0;
+      reed_clk_buf_tn[4 * blockIdx.x + 1] = cr1 - cr0;
+      reed_clk_buf_tn[4 * blockIdx.x + 2] = nt;
+      reed_clk_buf_tn[4 * blockIdx.x + 3] = WIDE ? 1 : 0;
+    }
+  }
+#endif
   // fp32 output (slabs / accumulate): pointer-path epilogue, 64 columns at a time
 #pragma unroll
   for (int h = 0; h < TNN / 4; ++h) {

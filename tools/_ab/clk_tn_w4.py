@@ -1,0 +1,37 @@
+import ctypes, os, statistics, sys, time
+import torch
+sys.path.insert(0, "/root/repo")
+from reed_amd import _lib, ops
+b = 256
+dev = torch.device("cuda")
+D, Hm, T = 1152, 4608, 256
+shapes = [(D, Hm), (Hm, D), (D, D), (3 * D, D)]
+M = b * T
+probs = []
+for n_out, k_in in shapes:
+    dy = (torch.randn(M, n_out, device=dev) * 0.05).to(torch.bfloat16)
+    x = (torch.randn(M, k_in, device=dev) * 0.05).to(torch.bfloat16)
+    out = torch.zeros(n_out * k_in + n_out, device=dev)
+    probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:], n_out, k_in))
+flop = sum(2.0 * M * n * k for n, k in shapes)
+L = _lib.load("bf16")
+rd = L.reed_clk_probe_read; rd.restype = ctypes.c_int; rd.argtypes = [ctypes.c_void_p, ctypes.c_int]
+ops.wgrad_group(probs, M); torch.cuda.synchronize()
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 2.0:
+    for _ in range(10): ops.wgrad_group(probs, M)
+    torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): ops.wgrad_group(probs, M)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+n = 512
+buf = (ctypes.c_ulonglong * (8 * n))()
+assert rd(buf, 8 * n) == 0
+W = [[buf[8 * i + j] for j in range(8)] for i in range(n) if buf[8 * i + 1] > 0]
+for mode in (0, 1, 2, 3):
+    w = [x for x in W if x[3] == mode]
+    if w:
+        print(f"MODE {mode}: {len(w)} records, clock {statistics.median([x[0]/x[1]*0.1 for x in w]):.3f} GHz, {statistics.median([x[0]/x[2] for x in w]):.1f} cycles per K-tile of 64 (MFMA floor 2048 full tile), loop {statistics.median([x[1] for x in w])/100:.1f} us")
+print(f"REED_WGRAD_W4={os.environ.get('REED_WGRAD_W4')}: {ms:.4f} ms per launch, {flop/ms/1e9:.1f} TF")
