@@ -9,9 +9,10 @@ repr_detach, repr_residue, strict_conditioning, flex_param_gamma — are dropped
 same folder name (:92-100) and sample index rule (i*world+rank+total, :164), same .npz packer (:20-34).
 Sampling is embarrassingly parallel: ranks only meet at barriers (RCCL via torch.distributed); no tensor collective.
 
-The SD-VAE decoder (diffusers AutoencoderKL) is not part of this build: if `diffusers` and the
-weights are importable they are used; otherwise pass --save-latents to write the fp32 latents [N,4,32,32] as
-<folder>_latents.npz (decode + PNG can then run anywhere).
+The SD-VAE decoder: with --vae-ckpt <local sd-vae-ft checkpoint> the in-repo restatement of diffusers'
+AutoencoderKL decoder runs (reed_amd/vae.py; parity unpinned: no diffusers / weights here to compare with); without it,
+`diffusers` and its hub weights are used if importable; --save-latents writes the fp32 latents [N,4,32,32] as
+<folder>_latents.npz instead (decode + PNG can then run anywhere).
 """
 import argparse
 import math
@@ -90,6 +91,9 @@ def build_parser():
     parser.add_argument("--prediction", type=str, default="v", choices=["v"])
     # additive
     parser.add_argument("--save-latents", action="store_true", help="write latents .npz instead of decoding to PNG")
+    parser.add_argument("--vae-ckpt", type=str, default=None,
+                        help="local sd-vae-ft-{ema,mse} checkpoint (diffusers directory or its diffusion_pytorch_model file): "
+                             "decode with the in-repo decoder instead of the diffusers package")
     parser.add_argument("--sample-precision", type=str, choices=["fp16", "bf16"], default="fp16",
                         help="16-bit operand type of the model evaluations: fp16 = 10-bit mantissa (the reference's TF32), "
                              "bf16 = the training precision")
@@ -136,12 +140,17 @@ def main(args):
 
     vae = None
     if not args.save_latents:
-        try:
-            from diffusers.models import AutoencoderKL
-            vae = AutoencoderKL.from_pretrained(f"stabilityai/sd-vae-ft-{args.vae}").to(device)
-        except Exception as e:
-            raise RuntimeError("the SD-VAE decoder (diffusers AutoencoderKL + weights) is unavailable; rerun with "
-                               "--save-latents to write latents instead of PNGs") from e
+        if args.vae_ckpt:     # the in-repo restatement of the decoder (reed_amd/vae.py) on a local sd-vae-ft checkpoint
+            from .vae import load_sd_vae_decoder
+            vae = load_sd_vae_decoder(args.vae_ckpt, device=device)
+        else:
+            try:
+                from diffusers.models import AutoencoderKL
+                vae = AutoencoderKL.from_pretrained(f"stabilityai/sd-vae-ft-{args.vae}").to(device)
+            except Exception as e:
+                raise RuntimeError("the SD-VAE decoder is unavailable through diffusers (package or weights missing): pass "
+                                   "--vae-ckpt <sd-vae-ft-{ema,mse} directory or diffusion_pytorch_model.safetensors> to decode "
+                                   "with reed_amd/vae.py, or --save-latents to write latents instead of PNGs") from e
 
     sample_folder_dir = f"{args.sample_dir}/{folder_name(args)}"
     if rank == 0:
@@ -175,7 +184,8 @@ def main(args):
             raise NotImplementedError()
         if vae is not None:
             from PIL import Image
-            img = vae.decode(samples / 0.18215).sample
+            img = vae.decode(samples / 0.18215)
+            img = getattr(img, "sample", img)     # diffusers returns a DecoderOutput, reed_amd.vae the tensor
             img = torch.clamp(255. * ((img + 1) / 2.), 0, 255).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8).numpy()
             for i, s in enumerate(img):
                 Image.fromarray(s).save(f"{sample_folder_dir}/{sample_index(i, world, rank, total):06d}.png")

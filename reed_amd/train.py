@@ -11,7 +11,8 @@ by reed_amd.parallel.GradReducer (RCCL over xGMI, bucketed, overlapped with back
 rejected: there is no fp32 GEMM path).
 
 Deliberate fixes of reference defects: `--enc-type None` = alignment off (§9-4); the preview
-sampling at step 1 / every --sampling-steps runs only if a VAE decoder is importable (§9-2); checkpoints and
+sampling at step 1 / every --sampling-steps runs only with --vae-ckpt (a local SD-VAE checkpoint, reed_amd/vae.py) and writes
+PNG grids instead of wandb images (§9-2); checkpoints and
 args.json are written regardless of --report-to (§9-11); gradients are clipped once and the pre-clip norm is
 logged (§9-5); unknown --text-embeds-dir names get their width from the first .npy (§9-9).
 Additive flags: --features-dirs (precomputed frozen-encoder features, §8f N2), --encoder-ckpts (clip-vit-* encoder run
@@ -105,6 +106,9 @@ def parse_args(input_args=None):
                              "the same items as --data-dir, SURVEY.md §8f N3)")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir (items are drawn on the CPU, ~300 items/s per loader process: keep --num-workers >= 4 or the loader, not the step, sets images_per_sec)")
     parser.add_argument("--log-every", type=int, default=1)
+    parser.add_argument("--vae-ckpt", type=str, default=None,
+                        help="local sd-vae-ft checkpoint (diffusers layout): turns on the reference's preview sampling at step 1 "
+                             "and every --sampling-steps (train.py:431-454), written as PNG grids under <exp>/samples/")
     return parser.parse_args(input_args) if input_args is not None else parser.parse_args()
 
 
@@ -311,6 +315,7 @@ def main(args):
     log_path = os.path.join(save_dir, "metrics.jsonl")
     t_last, n_last = time.time(), global_step
     done = False
+    previews = None
     for epoch in range(args.epochs):
         for item in loader:
             _raw, moments, y, textemb = item[:4]
@@ -331,10 +336,15 @@ def main(args):
                 labels = torch.zeros_like(labels)
             if args.text_embeds_dir is not None:
                 zs.append(textemb.to(device, non_blocking=True))
+            if args.vae_ckpt and previews is None:
+                previews = Previews(args, moments, device, world, save_dir, is_main, latent_size)
             res = step_fn(None, labels, zs, moments=moments)
             if "grad_norm" not in res:
                 continue  # accumulation micro-step
             global_step = step_fn.global_step
+            if previews is not None and (global_step == 1 or (global_step % args.sampling_steps == 0 and global_step > 0)):
+                previews(model, global_step)
+                logger.info("Generating EMA samples done.")
             if global_step % args.checkpointing_steps == 0 and global_step > 0 and is_main:
                 ckpt = {"model": model.state_dict(), "ema": ema.state_dict(), "opt": optimizer.state_dict(),
                         "args": args, "steps": global_step}
@@ -374,6 +384,68 @@ def main(args):
     if world > 1:
         dist.destroy_process_group()
     return save_dir
+
+
+def array2grid(x, padding=2):
+    """train.py:77-81 (torchvision.utils.make_grid with its defaults: nrow = round(sqrt(N)) images per row, 2-pixel black
+    border and gutters) -> uint8 [H, W, 3]."""
+    import math
+    x = x.clamp(0, 1)
+    n, c, h, w = x.shape
+    nrow = max(1, round(math.sqrt(n)))
+    xmaps, ymaps = min(nrow, n), int(math.ceil(n / nrow))
+    grid = x.new_zeros((c, ymaps * (h + padding) + padding, xmaps * (w + padding) + padding))
+    for k in range(n):
+        r, col = divmod(k, xmaps)
+        grid[:, r * (h + padding) + padding:r * (h + padding) + padding + h,
+             col * (w + padding) + padding:col * (w + padding) + padding + w] = x[k]
+    return grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+
+
+class Previews:
+    """The reference's in-training preview (train.py:315-329,431-454): 64 // world fixed noises and labels per rank, sampled with
+    the TRAINING model (50 Euler steps, cfg 4.0), decoded by the SD-VAE and logged as an image grid — here a PNG under
+    <exp>/samples/ instead of a wandb image. On only with --vae-ckpt (reed_amd/vae.py; SURVEY.md §9-2: the reference crashes
+    without a decoder)."""
+
+    def __init__(self, args, first_moments, device, world, save_dir, is_main, latent_size):
+        from .trainer import sample_posterior
+        from .vae import load_sd_vae_decoder
+        self.vae = load_sd_vae_decoder(args.vae_ckpt, device=device)
+        self.args, self.world, self.is_main, self.device = args, world, is_main, device
+        self.dir = os.path.join(save_dir, "samples")
+        if is_main:
+            os.makedirs(self.dir, exist_ok=True)
+        n = max(1, 64 // world)
+        self.gt_xs = sample_posterior(first_moments[:n].to(device), 0.18215, 0.0)   # (fewer than n if the batch is smaller)
+        self.ys = torch.randint(1000, size=(n,), device=device)
+        if not args.cfg:
+            self.ys = torch.zeros_like(self.ys)
+        self.xT = torch.randn((n, 4, latent_size, latent_size), device=device)
+        self._gt_done = False
+
+    def _gather(self, x):
+        if self.world == 1:
+            return x
+        import torch.distributed as dist
+        out = [torch.empty_like(x) for _ in range(self.world)]
+        dist.all_gather(out, x.contiguous())
+        return torch.cat(out)
+
+    @torch.no_grad()
+    def __call__(self, model, step):
+        from PIL import Image
+        from .samplers import euler_sampler
+        a = self.args
+        samples = euler_sampler(model, self.xT, self.ys, num_steps=50, cfg_scale=4.0, guidance_low=0., guidance_high=1.,
+                                path_type=a.path_type, heun=False, prediction=a.prediction).to(torch.float32)
+        out = self._gather((self.vae.decode(samples / 0.18215) + 1) / 2.)
+        gt = None if self._gt_done else self._gather((self.vae.decode(self.gt_xs / 0.18215) + 1) / 2.)
+        if self.is_main:
+            Image.fromarray(array2grid(out)).save(os.path.join(self.dir, f"{step:07d}.png"))
+            if gt is not None:
+                Image.fromarray(array2grid(gt)).save(os.path.join(self.dir, "gt_samples.png"))
+        self._gt_done = True
 
 
 if __name__ == "__main__":

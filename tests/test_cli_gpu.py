@@ -49,6 +49,28 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
     torch.set_grad_enabled(True)
     lat = np.load(folder + "_latents.npz")["arr_0"]
     assert lat.shape == (8, 4, 32, 32) and np.isfinite(lat).all()
+    # the same through the in-repo SD-VAE decoder (reed_amd/vae.py) on a local checkpoint in diffusers' layout: PNGs + .npz
+    from safetensors.torch import save_file
+    from reed_amd.vae import SDVAEDecoder
+    torch.manual_seed(1)
+    vdir = tmp_path / "sd-vae-ft-ema"
+    vdir.mkdir()
+    save_file({k: v.contiguous() for k, v in SDVAEDecoder().state_dict().items()}, str(vdir / "diffusion_pytorch_model.safetensors"))
+    g2 = generate.build_parser().parse_args(["--ckpt", ck[-1], "--model", "SiT-S/2", "--sample-dir", str(tmp_path / "samples_png"),
+                                             "--per-proc-batch-size", "4", "--num-fid-samples", "4", "--num-steps", "2",
+                                             "--vae-ckpt", str(vdir)])
+    folder2 = generate.main(g2)
+    torch.set_grad_enabled(True)
+    assert sorted(os.listdir(folder2)) == [f"{i:06d}.png" for i in range(4)]
+    arr = np.load(folder2 + ".npz")["arr_0"]
+    assert arr.shape == (4, 256, 256, 3) and arr.dtype == np.uint8
+    # the reference's in-training previews (train.py:431-454) with that decoder: a grid at step 1 (and every --sampling-steps)
+    a4 = train.parse_args(["--exp-name", "prev", "--enc-type", "None", "--max-train-steps", "1", "--vae-ckpt", str(vdir)] + common)
+    d4 = train.main(a4)
+    assert sorted(os.listdir(os.path.join(d4, "samples"))) == ["0000001.png", "gt_samples.png"]
+    from PIL import Image
+    grid = np.asarray(Image.open(os.path.join(d4, "samples", "0000001.png")))
+    assert grid.shape == (8 * 258 + 2, 8 * 258 + 2, 3)      # 64 previews, 8 per row, 2-pixel gutters
 
 
 def test_train_default_mixed_precision_is_fp16(dev, tmp_path):

@@ -465,3 +465,44 @@ def test_gloo_world4_reduce_scatter_allgather_form():
             for algo in ("allreduce", "rsag"):
                 torch.testing.assert_close(ret[r][(algo, n)], exp, rtol=1e-6, atol=1e-6)
             assert torch.equal(ret[r][("rsag", n)], ret[0][("rsag", n)])
+
+
+def test_sd_vae_decoder_two_restatements_agree(tmp_path):
+    """reed_amd/vae.py (torch modules, diffusers key names) vs oracle/vae.py (numpy fp64 walk over the checkpoint keys) on
+    random weights: a reduced config end to end, then the published sd-vae-ft config's key surface and a round trip through
+    a checkpoint file with the legacy attention names. PARITY UNPINNED vs diffusers itself (absent here): both files say so."""
+    from oracle import vae as ovae
+    from reed_amd import vae as rvae
+    torch.manual_seed(0)
+    small = rvae.SDVAEDecoder(block_out_channels=(16, 32, 32), layers_per_block=1, norm_num_groups=8).double()
+    for p in small.parameters():
+        p.data.normal_(0, 0.15)
+    z = torch.randn(2, 4, 5, 6, dtype=torch.float64)
+    got = small.decode(z).numpy()
+    want = ovae.Decoder({k: v.numpy() for k, v in small.state_dict().items()}, groups=8).decode(z.numpy())
+    assert got.shape == (2, 3, 20, 24)          # two upsamplers for three blocks: x4
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+    # the published configuration: key names / shapes of the decoder half of sd-vae-ft-{ema,mse}
+    full = rvae.SDVAEDecoder()
+    sd = full.state_dict()
+    assert sd["decoder.conv_in.weight"].shape == (512, 4, 3, 3) and sd["post_quant_conv.weight"].shape == (4, 4, 1, 1)
+    assert sd["decoder.up_blocks.2.resnets.0.conv_shortcut.weight"].shape == (256, 512, 1, 1)
+    assert sd["decoder.up_blocks.3.resnets.0.conv_shortcut.weight"].shape == (128, 256, 1, 1)
+    assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in sd and "decoder.up_blocks.2.upsamplers.0.conv.weight" in sd
+    assert sd["decoder.mid_block.attentions.0.to_q.weight"].shape == (512, 512)
+    assert sd["decoder.conv_out.weight"].shape == (3, 128, 3, 3)
+    assert sum(v.numel() for v in sd.values()) == 49_490_199   # decoder 49,490,179 + post_quant_conv 20
+    # a checkpoint with encoder keys and the legacy attention names (conv-shaped weights) loads into the same module
+    legacy = {"encoder.conv_in.weight": torch.zeros(1), "quant_conv.weight": torch.zeros(1)}
+    ren = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    for k, v in small.state_dict().items():
+        for new, old in ren.items():
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".{new}.", f".{old}.")
+                if k.endswith("weight"):
+                    v = v[:, :, None, None]
+        legacy[k] = v.float()
+    path = str(tmp_path / "diffusion_pytorch_model.bin")
+    torch.save(legacy, path)
+    re = rvae.load_sd_vae_decoder(str(tmp_path), block_out_channels=(16, 32, 32), layers_per_block=1, norm_num_groups=8)
+    np.testing.assert_allclose(re.decode(z.float()).numpy(), got, rtol=2e-4, atol=2e-4)
