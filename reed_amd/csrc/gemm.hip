@@ -222,7 +222,7 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 / 144 = force where the shape allows (tests, A/B timing)
+static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 / 144 / 257 / 258 = force where the shape allows (tests, A/B timing)
 extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
 int reed_gemm_forced_tile() { return g_force_tile; }
 
@@ -257,7 +257,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
-  if (g_force_tile == 257 && reed_gemm256w_eligible(layout, epi, a, splits)) return reed_gemm256w_launch(layout, epi, a, stream);
+  if ((g_force_tile == 257 || g_force_tile == 258) && reed_gemm256w_eligible(layout, epi, a, splits))
+    return reed_gemm256w_launch(layout, epi, a, stream);   // 257: one-shot form, 258: persistent form wherever it applies
   if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits))))
     return reed_gemm144_launch(layout, epi, a, stream);
   if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, epi, a, splits)) &&

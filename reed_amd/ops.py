@@ -147,7 +147,8 @@ def colsum_bf16(x, ld, ws, out, M, N, accumulate=False):
 
 
 def gemm_force_tile(tile):
-    """0 = heuristic; 128 / 256 (eight waves) / 257 (four 128x128 waves) / 144 = force that GEMM kernel where it applies
+    """0 = heuristic; 128 / 256 (eight waves) / 257 (four 128x128 waves, one tile per workgroup) / 258 (the same, persistent
+    form wherever it applies) / 144 = force that GEMM kernel where it applies
     (tests and A/B timing).  Set in both builds of the library."""
     for prec in ("bf16", "fp16"):
         _lib.load(prec).reed_gemm_force_tile(int(tile))

@@ -6,7 +6,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 128, 256, 144, 257], autouse=True)
+@pytest.fixture(params=[0, 128, 256, 144, 257, 258], autouse=True)
 def force_tile(request):
     """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined with eight
     waves, 256x144 ring — only NT / NN shapes whose N is a multiple of 144 —, 257 = the 256^2 tile with four 128x128 waves —
@@ -281,7 +281,7 @@ def test_gemm_arg_errors(dev):
 
 
 @pytest.mark.parametrize("lay", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K", [(8192, 4608, 128), (9000, 2432, 320), (65536, 1152, 64)])
+@pytest.mark.parametrize("M,N,K", [(8192, 4608, 128), (9000, 2432, 320), (65536, 1152, 64), (16640, 1152, 256), (9000, 2432, 512)])
 def test_many_tiles(dev, lay, M, N, K):
     """Several rounds of tiles per CU, ragged M edge and a half-empty last 256-column tile: every tile written exactly
     once through the LDS-staged epilogue, and the 128^2 and 256^2 kernels agree bit for bit."""
@@ -301,9 +301,12 @@ def test_many_tiles(dev, lay, M, N, K):
             ops.gemm(ops.NN, ops.EPI_BF16, x, wq, M, N, K, out, K, N, N, bias=b)
         return out
 
-    o128, o256 = run(128), run(256)
+    o128, o256, o257, o258 = run(128), run(256), run(257), run(258)
     ops.gemm_force_tile(0)
     assert torch.isnan(o128[M]).all() and torch.isnan(o256[M]).all()       # nothing written past row M-1
+    assert torch.isnan(o257[M]).all() and torch.isnan(o258[M]).all()
+    # four 128x128 waves, one tile per workgroup / the persistent walk over the tile list: the same bits
+    assert torch.equal(o257[:M], o256[:M]) and torch.equal(o258[:M], o256[:M])
     ref = x.float() @ w.float().t() + b.float()
     err = (o256[:M].float() - ref).abs().max().item()
     assert err <= ref.abs().max().item() * 2 ** -7, err

@@ -501,7 +501,7 @@ def test_fp16_library_gemm_and_attention(dev):
     outs = {}
     prev = ops.use("fp16")
     try:
-        for tile in (256, 257, 144):
+        for tile in (256, 257, 258, 144):
             ops.gemm_force_tile(tile)
             o1 = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
             o2 = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
@@ -514,4 +514,5 @@ def test_fp16_library_gemm_and_attention(dev):
     torch.testing.assert_close(outs[257][0].float(), x.float() @ w.float().t(), atol=4e-3, rtol=2e-3)
     torch.testing.assert_close(outs[257][1].float(), x.float() @ wn.float(), atol=4e-3, rtol=2e-3)
     assert torch.equal(outs[256][0], outs[257][0]) and torch.equal(outs[256][1], outs[257][1])
+    assert torch.equal(outs[258][0], outs[257][0]) and torch.equal(outs[258][1], outs[257][1])   # persistent form
     torch.testing.assert_close(outs[144][0].float(), outs[257][0].float(), atol=4e-3, rtol=2e-3)
