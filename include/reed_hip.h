@@ -61,6 +61,9 @@ int reed_wgrad_group(int n, const void* const* dy, const void* const* x, float* 
  * beside the GEMMs (RCCL channels during a gradient bucket).  reed_set_cu_reserve(n): n >= 0; reed_planning_cus(): the result. */
 int reed_set_cu_reserve(int n);
 int reed_planning_cus(void);
+/* reed_set_concurrent_comm(1): collectives will run beside the following GEMMs (a data-parallel backward).  Kernels that hold
+ * a whole CU per workgroup for their entire run (the persistent form of the 256x256 kernel) are then not selected. */
+int reed_set_concurrent_comm(int on);
 
 /* tile selection override for tests / A-B timing: 0 = heuristic (default), 128 or 256 = force that kernel, 144 = force
  * the 256x144 kernel wherever it applies (NT / NN, bf16-output epilogue, N % 144 == 0, no split-K) */

@@ -405,6 +405,12 @@ int reed_num_cus() {
   return n - g_cu_reserve > 32 ? n - g_cu_reserve : 32;
 }
 extern "C" int reed_planning_cus(void) { return reed_num_cus(); }
+// Collectives run beside the GEMMs (a data-parallel step): kernels that need a whole CU per workgroup for their whole run
+// (the persistent form of gemm256w.hip) lose more than they gain when RCCL's channels hold some CUs — the workgroups that
+// find no CU start when another finishes its entire list.  The one-shot kernels degrade gracefully; they are used then.
+static int g_concurrent_comm = 0;
+extern "C" int reed_set_concurrent_comm(int on) { g_concurrent_comm = on ? 1 : 0; return 0; }
+int reed_concurrent_comm() { return g_concurrent_comm; }
 
 // Kernel selection (NT forward / NN dgrad), a round-count model fitted to A/B timing at the SiT-XL/2 shapes for b = 64
 // and 256 per GPU (tools/stagger_sweep.py): the 256^2 kernel does one tile per CU at a time and is ~1.18x faster per

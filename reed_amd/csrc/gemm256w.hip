@@ -26,6 +26,7 @@
 
 int reed_num_cus();   // gemm256.hip
 int reed_gemm_forced_tile();  // gemm.hip
+int reed_concurrent_comm();   // gemm256.hip
 
 #ifdef REED_CLK_PROBE
 // diagnostic build only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, read by tools/clk_probe.py): shader-clock and
@@ -593,7 +594,7 @@ int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
   static int env_mode = -1;
   if (env_mode < 0) { const char* e = getenv("REED_GEMM_PERSIST"); env_mode = e ? atoi(e) : 1; }
   const int forced = reed_gemm_forced_tile();   // tests: 257 = the one-shot kernel, 258 = this form wherever it applies
-  const int mode = forced == 257 ? 0 : forced == 258 ? 2 : env_mode;
+  const int mode = forced == 257 ? 0 : forced == 258 ? 2 : reed_concurrent_comm() ? 0 : env_mode;
   *used = false;
   const int nt = cdiv(a.K, WBK), ntm = cdiv(a.M, WBM), ntn = cdiv(a.N, WBN);
   const int wpx = reed_num_cus() / 8;

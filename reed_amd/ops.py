@@ -166,6 +166,13 @@ def set_cu_reserve(n):
         _lib.load(prec).reed_set_cu_reserve(_CU_RESERVE)
 
 
+def set_concurrent_comm(on):
+    """Collectives run beside the GEMMs from now on (data-parallel training): the library keeps to kernels that degrade
+    gracefully when RCCL's channels hold CUs (csrc/gemm256.hip:reed_set_concurrent_comm)."""
+    for prec in ("bf16", "fp16"):
+        _lib.load(prec).reed_set_concurrent_comm(1 if on else 0)
+
+
 def wgrad_slots():
     """Workgroup slots the weight-gradient planning fills: 2 per CU the heuristics plan for."""
     if torch.cuda.is_available():

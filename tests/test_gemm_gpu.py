@@ -397,3 +397,26 @@ def test_tile144_identity(dev, force_tile):
     out.zero_()
     ops.gemm(ops.NN, ops.EPI_BF16, x, w.t().contiguous(), M, N, K, out, K, N, N)
     assert torch.equal(out.float(), w.float().t().contiguous())
+
+
+def test_concurrent_comm_switch_keeps_results(dev, force_tile):
+    """reed_set_concurrent_comm(1) (a data-parallel step: collectives beside the GEMMs) only changes WHICH kernel runs — the
+    persistent form of the four-wave kernel is not selected — never the result."""
+    from reed_amd import ops
+    if force_tile != 0:
+        pytest.skip("heuristic path only")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 32768, 4608, 256
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    outs = []
+    try:
+        for on in (0, 1):
+            ops.set_concurrent_comm(on)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.linear_fwd(x, w, None, out)
+            outs.append(out)
+    finally:
+        ops.set_concurrent_comm(0)
+    assert torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[0][:512].float(), x[:512].float() @ w.float().t(), atol=2e-2, rtol=2e-2)
