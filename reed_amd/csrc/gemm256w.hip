@@ -605,10 +605,21 @@ int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
   const double ideal = total / (8.0 * wpx);
   if (mode == 1 && ideal < 3.0) return REED_OK;       // too few tiles per workgroup for the hand-over to matter
   if (mode == 1) {
-    const double worst = w_static_max_load(ntm, ntn, rag, GM, wpx);
-    // the greedy hand-out of the one-shot kernel ends about half a tile after the balanced time when ragged tiles are mixed in
-    const double greedy = ideal + (rag ? 0.45 : 0.0);
-    if (worst > greedy + 0.05) return REED_OK;
+    // the verdict per (tile grid, group rows, workgroups per XCD) is remembered: the walk below is ~5 k steps on the host
+    static thread_local struct { int ntm, ntn, gm, wpx, ok; } memo[8];   // ntn carries the ragged flag in its sign
+    static thread_local int memo_n = 0;
+    int ok = -1;
+    for (int i = 0; i < memo_n; ++i)
+      if (memo[i].ntm == ntm && memo[i].ntn == (rag ? -ntn : ntn) && memo[i].gm == GM && memo[i].wpx == wpx) ok = memo[i].ok;
+    if (ok < 0) {
+      const double worst = w_static_max_load(ntm, ntn, rag, GM, wpx);
+      // the greedy hand-out of the one-shot kernel ends about half a tile after the balanced time when ragged tiles are mixed in
+      const double greedy = ideal + (rag ? 0.45 : 0.0);
+      ok = worst > greedy + 0.05 ? 0 : 1;
+      memo[memo_n % 8] = {ntm, rag ? -ntn : ntn, GM, wpx, ok};
+      if (memo_n < 8) ++memo_n;
+    }
+    if (!ok) return REED_OK;
   }
   static bool attr_set = false;
   if (!attr_set) {
