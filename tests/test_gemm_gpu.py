@@ -420,3 +420,29 @@ def test_concurrent_comm_switch_keeps_results(dev, force_tile):
         ops.set_concurrent_comm(0)
     assert torch.equal(outs[0], outs[1])
     torch.testing.assert_close(outs[0][:512].float(), x[:512].float() @ w.float().t(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("reserve", [16, 40])
+def test_persistent_form_with_cu_reserve(dev, force_tile, reserve):
+    """With CUs held back for RCCL's channels the persistent form runs fewer workgroups per XCD (positions s + 30 k, s + 27 k of
+    the run): every tile still computed exactly once, same bits as the eight-wave kernel."""
+    from reed_amd import ops
+    if force_tile != 258:
+        pytest.skip("persistent form only")
+    g = torch.Generator(device="cpu").manual_seed(reserve)
+    M, N, K = 20000, 1152, 384   # nt = 6; ragged last row tile and ragged last column tile
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    outs = {}
+    try:
+        ops.set_cu_reserve(reserve)
+        for tile in (258, 256):
+            ops.gemm_force_tile(tile)
+            out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(ops.NT, ops.EPI_BF16, x, w, M, N, K, out, K, K, N)
+            outs[tile] = out
+    finally:
+        ops.set_cu_reserve(0)
+        ops.gemm_force_tile(258)
+    assert torch.isnan(outs[258][M]).all() and not torch.isnan(outs[258][:M]).any()
+    assert torch.equal(outs[258][:M], outs[256][:M])
