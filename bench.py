@@ -208,6 +208,11 @@ def args_D(model):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: C libraries write there too (RCCL prints a version banner on stdout
+    # at communicator creation whatever NCCL_DEBUG_FILE says), so file descriptor 1 points at stderr until that line is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -382,7 +387,10 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:   # rank 0 is still timing the kernel table: nobody tears a communicator down under it
         torch.cuda.synchronize()
         dist.barrier()

@@ -327,9 +327,17 @@ class Engine:
         if getattr(tp, "prec", prec) != prec:
             raise RuntimeError("reed_amd.SiT: model.precision changed between forward and backward")
         prev = ops.use(prec)
+        # gradient buckets are reduced beside this backward's GEMMs (RCCL channels hold CUs): only then does the library keep to
+        # kernels that degrade gracefully without every CU (csrc/gemm256.hip:reed_set_concurrent_comm); the forward, the
+        # optimiser and the sampler run with no collective in flight (the step waits for the last bucket before the update)
+        comm = self.reducer is not None and self.reducer.active()
+        if comm:
+            ops.set_concurrent_comm(True)
         try:
             return self._backward(tp, dout, dzs, ops.half_dtype(prec))
         finally:
+            if comm:
+                ops.set_concurrent_comm(False)
             ops.use(prev)
 
     def _backward(self, tp, dout, dzs, hdt):

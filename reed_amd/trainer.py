@@ -77,7 +77,6 @@ class TrainStep:
         self.cu_tuning = None
         self._tune = []
         self._tune_algo = False
-        ops.set_concurrent_comm(reducer is not None and reducer.active())
         mode = os.environ.get("REED_COMM_CUS", "auto")
         if reducer is not None and reducer.active() and mode != "off":
             if mode == "auto":

@@ -492,3 +492,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and rf["launches_timed"] == 3 * 28
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
     assert "cpu_baseline" not in d      # --no-cpu-baseline; the default run adds {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_bench_stdout_is_one_line_under_a_reducer(dev):
+    """The multi-GPU path of bench.py (process group, RCCL reducer: rehearsed with one rank through REED_FORCE_REDUCER=1): RCCL
+    prints a version banner on stdout when the communicator is created — stdout must still be the one JSON line."""
+    env = dict(os.environ, REED_FORCE_REDUCER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--global-batch", "16", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-kernel-table"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["data_parallel"]["world"] == 1 and d["data_parallel"]["cu_reserve_tuning_ms"] is not None
