@@ -144,22 +144,32 @@ class PackedDataset(Dataset):
 
 
 class SyntheticLatents(Dataset):
-    """Random ImageNet-256-shaped items (SURVEY.md §8d synthetic inputs): for plumbing tests and throughput runs."""
+    """Random ImageNet-256-shaped items (SURVEY.md §8d synthetic inputs): for plumbing tests and throughput runs.  Latents and
+    labels are drawn per index; the encoder features (1 MB per item for a 256 x 1024 target: drawing them per item costs 3 ms of
+    host time, i.e. 300 items/s per loader process) come from a pool of `pool` tensors per encoder drawn once per process."""
 
-    def __init__(self, n, z_dims=(), z_types=(), num_classes=1000, seed=0, latent=32):
+    def __init__(self, n, z_dims=(), z_types=(), num_classes=1000, seed=0, latent=32, pool=32):
         self.n, self.z_dims, self.z_types, self.nc, self.seed, self.latent = n, list(z_dims), list(z_types), num_classes, seed, latent
+        self.pool = max(1, int(pool))
+        self._zs = None
 
     def __len__(self):
         return self.n
+
+    def _pool(self):
+        if self._zs is None:
+            T = (self.latent // 2) ** 2
+            g = torch.Generator().manual_seed(self.seed * 7919 + 17)
+            self._zs = [torch.randn(self.pool, T, z, generator=g) if k == "i" else torch.randn(self.pool, z, generator=g)
+                        for z, k in zip(self.z_dims, self.z_types)]
+        return self._zs
 
     def __getitem__(self, idx):
         g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
         mean = torch.randn(4, self.latent, self.latent, generator=g) * 5.49
         moments = torch.cat([mean, torch.full_like(mean, 0.5)], 0)
         label = torch.randint(0, self.nc, (), generator=g)
-        T = (self.latent // 2) ** 2
-        zs = tuple(torch.randn(T, z, generator=g) if k == "i" else torch.randn(z, generator=g)
-                   for z, k in zip(self.z_dims, self.z_types))
+        zs = tuple(z[idx % self.pool] for z in self._pool())
         return (torch.zeros(0, dtype=torch.uint8), moments, label, torch.zeros(0)) + zs
 
 

@@ -104,7 +104,7 @@ def parse_args(input_args=None):
     parser.add_argument("--packed-dir", type=str, default=None,
                         help="train from a directory written by `python -m reed_amd.dataset pack` (memory-mapped arrays of "
                              "the same items as --data-dir, SURVEY.md §8f N3)")
-    parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir (items are drawn on the CPU, ~300 items/s per loader process: keep --num-workers >= 4 or the loader, not the step, sets images_per_sec)")
+    parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir (plumbing and throughput runs; 1 MB of encoder features per item still crosses the loader: keep --num-workers >= 4)")
     parser.add_argument("--log-every", type=int, default=1)
     parser.add_argument("--vae-ckpt", type=str, default=None,
                         help="local sd-vae-ft checkpoint (diffusers layout): turns on the reference's preview sampling at step 1 "
