@@ -17,8 +17,9 @@
 
 #include "gemm_common.hpp"
 
-#ifdef REED_CLK_PROBE
-// diagnostic build only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, tools/clk_probe_tn.py): stamps around the K loop
+#if defined(REED_CLK_PROBE) || defined(REED_CLK_SEG)
+// diagnostic builds only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, tools/clk_probe_tn.py: stamps around the K loop;
+// seg -DREED_CLK_SEG, tools/_ab/seg_tn.py: per-segment stamps inside it)
 __device__ unsigned long long reed_clk_buf_tn[4 * 1024];
 extern "C" int reed_clk_probe_read_tn(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(reed_clk_buf_tn), sizeof(unsigned long long) * n);
@@ -93,9 +94,28 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, cons
   const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
+#ifdef REED_CLK_SEG
+  // diagnostic build (tools/_ab/build_variant.py seg -DREED_CLK_SEG, tools/_ab/seg_tn.py): where a wave's time goes inside
+  // the K loop (one stamp = s_memtime + lgkmcnt(0), ~40 cycles each; the stamped kernel runs ~10 % slower)
+  unsigned long long sg[5] = {0, 0, 0, 0, 0}, sp;
+#define SEG_STAMP(K)                                                                        \
+  do {                                                                                      \
+    unsigned long long now_;                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if ((K) >= 0) sg[(K) < 0 ? 0 : (K)] += now_ - sp;                                       \
+    sp = now_;                                                                              \
+  } while (0)
+  SEG_STAMP(-1);
+#else
+#define SEG_STAMP(K)
+#endif
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
+    SEG_STAMP(4);      // 4: the barrier at the end of the previous K-tile (+ loop overhead)
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    SEG_STAMP(0);      // 0: issue of the 6 LDS-DMAs of K-tile t+1
     const char* tp = smem + buf * STAGE;
     const char* tq = tp + PSUB * SUB_BYTES;
     bf16x8 pf[TM], qf[TNN];
@@ -109,6 +129,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, cons
       const int c = pcol + j * 16;
       qf[j] = frag_tr(tq + (c >> 7) * SUB_BYTES, c & 127, 0, lane);
     }
+    SEG_STAMP(1);      // 1: 24 transposing reads issued AND returned (the stamp waits lgkmcnt(0))
     REED_LDS_WAIT();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -119,9 +140,21 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, cons
 #pragma unroll
       for (int i = 0; i < TM; ++i) accb[i] = REED_MFMA_16x16x32(ones, pf[i], accb[i]);
     }
+    SEG_STAMP(2);      // 2: the MFMAs issued
+#ifdef REED_CLK_SEG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SEG_STAMP(3);      // 3: K-tile t+1's DMAs landed (what the barrier's vmcnt(0) waits for)
+#endif
     __syncthreads();
   }
 
+#ifdef REED_CLK_SEG
+  if (lane == 0 && blockIdx.x < 128) {
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) reed_clk_buf_tn[(blockIdx.x * 4 + wave) * 8 + k2] = sg[k2];
+    reed_clk_buf_tn[(blockIdx.x * 4 + wave) * 8 + 5] = nt;
+  }
+#endif
 #ifdef REED_CLK_PROBE
   {
     const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
