@@ -547,7 +547,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
       else { tm = g.fm[p]; tn = g.fn[p]; mode = 3; }
     }
   }
-  const GemmArgs& a = g.a[p];
+  // by value: through a reference into the kernel-argument array the compiler re-loads M, N, ldc (s_load + lgkmcnt(0)) in the
+  // middle of the hand-placed K loop, where the SIMD's only wave then stands still (tools/isa_sload_scan.py)
+  const GemmArgs a = g.a[p];
   if (mode == 0) gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, tm, tn);
   else if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
   else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);

@@ -64,13 +64,16 @@ __device__ __forceinline__ void gemm_tn_body(const GemmArgs& a, char* smem, cons
 
   const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(a.Q + n0, ((long)kend * a.ldq - n0) * 2);
+  // the leading dimensions in registers: `a` lives in kernel-argument memory, and every asm statement with a "memory" clobber in
+  // the K loop (the LDS waits) made the compiler load them again — an s_load + s_waitcnt lgkmcnt(0) in front of each K-tile's DMAs
+  const long ldp = a.ldp, ldq = a.ldq;
   auto stage = [&](int t, int buf) {
     char* tp = smem + buf * STAGE;
     const int k0 = kbeg + t * TBK;
 #pragma unroll
-    for (int s = 0; s < PSUB; ++s) stage_sub(rsP, tp + s * SUB_BYTES, a.ldp, k0, s * 128, tid, wave);
+    for (int s = 0; s < PSUB; ++s) stage_sub(rsP, tp + s * SUB_BYTES, ldp, k0, s * 128, tid, wave);
 #pragma unroll
-    for (int s = 0; s < QSUB; ++s) stage_sub(rsQ, tp + (PSUB + s) * SUB_BYTES, a.ldq, k0, s * 128, tid, wave);
+    for (int s = 0; s < QSUB; ++s) stage_sub(rsQ, tp + (PSUB + s) * SUB_BYTES, ldq, k0, s * 128, tid, wave);
   };
 
   f32x4 acc[TM][TNN];
