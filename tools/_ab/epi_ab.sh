@@ -1,3 +1,4 @@
+# the -DREED_EPI_EXP=1 probe this script timed has been removed from gemm_common.hpp (result recorded)
 cd /root/repo
 for rep in 1 2; do
 for lib in "" tools/_ab/libreed_epi1.so; do
