@@ -1,10 +1,11 @@
 // 256x256x64 MFMA GEMM with FOUR waves (one per SIMD), each owning a 128x128 piece of the output = 8x8 MFMA tiles
 // in 256 accumulator registers (the unified 512-register file of a SIMD that holds a single wave).
 //
-// Why: in gemm256.hip's 2 x 4 wave grid a wave owns 128x64 and reads 12 operand fragments per 32 MFMAs; the LDS pipe
-// (128 B/clk) is then exactly as busy as the MFMA pipe — per K-tile 192 KiB of fragment reads + 64 KiB of DMA writes =
-// 2048 clk against 2 waves x 64 MFMAs x 16 clk = 2048 clk per SIMD — and every bank conflict or barrier skew shows.
-// With 128x128 per wave it is 16 fragments per 64 MFMAs: 128 + 64 KiB = 1536 clk of LDS under the same 2048 clk of MFMA.
+// Why: in gemm256.hip's 2 x 4 wave grid a wave owns 128x64 and reads 12 operand fragments per 32 MFMAs; with 128x128 per
+// wave it is 16 fragments per 64 MFMAs — a third fewer LDS instructions (and DMA pieces per wave stay 16 per K-tile) in the
+// issue slots the MFMAs leave.  (The design estimate counted LDS bytes at 128 B/clk: 192 + 64 KiB = 2048 clk per K-tile, level
+// with the matrix pipe, against 128 + 64 KiB = 1536 clk; tools/micro/lds_rate.hip later measured 218 B/clk for ds_read_b128 at
+// 8 waves per CU and 341 at 16, so the pipe was never byte-bound — the gain is in instructions issued per MFMA.)
 // Same LDS tile formats, staging (LDS-DMA half-tiles of 16 KiB, two K-tile buffers), layouts and epilogues as
 // gemm256.hip, same accumulation order (bit-identical results).
 //
