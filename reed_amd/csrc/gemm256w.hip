@@ -29,7 +29,7 @@ int reed_num_cus();   // gemm256.hip
 int reed_gemm_forced_tile();  // gemm.hip
 int reed_concurrent_comm();   // gemm256.hip
 
-#ifdef REED_CLK_PROBE
+#if defined(REED_CLK_PROBE) || defined(REED_CLK_PHASE)
 // diagnostic build only (tools/_ab/build_variant.py clk -DREED_CLK_PROBE, read by tools/clk_probe.py): shader-clock and
 // 100 MHz stamps around the K loop of every workgroup; the product build has no stamp
 __device__ unsigned long long reed_clk_buf[8 * 8192];
@@ -285,21 +285,39 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 
   // PF: K-tile t+2 exists (literal true in the steady-state loop: no branch around the DMAs)
 #define WKTILE(T, CUR, PF, KIND, KT) WKTILE_(T, CUR, PF, KIND, KT, 0)
+#ifdef REED_CLK_PHASE   /* diagnostic build: cycles per phase (A, the waits + barrier, B), one stamp = s_memtime + lgkmcnt(0) */
+#define WSTAMP(K)                                                                          \
+  do {                                                                                     \
+    unsigned long long now_;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if ((K) >= 0) wph[(K) < 0 ? 0 : (K)] += now_ - wsp;                                    \
+    wsp = now_;                                                                            \
+  } while (0)
+  unsigned long long wph[3] = {0, 0, 0}, wsp = 0;
+#else
+#define WSTAMP(K)
+#endif
 #define WKTILE_(T, CUR, PF, KIND, KT, Z)                                                    \
   do {                                                                                     \
     const int t_ = (T);                                                                    \
     asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));     \
     /* phase A: MFMAs of (t, ks0); reads of (t, ks1) */                                    \
     WLGKM0();                                                                              \
+    WSTAMP(-1);                                                                            \
     WPHASE(0, (CUR), 1, false, 0, 0, 0, Z);                                                \
+    WSTAMP(0);                                                                             \
     /* phase B: K-tile t+1 landed, every wave done with K-tile t; MFMAs of (t, ks1); reads of (t+1, ks0); DMAs of t+2 */ \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
     WLGKM0();                                                                              \
     WBARRIER();                                                                            \
+    WSTAMP(1);                                                                             \
     {                                                                                      \
       const bool pf_ = (PF);                                                               \
       WPHASE(1, 1 - (CUR), 0, pf_, ((KIND) == 0 ? t_ + 2 : (KT)), (CUR), KIND, 0);         \
     }                                                                                      \
+    WSTAMP(2);                                                                             \
   } while (0)
 
   if (PM != 0 && !first) {
@@ -355,6 +373,17 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 
   // the MFMAs are inline asm: the compiler does not know the accumulators were just written by the matrix pipe
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef REED_CLK_PHASE
+  {
+    const int pidx = tm * ((a.N + WBN - 1) / WBN) + tn;
+    if (lane == 0 && wave == 0 && pidx < 8192 && MODE == 0) {
+      reed_clk_buf[8 * pidx + 0] = wph[0];
+      reed_clk_buf[8 * pidx + 1] = wph[1];
+      reed_clk_buf[8 * pidx + 2] = wph[2];
+      reed_clk_buf[8 * pidx + 3] = nt;
+    }
+  }
+#endif
 #ifdef REED_CLK_PROBE
   {
     unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
@@ -401,6 +430,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #undef WLGKM0
 #undef WKTILE
 #undef WKTILE_
+#undef WSTAMP
 }
 
 template <int LAY, int EPI>
