@@ -281,7 +281,7 @@ def test_gemm_arg_errors(dev):
 
 
 @pytest.mark.parametrize("lay", ["NT", "NN"])
-@pytest.mark.parametrize("M,N,K", [(8192, 4608, 128), (9000, 2432, 320), (65536, 1152, 64), (16640, 1152, 256), (9000, 2432, 512)])
+@pytest.mark.parametrize("M,N,K", [(8192, 4608, 128), (9000, 2432, 320), (65536, 1152, 64), (16640, 1152, 256), (9000, 2432, 512), (16640, 1152, 384), (9000, 2432, 768)])
 def test_many_tiles(dev, lay, M, N, K):
     """Several rounds of tiles per CU, ragged M edge and a half-empty last 256-column tile: every tile written exactly
     once through the LDS-staged epilogue, and the 128^2 and 256^2 kernels agree bit for bit."""
