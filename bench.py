@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py — SiT-XL/2 ImageNet-256 train images/sec on MI355X (BASELINE.json metric), HIP path only.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL. Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or — with no WORLD_SIZE in the environment —
+this process starts them itself: BEFORE any GPU call it spawns that very command as a child process (never exec), relays
+rank 0's single JSON line to its own stdout and returns the child's exit code; with fewer than N visible devices it exits
+non-zero with a one-line message.
 
 A "step" is one full optimisation step of image/train.py on one batch of synthetic inputs already resident in HBM:
 sample_posterior -> SILoss (interpolant, SiT-XL/2 forward with the 1024-d DINOv2-L-shaped projector tap, MSE +
@@ -26,7 +32,7 @@ PEAK_BF16 = 2.5e15             # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -39,7 +45,62 @@ def parse():
                          "operands with dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-c3-leg", action="store_true", help="skip the b = 32 per-GPU leg (the 8-GPU shape) the N = 1 run appends")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("REED_BENCH_LAUNCH_TIMEOUT", "2400")),
+                    help="seconds the self-launcher lets its ranks run before it ends them (a hung collective must not hang the caller)")
+    return ap.parse_args(argv)
+
+
+def launcher_argv(args, argv, port):
+    """The child command of the self-launcher: torch.distributed.run with one rank per GPU of this node, rendezvous on
+    127.0.0.1 (the container hostname may not resolve), this script and its own arguments unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no ranks started by the caller (image/README.md:23 uses `accelerate launch`, which does
+    the same): count the devices WITHOUT initialising the GPU (torch.cuda.device_count() does not, on this image), then run
+    the ranks as a child process group and relay rank 0's JSON line.  Nothing here touches HIP, so the parent stays exec-safe."""
+    import signal
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible on this node", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this image
+    cmd = launcher_argv(args, argv, _free_port())
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)
+    try:
+        out, _ = p.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)     # exactly the process group this function started
+        except ProcessLookupError:
+            pass
+        out, _ = p.communicate()
+        print(f"bench.py: ranks still running after {args.launch_timeout:.0f} s - ended", file=sys.stderr, flush=True)
+        return 3
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr, flush=True)
+        return 4
+    return p.returncode
 
 
 def random_fill(model, seed):
@@ -206,8 +267,35 @@ def args_D(model):
     return model.engine().D
 
 
+def c3_leg(step, dev, z_dim, b=32, steps=10, warmup=3):
+    """The per-GPU leg of C3 on this one GPU: the same model, optimiser and step at the local batch the 8-GPU run of the
+    headline configuration sees (global batch 256 / 8), no communication.  Run after the main timed region, so the driver's
+    record carries the 8-GPU-shape number; 8 x this is the upper bound of the 8-GPU run before any all-reduce cost."""
+    g = torch.Generator(device=dev).manual_seed(4242)
+    mean = torch.randn(b, 4, 32, 32, device=dev, generator=g) * 5.49
+    moments = torch.cat([mean, torch.full_like(mean, 0.5)], dim=1)
+    labels = torch.randint(0, 1000, (b,), device=dev, generator=g)
+    zs = [torch.randn(b, 256, z_dim, device=dev, generator=g)]
+    for _ in range(warmup):
+        step(None, labels, zs, moments=moments)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step(None, labels, zs, moments=moments)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ips = b * steps / dt
+    return {"local_batch": b, "steps": steps, "warmup": warmup, "images_per_sec_per_gpu": round(ips, 2),
+            "ms_per_step": round(dt / steps * 1e3, 3), "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
+            "x8_upper_bound_images_per_sec": round(8 * ips, 1), "final_loss": round(float(res["loss"]), 5),
+            "note": "one GPU, no gradient all-reduce: the compute side of the 8-GPU run (b = 256 / 8 per GPU)"}
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
     # stdout carries exactly ONE line, the JSON record: C libraries write there too (RCCL prints a version banner on stdout
     # at communicator creation whatever NCCL_DEBUG_FILE says), so file descriptor 1 points at stderr until that line is printed
     sys.stdout.flush()
@@ -217,7 +305,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment (unset it to let bench.py start "
+                         f"its own ranks, or launch with torch.distributed.run --nproc-per-node {args.gpus})")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -250,6 +341,10 @@ def main():
         reducer = GradReducer(model, rank, world)
         reducer.broadcast_params(0)
     loss_fn = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
+    # the run-time measurement of the CU reserve is opt-in in the library (REED_COMM_CUS=auto); the bench asks for it on a
+    # data-parallel run unless the caller fixed it.  The bucket form stays "allreduce" unless REED_COMM_ALGO says otherwise.
+    if reducer is not None:
+        os.environ.setdefault("REED_COMM_CUS", "auto")
     step = TrainStep(model, loss_fn, opt, reducer, proj_coeff=0.5, diffusion_warm_up_steps=0)
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -276,7 +371,8 @@ def main():
 
     # W untimed warm-up steps — more when the data-parallel step still measures its CU reserve (trainer.py): that
     # measurement (two steps per candidate) stays out of the timed region
-    for _ in range(max(args.warmup, step.tune_steps_left() + 1 if step.tune_steps_left() else 0)):
+    n_warm = max(args.warmup, step.tune_steps_left() + 1 if step.tune_steps_left() else 0)
+    for _ in range(n_warm):
         res = step(None, labels, zs, moments=moments)
     barrier()
     if rank == 0 and not args.no_kernel_table:
@@ -284,7 +380,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(None, labels, zs, moments=moments)
-    t_enq = time.perf_counter() - t0    # host time to enqueue the K steps (the GPU runs behind; no sync inside a step)
     barrier()
     dt = time.perf_counter() - t0
     ops.wgrad_group_probe = None
@@ -352,35 +447,52 @@ def main():
                                    "(fwd+bwd+clip+AdamW+EMA), bf16 MFMA / fp32 master",
                        "global_batch": args.global_batch, "local_batch": b, "parallelism": f"dp{world}"},
             "final_loss": round(loss_val, 5),
-            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             # the whole step against the MFMA roofline: images/s/GPU x 724.97 GFLOP / 2.5 PFLOP/s (the headline efficiency)
             "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
             "data_parallel": dp,
         }
         if not args.no_kernel_table:
             # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region
+            rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm)
             n_l = sum(len(v) for v in dom.values())
-            tot_ms = sum(sum(v) for v in dom.values())
-            tot_fl = sum(fl * len(v) for fl, v in dom.items())
-            ach = tot_fl / max(tot_ms, 1e-9) / 1e9
-            out["roofline"] = {
-                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": round(ach * 1e12 / PEAK_BF16, 4),
-                "traffic": TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None,
-                "traffic_source": TRAFFIC_SOURCE if (b == 256 and args.model == "SiT-XL/2") else None,
-                "kernel": "gemm_tn_group_kernel = the weight (+ bias) gradients of one transformer block's four linears (fc2, fc1, "
-                          "proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch of 256x128 / 128x256 tiles without split-K; "
-                          "algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration of every such launch "
-                          "INSIDE the timed region (events on the launch stream; the largest single share of the step)",
-                "launches_timed": n_l, "avg_ms_per_launch": round(tot_ms / max(n_l, 1), 4),
-                "flop_per_launch": (next(iter(dom)) if dom else None)}
-            rows = time_gemms(b)
+            if n_l:
+                tot_ms = sum(sum(v) for v in dom.values())
+                tot_fl = sum(fl * len(v) for fl, v in dom.items())
+                ach = tot_fl / max(tot_ms, 1e-9) / 1e9
+                out["roofline"] = {
+                    "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": round(ach * 1e12 / PEAK_BF16, 4),
+                    "traffic": TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None,
+                    "traffic_source": TRAFFIC_SOURCE if (b == 256 and args.model == "SiT-XL/2") else None,
+                    "kernel": "gemm_tn_group_kernel = the weight (+ bias) gradients of one transformer block's four linears (fc2, fc1, "
+                              "proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch of 256x128 / 128x256 tiles without split-K; "
+                              "algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration of every such launch "
+                              "INSIDE the timed region (events on the launch stream; the largest single share of the step)",
+                    "launches_timed": n_l, "avg_ms_per_launch": round(tot_ms / n_l, 4),
+                    "flop_per_launch": next(iter(dom))}
+            else:
+                # the grouped launch did not run (a CU reserve under data parallelism, a model whose tiles do not fill the
+                # slots, REED_WGRAD_GROUP=0): the same gradients go through the per-GEMM split-K path, and the roofline kernel
+                # is its largest member, timed in isolation after the timed region (the kernel table below)
+                r = max((r for r in rows if r["kernel"].startswith("wgrad")), key=lambda r: r["ms"])
+                out["roofline"] = {
+                    "bound": "mfma", "achieved": r["tflops"], "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": round(r["tflops"] * 1e12 / PEAK_BF16, 4), "traffic": None, "traffic_source": None,
+                    "kernel": f"gemm_tn_kernel ({r['kernel']}): the largest weight-gradient GEMM of a block through the split-K slab "
+                              "path (the grouped launch was not used in this run), event-timed in ISOLATION after the timed region",
+                    "launches_timed": 0, "avg_ms_per_launch": r["ms"],
+                    "flop_per_launch": round(r["tflops"] * r["ms"] * 1e9)}
             tot = sum(r["ms"] for r in rows)
             agg = sum(r["tflops"] * r["ms"] for r in rows) / tot
             # the GEMM family launched in ISOLATION after the timed region (12 shapes of one block, time-weighted): an upper
             # view of the kernels, not the step — the step's efficiency is step_mfma_frac
             out["gemm_family_isolated"] = {"tflops": round(agg, 1), "frac": round(agg * 1e12 / PEAK_BF16, 4),
                                            "ms_per_block": round(tot, 4), "table": rows}
+        if world == 1 and not args.no_c3_leg and b != 32 and args.model == "SiT-XL/2":
+            try:
+                out["c3_per_gpu_leg"] = c3_leg(step, dev, args.z_dim)
+            except Exception as e:   # a reported leg, never a reason to lose the headline line
+                out["c3_per_gpu_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

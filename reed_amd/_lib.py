@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REED_HIP_LIB") or os.path.join(_HERE, "libreed_hip.so")
 # the same sources built with IEEE-half operands (csrc/common.hpp, -DREED_FP16): the sampling path
 LIB_PATH_F16 = os.environ.get("REED_HIP_LIB_F16") or os.path.join(_HERE, "libreed_hip_f16.so")
+# the fp32-operand build (-DREED_FP32): --mixed-precision no / generate.py --no-tf32
+LIB_PATH_F32 = os.environ.get("REED_HIP_LIB_F32") or os.path.join(_HERE, "libreed_hip_f32.so")
+PRECISIONS = ("bf16", "fp16", "fp32")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "reed_hip.h")
 
 _lib = None
@@ -44,11 +47,12 @@ def parse_header(path=HEADER_PATH):
 
 
 def load(precision="bf16"):
-    """precision "bf16": libreed_hip.so (training and everything else); "fp16": libreed_hip_f16.so (sampling)."""
+    """precision "bf16": libreed_hip.so (training and everything else); "fp16": libreed_hip_f16.so (sampling at TF32's
+    mantissa, --mixed-precision fp16); "fp32": libreed_hip_f32.so (--mixed-precision no, generate.py --no-tf32)."""
     global _lib
     if precision in _libs:
         return _libs[precision]
-    path = {"bf16": LIB_PATH, "fp16": LIB_PATH_F16}[precision]
+    path = {"bf16": LIB_PATH, "fp16": LIB_PATH_F16, "fp32": LIB_PATH_F32}[precision]
     if not os.path.exists(path):
         raise RuntimeError(
             f"reed_amd: {path} not found. Build it with `python -m reed_amd.build` "
@@ -68,12 +72,17 @@ def load(precision="bf16"):
         fn.restype = restype
         fn.argtypes = [t for t, _ in args]
     lib._reed_missing = missing  # tests assert this is empty; calling a missing symbol raises
-    if not missing and lib.reed_half_kind() != {"bf16": 0, "fp16": 1}[precision]:
+    if not missing and lib.reed_half_kind() != {"bf16": 0, "fp16": 1, "fp32": 2}[precision]:
         raise RuntimeError(f"reed_amd: {path} was not built for {precision} operands")
     _libs[precision] = lib
     if precision == "bf16":
         _lib = lib
     return lib
+
+
+def loaded():
+    """The builds this process has loaded so far (knobs that every build carries are set in each of them)."""
+    return dict(_libs)
 
 
 def check(rc, what="", lib=None):

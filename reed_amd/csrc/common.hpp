@@ -8,7 +8,16 @@
 // -DREED_FP16) with IEEE half operands for the sampling path: the reference samples with an fp32 model under TF32
 // (image/generate.py:41,183), whose 10-bit mantissa is half's, at the same MFMA rate as bf16 (v_mfma_f32_16x16x32_f16).
 // The type keeps its name `bf16` in the sources ("the 16-bit operand"); only this block knows which one it is.
-#ifdef REED_FP16
+#if defined(REED_FP32)
+// Third build (libreed_hip_f32.so): the reference's `--mixed-precision no` / `generate.py --no-tf32` arithmetic
+// (image/train.py:505, image/generate.py:41,183).  The "16-bit operand" IS float: every rounding point of the mixed-precision
+// contract (f2bf, bfround) becomes the identity, activations and the weight shadow are fp32 arrays, and the contractions run
+// on the fp32-input matrix instruction v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the 16-bit rate; csrc/gemm_f32.hip,
+// csrc/attention_f32.hip).  The MFMA-tuned 16-bit kernels (gemm*.hip, gemm_tn.hip, attention.hip, encoder.hip) are not part
+// of this build; the row / loss / optimiser / sampler kernels are the same sources.
+typedef float bf16;
+#define REED_HALF_KIND 2
+#elif defined(REED_FP16)
 typedef _Float16 bf16;
 #define REED_HALF_KIND 1
 #define REED_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)

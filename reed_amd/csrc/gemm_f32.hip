@@ -1,0 +1,260 @@
+// fp32-operand GEMM for gfx950 — the dense contraction of the fp32 build of the library (libreed_hip_f32.so, -DREED_FP32):
+// the reference's `--mixed-precision no` training (image/train.py:505) and `generate.py --no-tf32` sampling
+// (image/generate.py:41,183), where every nn.Linear multiplies fp32 operands and accumulates in fp32.
+//
+//   C[M,N] (+)= sum_k P(m,k) * Q(n,k)        same three operand layouts and the same epilogue ids as csrc/gemm.hip
+//
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate; exact fp32 products, 64 cycles per SIMD = 1/16 of
+// the bf16 rate, MI355X_MICROARCH.md "Matrix cores").  At that rate the loop is MFMA-bound by a wide margin, so the kernel is
+// the plain form: tile 128x128x16, four waves of 64x64 (2x2 MFMA tiles, 64 accumulator registers), operands staged
+// global -> registers -> LDS k-major ([16][128+32] floats per operand: a fragment read is 2 rows x 32 consecutive floats,
+// the 32-float pad puts the two rows on disjoint bank halves), double buffered, one barrier per K step; every bound
+// (ragged M, N, K; split-K ranges) is a guard on the staging loads and on the stores, so there are no shape restrictions
+// beyond 4-element alignment.  In this build `bf16` IS float (common.hpp): C, C2, R, bias and the gate are fp32 arrays and
+// every rounding point of the mixed-precision epilogues is the identity — one kernel per layout, the epilogue a run-time
+// switch.  This file is not part of the 16-bit builds (reed_amd/build.py).
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/reed_hip.h"
+#include "gemm.h"
+
+#ifndef REED_FP32
+#error "gemm_f32.hip belongs to the fp32-operand build (-DREED_FP32) only"
+#endif
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 160;     // LDT: floats per k-row of an LDS tile (128 + 32 pad)
+constexpr int TILE_FLOATS = BK * LDT;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct Stage {       // one K step of one operand in registers: two float4 per thread
+  f32x4 v[2];
+};
+
+// k-contiguous operand X[rows][K] (ld floats per row): tile rows r0.. x k [k0, k0+16).  Thread t: row t>>1, k-half (t&1)*8.
+__device__ __forceinline__ void load_row(Stage& s, const float* X, long ld, int r0, int rows, int k0, int kend, int t) {
+  const int r = r0 + (t >> 1), kq = k0 + (t & 1) * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = kq + 4 * i;
+    s.v[i] = (r < rows && k < kend) ? *(const f32x4*)(X + (long)r * ld + k) : f32x4{0.f, 0.f, 0.f, 0.f};   // K % 4 == 0
+  }
+}
+__device__ __forceinline__ void store_row(const Stage& s, float* tile, int t) {
+  const int r = t >> 1, kq = (t & 1) * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(kq + 4 * i + e) * LDT + r] = s.v[i][e];
+}
+// k-strided operand X[K][cols]: tile k [k0, k0+16) x cols c0..  Thread t: k-row (t>>5) + 8 i, columns (t&31)*4.
+__device__ __forceinline__ void load_tr(Stage& s, const float* X, long ld, int c0, int cols, int k0, int kend, int t) {
+  const int c = c0 + (t & 31) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = k0 + (t >> 5) + 8 * i;
+    s.v[i] = (k < kend && c < cols) ? *(const f32x4*)(X + (long)k * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};     // cols % 4 == 0
+  }
+}
+__device__ __forceinline__ void store_tr(const Stage& s, float* tile, int t) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *(f32x4*)(tile + ((t >> 5) + 8 * i) * LDT + (t & 31) * 4) = s.v[i];
+}
+
+__device__ __forceinline__ float act_fwd(int epi, int variant, float x) {
+  if (epi == EPI_GELU) return gelu_tanh_f(x);
+  if (epi == EPI_SILU) return silu_f(x);
+  return variant ? gelu_erf_f(x) : x * sigmoid_f(1.702f * x);   // EPI_QGELU
+}
+
+template <int LAY>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int epi) {
+  __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];   // [buffer][P | Q]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (a.N + BN - 1) / BN;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int z = blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = z * a.ksplit_len;
+  const int kend = min(a.K, kbeg + a.ksplit_len);
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  auto load = [&](int t, Stage& sp, Stage& sq) {
+    const int k0 = kbeg + t * BK;
+    if constexpr (LAY == LAY_TN) load_tr(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
+    else load_row(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
+    if constexpr (LAY == LAY_NT) load_row(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
+    else load_tr(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
+  };
+  auto store = [&](int buf, const Stage& sp, const Stage& sq) {
+    if constexpr (LAY == LAY_TN) store_tr(sp, smem[buf][0], tid);
+    else store_row(sp, smem[buf][0], tid);
+    if constexpr (LAY == LAY_NT) store_row(sq, smem[buf][1], tid);
+    else store_tr(sq, smem[buf][1], tid);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // TN: the bias gradient dbias[m] = sum_k P[k][m] (column sums of dY) rides along in the blocks of the first column tile:
+  // thread t < 128 owns column m0 + t of the staged P tile
+  const bool do_dbias = (LAY == LAY_TN) && a.dbias != nullptr && tn == 0;
+  float bsum = 0.f;
+
+  Stage sp, sq;
+  if (nt > 0) {
+    load(0, sp, sq);
+    store(0, sp, sq);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) load(t + 1, sp, sq);
+    const float* tp = smem[buf][0];
+    const float* tq = smem[buf][1];
+    const int kr = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float pf[2], qf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        pf[i] = tp[(2 * ks + kr) * LDT + wm * 64 + i * 32 + c];
+        qf[i] = tq[(2 * ks + kr) * LDT + wn * 64 + i * 32 + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_dbias && tid < BM) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) bsum += tp[k * LDT + tid];
+    }
+    if (t + 1 < nt) store(buf ^ 1, sp, sq);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns column n (32 consecutive lanes = 32 consecutive columns) of 16 rows per MFMA tile ----
+  const float* bias = a.bias;
+  const float* Rf = (const float*)a.R;
+  float* C = (float*)a.C;
+  float* C2 = (float*)a.C2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (n >= a.N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+        if (m >= a.M) continue;
+        const float v = acc[i][j][r] + bv;
+        switch (epi) {
+          case EPI_BF16: C[(long)m * a.ldc + n] = v; break;
+          case EPI_GELU: case EPI_SILU: case EPI_QGELU:
+            if (C) C[(long)m * a.ldc + n] = v;
+            C2[(long)m * a.ldc2 + n] = act_fwd(epi, a.act_variant, v);
+            break;
+          case EPI_GATE_RES: {
+            if (C2) C2[(long)m * a.ldc2 + n] = v;
+            const float g = a.gate[(long)(m / a.rows_per_gate) * a.ldgate + n];
+            C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + g * v;
+          } break;
+          case EPI_LS_RES: C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + a.gate[n] * v; break;
+          case EPI_DGELU: C[(long)m * a.ldc + n] = v * gelu_tanh_grad_f(Rf[(long)m * a.ldr + n]); break;
+          case EPI_DSILU: C[(long)m * a.ldc + n] = v * silu_grad_f(Rf[(long)m * a.ldr + n]); break;
+          case EPI_RES_BF16: C[(long)m * a.ldc + n] = v + Rf[(long)m * a.ldr + n]; break;
+          case EPI_F32: {
+            float* cp = C + (long)z * a.slab_stride + (long)m * a.ldc + n;
+            *cp = a.accumulate ? *cp + v : v;
+          } break;
+          case EPI_ADDF32_RB: C[(long)m * a.ldc + n] += v; break;
+          case EPI_ATOMIC_F32: atomicAdd(C + (long)m * a.ldc + n, v); break;
+        }
+      }
+    }
+  if (do_dbias && tid < BM) {
+    const int m = m0 + tid;
+    if (m < a.M) {
+      if (gridDim.y > 1) a.dbias[(long)z * a.slab_stride + m] = bsum;   // split-K: per-slice slab (C's stride)
+      else if (a.accumulate) a.dbias[m] += bsum;
+      else a.dbias[m] = bsum;
+    }
+  }
+}
+
+template <int LAY>
+int launch(const GemmArgs& a, int epi, int splits, hipStream_t stream) {
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), splits, 1);
+  REED_KLAUNCH((gemm_f32_kernel<LAY>), grid, dim3(256), 0, stream, a, epi);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+}  // namespace
+
+// The tile-selection knobs of the 16-bit kernels: accepted and without effect here (one kernel).
+static int g_force_tile = 0, g_cu_reserve = 0, g_concurrent_comm = 0;
+extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
+extern "C" int reed_set_cu_reserve(int n) { g_cu_reserve = n > 0 ? n : 0; return 0; }
+extern "C" int reed_set_concurrent_comm(int on) { g_concurrent_comm = on ? 1 : 0; return 0; }
+int reed_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n - g_cu_reserve > 32 ? n - g_cu_reserve : 32;
+}
+extern "C" int reed_planning_cus(void) { return reed_num_cus(); }
+
+// The grouped weight-gradient launch is a 16-bit MFMA kernel (gemm_tn.hip): not part of this build; the caller falls back to
+// one reed_gemm(TN) per weight (ops.wgrad_group returns False on this code).
+int reed_gemm_tn_group_launch(int, const GemmArgs*, hipStream_t) {
+  reed_set_error("reed_wgrad_group: not built for fp32 operands (one reed_gemm(TN) per weight instead)");
+  return REED_ERR_UNSUPPORTED;
+}
+
+int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
+  REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  REED_CHECK_ARG(a.ldp % 4 == 0 && a.ldq % 4 == 0 && a.N % 4 == 0, "reed_gemm(fp32): leading dims and N must be multiples of 4 elements");
+  REED_CHECK_ARG(((uintptr_t)a.P % 16) == 0 && ((uintptr_t)a.Q % 16) == 0, "reed_gemm: operands must be 16-byte aligned");
+  if (layout == LAY_TN_TALL || layout == LAY_TN_WIDE) layout = LAY_TN;   // tile hints of the 16-bit weight-gradient kernel
+  if (layout == LAY_TN) REED_CHECK_ARG(a.M % 4 == 0, "reed_gemm(TN, fp32): M=%d must be a multiple of 4", a.M);
+  else REED_CHECK_ARG(a.K % 4 == 0, "reed_gemm(NT/NN, fp32): K=%d must be a multiple of 4", a.K);
+  switch (epi) {
+    case EPI_BF16: case EPI_GELU: case EPI_SILU: case EPI_GATE_RES: case EPI_DGELU: case EPI_DSILU: case EPI_F32:
+    case EPI_ADDF32_RB: case EPI_ATOMIC_F32: case EPI_QGELU: case EPI_RES_BF16: case EPI_LS_RES: break;
+    default: reed_set_error("reed_gemm: unknown epilogue %d", epi); return REED_ERR_ARG;
+  }
+  if (splits < 1) splits = 1;
+  // K per split: the same arithmetic as the 16-bit kernels (units of 64), so callers that size slab workspaces by it
+  // (ops.linear_wgrad, engine.py) see the same slab count from either build
+  const int ksteps = cdiv(a.K, 64);
+  const int per = cdiv(ksteps, splits);
+  splits = cdiv(ksteps, per);
+  a.ksplit_len = per * 64;
+  if (splits > 1)
+    REED_CHECK_ARG(epi == EPI_ATOMIC_F32 || (epi == EPI_F32 && a.slab_stride > 0),
+                   "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
+  switch (layout) {
+    case LAY_NT: return launch<LAY_NT>(a, epi, splits, stream);
+    case LAY_NN: return launch<LAY_NN>(a, epi, splits, stream);
+    case LAY_TN: return launch<LAY_TN>(a, epi, splits, stream);
+  }
+  reed_set_error("reed_gemm: unknown layout %d", layout);
+  return REED_ERR_ARG;
+}

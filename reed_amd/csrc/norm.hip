@@ -259,6 +259,10 @@ struct HalfRow {
     for (int t = 0; t < TS; ++t)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[4 * NF + t]), rs, vo[NF + t] * 4, soff, 0);
   }
+#ifdef REED_FP32   // the "16-bit" arrays are fp32 arrays in this build (common.hpp): the same accesses as ld_f32 / st_f32
+  __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const { ld_f32(rs, soff, v); }
+  __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const { st_f32(rs, soff, v); }
+#else
   __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const {   // bf16 -> f32
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
@@ -282,6 +286,7 @@ struct HalfRow {
     for (int t = 0; t < TS; ++t)
       __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f2bf(v[4 * NF + t])), rs, vo[NF + t] * 2, soff, 0);
   }
+#endif
   // LDS (column partials): plain pointers
   __device__ __forceinline__ void st_lds(float* p, const float (&v)[NE]) const {
 #pragma unroll
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
     float* __restrict__ part, const bf16* __restrict__ y, const bf16* __restrict__ gate, long ldgate,
     bf16* __restrict__ dy, float* __restrict__ part_g, float* __restrict__ part_dy, int M, int T) {
   using HR = HalfRow<NF, TS>;
-  constexpr int NE = HR::NE, D = 128 * NE;
+  constexpr int NE = HR::NE, D = 128 * NE, HB = sizeof(bf16);   // HB: bytes per element of the 16-bit (fp32 build: 32-bit) arrays
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 groups][2][D], then row sums [4][4][2 halves][2]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row offsets stay in SGPRs
@@ -308,12 +313,12 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
   const long blk0 = (long)blockIdx.x * 16;      // first row of the block
   const long smp = blk0 / T;
   const __amdgpu_buffer_rsrc_t rsX = row_rsrc(x + blk0 * D, 16 * D * 4), rsDX = row_rsrc(dx + blk0 * D, 16 * D * 4),
-                               rsDH = row_rsrc(dh + blk0 * D, 16 * D * 2),
-                               rsY = row_rsrc(GATE ? y + blk0 * D : nullptr, 16 * D * 2),
-                               rsDY = row_rsrc(GATE ? dy + blk0 * D : nullptr, 16 * D * 2);
+                               rsDH = row_rsrc(dh + blk0 * D, 16 * D * HB),
+                               rsY = row_rsrc(GATE ? y + blk0 * D : nullptr, 16 * D * HB),
+                               rsDY = row_rsrc(GATE ? dy + blk0 * D : nullptr, 16 * D * HB);
   // per-sample constants: bf16(1 + scale) and the gate (bf16 values held as f32)
   float s1[NE], gv[GATE ? NE : 1], ps[NE], pq[NE], pg[GATE ? NE : 1], pd[GATE ? NE : 1];
-  hr.ld_bf(row_rsrc(scale + smp * ldmod, D * 2), 0, s1);
+  hr.ld_bf(row_rsrc(scale + smp * ldmod, D * HB), 0, s1);
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     s1[e] = bfround(1.f + s1[e]);
@@ -321,16 +326,16 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
     pq[e] = 0.f;
     if (GATE) { pg[e] = 0.f; pd[e] = 0.f; }
   }
-  if constexpr (GATE) hr.ld_bf(row_rsrc(gate + smp * ldgate, D * 2), 0, gv);
+  if constexpr (GATE) hr.ld_bf(row_rsrc(gate + smp * ldgate, D * HB), 0, gv);
 #pragma unroll 1
   for (int rr = 0; rr < 4; ++rr) {
     const int lr = rg * 4 + rr;      // row inside the block; global row < M: the grid is M / 16 blocks, M % 16 == 0
     const float mu = mean[blk0 + lr], r = rstd[blk0 + lr];
     float xh[NE], gy[NE], o[NE], yin[GATE ? NE : 1];
     hr.ld_f32(rsX, lr * D * 4, xh);   // all of the row's loads first
-    hr.ld_bf(rsDH, lr * D * 2, gy);
+    hr.ld_bf(rsDH, lr * D * HB, gy);
     hr.ld_f32(rsDX, lr * D * 4, o);
-    if constexpr (GATE) hr.ld_bf(rsY, lr * D * 2, yin);
+    if constexpr (GATE) hr.ld_bf(rsY, lr * D * HB, yin);
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
         pg[e] += bfround(dg * yin[e]);
         pd[e] += bfround(o[e]);
       }
-      hr.st_bf(rsDY, lr * D * 2, o);
+      hr.st_bf(rsDY, lr * D * HB, o);
     }
   }
   // column partials of the 16 rows: per row group in registers, summed over the 4 groups in a fixed order

@@ -346,6 +346,29 @@ def resample_abs_pos_embed(posemb, new_size, num_prefix_tokens=1):
     return torch.cat([pre, g], dim=1)
 
 
+_MOCO_MISNAMED = (("blocks.13.norm13", "norm13", "norm1"), ("blocks.13.mlp.fc13", "fc13", "fc1"),
+                  ("blocks.14.norm14", "norm14", "norm2"), ("blocks.14.mlp.fc14", "fc14", "fc2"))
+
+
+def mocov3_key(k):
+    """Key of a published MoCo-v3 checkpoint -> tower parameter name, or None for a tensor the tower does not hold
+    (image/utils.py:27-52 fix_mocov3_state_dict): only `module.base_encoder.*` survives (the momentum encoder and the
+    predictor are dropped; a plain state dict without that prefix is taken as it is), the projection head (`head.*`,
+    `fc.*`) is dropped, and the four mis-named entries of the ViT-L file are repaired — there `blocks.13.norm1 / mlp.fc1`
+    are stored as `norm13 / fc13` and `blocks.14.norm2 / mlp.fc2` as `norm14 / fc14`."""
+    pre = "module.base_encoder."
+    if k.startswith(pre):
+        k = k[len(pre):]
+    elif k.startswith("module."):
+        return None
+    for where, bad, good in _MOCO_MISNAMED:
+        if where in k:
+            k = k.replace(bad, good)
+    if "head" in k or k.split(".")[0] == "fc":
+        return None
+    return k
+
+
 def load_vit_encoder(enc_type, ckpt_path, device):
     """`jepa-vit-h`, `mocov3-vit-{b,l}`, `mae-vit-l` of image/utils.py:73-82,133-160 from the checkpoint files the reference
     names (ckpts/ijepa_vith.pth: state_dict['encoder'] with a 'module.' prefix; ckpts/mocov3_vit{b,l}.pth: ['state_dict']
@@ -361,11 +384,14 @@ def load_vit_encoder(enc_type, ckpt_path, device):
             sd = sd[key]
             break
     out = {}
+    moco = enc_type.startswith("mocov3")
     for k, v in sd.items():
-        for pre in ("module.base_encoder.", "module."):
-            if k.startswith(pre):
-                k = k[len(pre):]
-                break
+        if moco:
+            k = mocov3_key(k)
+            if k is None:
+                continue
+        elif k.startswith("module."):
+            k = k[len("module."):]
         out[k] = v.float() if torch.is_floating_point(v) else v
     if "pos_embed" in out and out["pos_embed"].shape != enc.pos_embed.shape:
         G = enc.image // enc.patch

@@ -37,12 +37,7 @@ class Engine:
         self.C = model.in_channels
         self.depth = model.depth
         self.NO = self.P * self.P * self.C
-        for n, v in (("hidden_size", self.D), ("mlp hidden", self.Hm), ("projector_dim", model.projector_dim)):
-            if v % 128:
-                raise ValueError(f"{n}={v} must be a multiple of 128 for the MFMA GEMM tiles")
-        for z in model.z_dims:
-            if z % 128:
-                raise ValueError(f"z_dim={z} must be a multiple of 128 for the MFMA GEMM tiles")
+        self._dims_ok = set()    # precisions whose shape restrictions this model has passed (_check_dims)
         split = model.encoder_depth_text is not None and model.encoder_depth_text != model.encoder_depth
         self.split = split
         self.tap_depth = [model.encoder_depth if (zt == "i" or not split) else model.encoder_depth_text
@@ -60,7 +55,23 @@ class Engine:
         self.wgrad_stream_max_tokens = int(os.environ.get("REED_WGRAD_STREAM_MAXTOK", "12288"))
         self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
         self.table_rows = model.num_classes + (1 if model.class_dropout_prob > 0 else 0)
+        self._hb = 2             # bytes per element of the current build's operand arrays (set per forward / backward)
         self._err = None         # sticky device flag: a label outside the embedding table was seen (see check_errors)
+
+    def _check_dims(self, prec):
+        """Shape restrictions of the build that evaluates the model: the 16-bit MFMA tiles want every GEMM width in multiples
+        of 128; the fp32-operand build (csrc/gemm_f32.hip) guards every bound and only needs 4-element alignment."""
+        if prec in self._dims_ok:
+            return
+        q = 4 if prec == "fp32" else 128
+        what = "4 (fp32 operands)" if prec == "fp32" else "128 for the MFMA GEMM tiles"
+        for n, v in (("hidden_size", self.D), ("mlp hidden", self.Hm), ("projector_dim", self.m.projector_dim)):
+            if v % q:
+                raise ValueError(f"{n}={v} must be a multiple of {what}")
+        for z in self.m.z_dims:
+            if z % q:
+                raise ValueError(f"z_dim={z} must be a multiple of {what}")
+        self._dims_ok.add(prec)
 
     def check_errors(self):
         """Raise if any forward since the last check saw a class label outside the embedding table (the reference's
@@ -75,7 +86,7 @@ class Engine:
 
     # ---- pointers into the arenas -------------------------------------------------
     def W(self, name):
-        return self._shadow.data_ptr() + 2 * self.L.off(name)
+        return self._shadow.data_ptr() + self._hb * self.L.off(name)
 
     def Wf(self, name):
         return self.A.master.data_ptr() + 4 * self.L.off(name)
@@ -112,8 +123,10 @@ class Engine:
         if C != self.C or HW != m.input_size or x.shape[-2] != HW:
             raise ValueError(f"input {tuple(x.shape)} does not match (N,{self.C},{m.input_size},{m.input_size})")
         M = B * T
+        self._check_dims(prec)
         self._shadow = self.A.ensure_shadow(prec)
         hdt = ops.half_dtype(prec)
+        hb = self._hb = hdt.itemsize    # bytes per element of the operand / activation arrays (2; 4 in the fp32-operand build)
         pend = self.A.pending   # parameter buckets an overlapped optimiser step is still rewriting (optim.py)
         if "all" in pend:
             self.A.wait_all()
@@ -163,7 +176,7 @@ class Engine:
         n_head = kh * 6 * D if kh else Nall
         if pend:
             self.A.wait("ada_head")
-        ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * L.ada_w_off, B, n_head, D, mod, D, D, Nall, bias=sp + 2 * L.ada_b_off)
+        ops.gemm(NT, EPI_BF16, silu_c, sp + hb * L.ada_w_off, B, n_head, D, mod, D, D, Nall, bias=sp + hb * L.ada_b_off)
         if need_grad:
             tp.sin, tp.t1p, tp.t1, tp.labels_eff, tp.c, tp.silu_c, tp.mod = sin, t1p, t1, labels_eff, c, silu_c, mod
 
@@ -175,11 +188,11 @@ class Engine:
         zs_by_proj = {}
         for i in range(self.depth):
             b = f"blocks.{i}."
-            mb = mp + 2 * (i * 6 * D)
+            mb = mp + hb * (i * 6 * D)
             if kh and i == kh:
                 self.A.wait("ada_tail")
-                ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * (L.ada_w_off + n_head * D), B, Nall - n_head, D, mp + 2 * n_head,
-                         D, D, Nall, bias=sp + 2 * (L.ada_b_off + n_head))
+                ops.gemm(NT, EPI_BF16, silu_c, sp + hb * (L.ada_w_off + n_head * D), B, Nall - n_head, D, mp + hb * n_head,
+                         D, D, Nall, bias=sp + hb * (L.ada_b_off + n_head))
                 kh = 0
             if pend:
                 self.A.wait(f"block{i}")
@@ -194,7 +207,7 @@ class Engine:
                 mean1 = rstd1 = mean2 = rstd2 = lse = None
                 xmid = xb if xcur is xa else xa
                 xout = xcur  # safe: fc2's epilogue reads R=xmid, writes xout; xcur is dead after proj
-            ops.ln_modulate_fwd(xcur, mb, mb + 2 * D, Nall, h, mean1, rstd1, M, D, T)
+            ops.ln_modulate_fwd(xcur, mb, mb + hb * D, Nall, h, mean1, rstd1, M, D, T)
             ops.gemm(NT, EPI_BF16, h, self.W(b + "attn.qkv.weight"), M, 3 * D, D, qkv, D, D, 3 * D,
                      bias=self.W(b + "attn.qkv.bias"))
             qkv_a, qstats = qkv, None
@@ -205,12 +218,12 @@ class Engine:
                                 self.Wf(b + "attn.k_norm.weight"), self.Wf(b + "attn.k_norm.bias"), qkv_a, qstats, M, H, hd)
             ops.attention_fwd(qkv_a, o, lse, B, T, H, hd)
             ops.gemm(NT, EPI_GATE_RES, o, self.W(b + "attn.proj.weight"), M, D, D, xmid, D, D, D, C2=y1, ldc2=D,
-                     R=xcur, ldr=D, bias=self.W(b + "attn.proj.bias"), gate=mb + 4 * D, ldgate=Nall, rows_per_gate=T)
-            ops.ln_modulate_fwd(xmid, mb + 6 * D, mb + 8 * D, Nall, h2, mean2, rstd2, M, D, T)
+                     R=xcur, ldr=D, bias=self.W(b + "attn.proj.bias"), gate=mb + 2 * hb * D, ldgate=Nall, rows_per_gate=T)
+            ops.ln_modulate_fwd(xmid, mb + 3 * hb * D, mb + 4 * hb * D, Nall, h2, mean2, rstd2, M, D, T)
             ops.gemm(NT, EPI_GELU, h2, self.W(b + "mlp.fc1.weight"), M, Hm, D, a1, D, D, Hm, C2=u, ldc2=Hm,
                      bias=self.W(b + "mlp.fc1.bias"))
             ops.gemm(NT, EPI_GATE_RES, u, self.W(b + "mlp.fc2.weight"), M, D, Hm, xout, Hm, Hm, D, C2=y2, ldc2=D,
-                     R=xmid, ldr=D, bias=self.W(b + "mlp.fc2.bias"), gate=mb + 10 * D, ldgate=Nall, rows_per_gate=T)
+                     R=xmid, ldr=D, bias=self.W(b + "mlp.fc2.bias"), gate=mb + 5 * hb * D, ldgate=Nall, rows_per_gate=T)
             if need_grad:
                 tp.blocks.append(types.SimpleNamespace(x=xcur, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, qkv_a=qkv_a,
                                                        qstats=qstats, o=o, lse=lse,
@@ -224,15 +237,15 @@ class Engine:
         # -- final layer
         if kh:   # depth <= ADA_HEAD_BLOCKS: the tail (final layer's rows) was never launched
             self.A.wait("ada_tail")
-            ops.gemm(NT, EPI_BF16, silu_c, sp + 2 * (L.ada_w_off + n_head * D), B, Nall - n_head, D, mp + 2 * n_head,
-                     D, D, Nall, bias=sp + 2 * (L.ada_b_off + n_head))
+            ops.gemm(NT, EPI_BF16, silu_c, sp + hb * (L.ada_w_off + n_head * D), B, Nall - n_head, D, mp + hb * n_head,
+                     D, D, Nall, bias=sp + hb * (L.ada_b_off + n_head))
         if pend:
             self.A.wait_all()
         out = f32(B, C, HW, HW)
         meanF = f32(M) if need_grad else None
         rstdF = f32(M) if need_grad else None
-        mf = mp + 2 * (self.depth * 6 * D)
-        ops.final_layer_fwd(xcur, mf, mf + 2 * D, Nall, self.W("final_layer.linear.weight"),
+        mf = mp + hb * (self.depth * 6 * D)
+        ops.final_layer_fwd(xcur, mf, mf + hb * D, Nall, self.W("final_layer.linear.weight"),
                             self.W("final_layer.linear.bias"), out, meanF, rstdF, B, T, D, C, P)
         if need_grad:
             tp.x_last, tp.meanF, tp.rstdF = xcur, meanF, rstdF
@@ -347,6 +360,7 @@ class Engine:
         M = B * T
         dev = dout.device
         Nall = L.ada_rows
+        hb = self._hb = hdt.itemsize
         self.A.ensure_grad()
         acc = self.grad_live
         mp = tp.mod.data_ptr()
@@ -366,9 +380,9 @@ class Engine:
             side = self._side
         dout = dout.contiguous().float()
         # -- final layer
-        mf = mp + 2 * (self.depth * 6 * D)
+        mf = mp + hb * (self.depth * 6 * D)
         hbuf, dlin, dh = bf(M, D), bf(M, self.NO), bf(M, D)
-        ops.final_layer_bwd_rows(dout, tp.x_last, tp.meanF, tp.rstdF, mf, mf + 2 * D, Nall,
+        ops.final_layer_bwd_rows(dout, tp.x_last, tp.meanF, tp.rstdF, mf, mf + hb * D, Nall,
                                  self.W("final_layer.linear.weight"), hbuf, dlin, dh, B, T, D, C, P)
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         partF = f32(M // 16, 2, D)
@@ -388,10 +402,10 @@ class Engine:
             nb_ = tp.blocks[nxt]
             dy_, pg_ = bf(M, D), f32(M // 16, D)
             ops.ln_modulate_bwd_gate(dh_, x_, mean_, rstd_, scale_ptr, Nall, dx, part_, nb_.y2,
-                                     mp + 2 * (nxt * 6 * D) + 10 * D, Nall, dy_, pg_, None, M, D, T)
+                                     mp + hb * (nxt * 6 * D + 5 * D), Nall, dy_, pg_, None, M, D, T)
             return dy_, pg_
 
-        pre = ln_bwd(dh, tp.x_last, tp.meanF, tp.rstdF, mf + 2 * D, partF, self.depth - 1)
+        pre = ln_bwd(dh, tp.x_last, tp.meanF, tp.rstdF, mf + hb * D, partF, self.depth - 1)
         wsf = self.ws(ops.smallk_ws_floats(D, max(self.NO, C * P * P)), dev)
         ops.smallk_wgrad(hbuf, False, dlin, wsf, self.G("final_layer.linear.weight"), None,
                          self.G("final_layer.linear.bias"), M, D, self.NO, 1, acc)
@@ -426,7 +440,7 @@ class Engine:
 
         def ada_wgrad(i):
             c0, rows = ada_rows(i)
-            ops.gemm(TN, EPI_F32, dmp + 2 * c0, tp.silu_c, rows, D, B, gp + 4 * (L.ada_w_off + c0 * D), Nall, D, D,
+            ops.gemm(TN, EPI_F32, dmp + hb * c0, tp.silu_c, rows, D, B, gp + 4 * (L.ada_w_off + c0 * D), Nall, D, D,
                      dbias=gp + 4 * (L.ada_b_off + c0), accumulate=acc)
 
         def ada_gather(i):   # block i's dmod rows are final: scale, pack [b, rows] contiguously, all-gather
@@ -460,14 +474,14 @@ class Engine:
                         self.reducer.ready("projectors")
             bk = tp.blocks[i]
             b = f"blocks.{i}."
-            mb = mp + 2 * (i * 6 * D)
+            mb = mp + hb * (i * 6 * D)
             # MLP branch (its gate backward usually came with the previous LayerNorm backward)
             # (bias gradients of fc2 / proj = column sums of dy2 / dy1: fused into their weight-gradient GEMMs)
             if pre is not None:
                 dy2, pg2 = pre
             else:
                 pg2, dy2 = f32(M // 16, D), bf(M, D)
-                ops.gate_bwd(dx, bk.y2, mb + 10 * D, Nall, dy2, pg2, M, D, T)
+                ops.gate_bwd(dx, bk.y2, mb + 5 * hb * D, Nall, dy2, pg2, M, D, T)
             wg = [] if group_wgrad else None   # the block's four weight gradients: one launch at the end of the block
             if wg is not None:
                 wg.append((dy2, bk.u, b + "mlp.fc2.weight", D, Hm))
@@ -485,7 +499,7 @@ class Engine:
             # LN2 backward + the attention branch's gate backward in one pass over dx
             pl2 = f32(M // 16, 2, D)
             pg1, dy1 = f32(M // 16, D), bf(M, D)
-            ops.ln_modulate_bwd_gate(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 8 * D, Nall, dx, pl2, bk.y1, mb + 4 * D, Nall,
+            ops.ln_modulate_bwd_gate(dh2, bk.xmid, bk.mean2, bk.rstd2, mb + 4 * hb * D, Nall, dx, pl2, bk.y1, mb + 2 * hb * D, Nall,
                                      dy1, pg1, None, M, D, T)
             if wg is not None:
                 wg.append((dy1, bk.o, b + "attn.proj.weight", D, D))
@@ -512,7 +526,7 @@ class Engine:
             dh1 = do  # reuse
             self._dgrad(EPI_BF16, dqkv, b + "attn.qkv.weight", M, 3 * D, D, dh1)
             pl1 = f32(M // 16, 2, D)
-            pre = ln_bwd(dh1, bk.x, bk.mean1, bk.rstd1, mb + 2 * D, pl1, i - 1)
+            pre = ln_bwd(dh1, bk.x, bk.mean1, bk.rstd1, mb + hb * D, pl1, i - 1)
             o6 = i * 6 * D
             p1, p2 = pl1.data_ptr(), pl2.data_ptr()
             ops.reduce_mod_parts([(p1, 2 * D, o6), (p1 + 4 * D, 2 * D, o6 + D), (pg1.data_ptr(), D, o6 + 2 * D),
@@ -539,7 +553,7 @@ class Engine:
             red.gather_sync()
             for i in reversed(range(self.depth + 1)):   # rank-major [world * b, rows] factors: K = the global batch
                 c0, rows = ada_rows(i)
-                ops.gemm(TN, EPI_F32, g_recv.data_ptr() + 2 * W * B * c0, s_all, rows, D, W * B,
+                ops.gemm(TN, EPI_F32, g_recv.data_ptr() + hb * W * B * c0, s_all, rows, D, W * B,
                          gp + 4 * (L.ada_w_off + c0 * D), rows, D, D, dbias=gp + 4 * (L.ada_b_off + c0), accumulate=False)
         elif not split_ada:
             ops.gemm(TN, EPI_F32, dmod, tp.silu_c, Nall, D, B, gp + 4 * L.ada_w_off, Nall, D, D,
@@ -548,7 +562,7 @@ class Engine:
         split = min(64, max(1, ksteps // 8))
         slab = B * D
         wsd = self.ws(split * slab, dev)
-        ops.gemm(NN, EPI_F32, dmod, sp + 2 * L.ada_w_off, B, D, Nall, wsd, Nall, D, D, split_k=split, slab_stride=slab)
+        ops.gemm(NN, EPI_F32, dmod, sp + hb * L.ada_w_off, B, D, Nall, wsd, Nall, D, D, split_k=split, slab_stride=slab)
         per = (ksteps + split - 1) // split
         eff = (ksteps + per - 1) // per
         dsilu = f32(B, D)

@@ -65,8 +65,9 @@ def build_parser():
     parser.add_argument("--global-seed", type=int, default=0)
     # The reference samples with an fp32 model and, with --tf32 (its default), TF32 matmuls (generate.py:41,183: 10-bit
     # mantissa operands, fp32 accumulation).  The MFMA equivalent at full rate is IEEE-half operands with fp32 accumulation:
-    # --tf32 selects the fp16 build of the kernels for the model evaluations (libreed_hip_f16.so), --no-tf32 too (there is no
-    # fp32-operand path: the flag is accepted for compatibility).  --sample-precision bf16 evaluates in the training precision.
+    # --tf32 selects the fp16 build of the kernels for the model evaluations (libreed_hip_f16.so).  --no-tf32 is the reference's
+    # true-fp32 mode and selects the fp32-operand build (libreed_hip_f32.so: v_mfma_f32_32x32x2_f32, fp32 activations, 1/16 of the
+    # 16-bit MFMA rate) — never a silent substitution of narrower arithmetic.  --sample-precision overrides either.
     parser.add_argument("--tf32", action=argparse.BooleanOptionalAction, default=True)
     parser.add_argument("--ckpt", type=str, default=None, help="Optional path to a SiT checkpoint.")
     parser.add_argument("--sample-dir", type=str, default="samples")
@@ -94,10 +95,46 @@ def build_parser():
     parser.add_argument("--vae-ckpt", type=str, default=None,
                         help="local sd-vae-ft-{ema,mse} checkpoint (diffusers directory or its diffusion_pytorch_model file): "
                              "decode with the in-repo decoder instead of the diffusers package")
-    parser.add_argument("--sample-precision", type=str, choices=["fp16", "bf16"], default="fp16",
-                        help="16-bit operand type of the model evaluations: fp16 = 10-bit mantissa (the reference's TF32), "
-                             "bf16 = the training precision")
+    parser.add_argument("--sample-precision", type=str, choices=["fp16", "bf16", "fp32"], default=None,
+                        help="operand type of the model evaluations: fp16 = 10-bit mantissa (the reference's TF32; the default "
+                             "with --tf32), fp32 = the reference's --no-tf32 arithmetic (the default with --no-tf32), bf16 = the "
+                             "training precision")
     return parser
+
+
+def sample_precision(args):
+    """--sample-precision if given; else what the reference's --tf32 / --no-tf32 means on this hardware (generate.py:41,183)."""
+    if getattr(args, "sample_precision", None):
+        return args.sample_precision
+    return "fp16" if args.tf32 else "fp32"
+
+
+def finite_or_retry(sampler, kw, model):
+    """Run one batch.  IEEE half saturates at 65504 where bf16 and the reference's TF32 do not: a checkpoint with large
+    activation outliers would give inf / nan latents silently.  One isfinite reduction per batch (one host
+    sync per several hundred model evaluations); a non-finite fp16 batch is re-sampled once with bf16 operands from the same
+    latents, labels and device RNG state (the SDE sampler draws noise per step), and anything still non-finite raises."""
+    dev = kw["latents"].device
+    rng = torch.cuda.get_rng_state(dev)
+    samples = sampler(**kw).to(torch.float32)
+    if bool(torch.isfinite(samples).all()):
+        return samples
+    if model.precision != "fp16":
+        raise FloatingPointError(f"non-finite latents from the {model.precision} sampler: the checkpoint or the inputs are broken")
+    import warnings
+    warnings.warn("reed_amd.generate: non-finite latents with fp16 operands (half saturates at 65504); re-sampling this batch "
+                  "with bf16 operands")
+    model.precision = "bf16"
+    after = torch.cuda.get_rng_state(dev)
+    torch.cuda.set_rng_state(rng, dev)
+    try:
+        samples = sampler(**kw).to(torch.float32)
+    finally:
+        model.precision = "fp16"
+        torch.cuda.set_rng_state(after, dev)      # later batches draw what they would have drawn without the retry
+    if not bool(torch.isfinite(samples).all()):
+        raise FloatingPointError("non-finite latents with fp16 AND bf16 operands: the checkpoint or the inputs are broken")
+    return samples
 
 
 def main(args):
@@ -133,7 +170,7 @@ def main(args):
             state_dict.pop(k)
     model.load_state_dict(state_dict, strict=False)
     model.eval()
-    model.precision = args.sample_precision
+    model.precision = sample_precision(args)
     assert args.cfg_scale >= 1.0, "In almost all cases, cfg_scale be >= 1.0"
     if args.cfg_scale > 1.0:
         assert args.num_classes == 1000, "the samplers hard-code the null class id 1000 (samplers.py:59)"
@@ -177,9 +214,9 @@ def main(args):
                   guidance_low=args.guidance_low, guidance_high=args.guidance_high, path_type=args.path_type,
                   prediction=args.prediction)
         if args.mode == "sde":
-            samples = euler_maruyama_sampler(**kw).to(torch.float32)
+            samples = finite_or_retry(euler_maruyama_sampler, kw, model)
         elif args.mode == "ode":
-            samples = euler_sampler(**kw).to(torch.float32)
+            samples = finite_or_retry(euler_sampler, kw, model)
         else:
             raise NotImplementedError()
         if vae is not None:

@@ -67,7 +67,7 @@ class _Cosine(torch.autograd.Function):
         Z = zt.shape[-1]
         loss = torch.empty(B, dtype=torch.float32, device=zt.device)
         rowdot = torch.empty(B * T, dtype=torch.float32, device=zt.device)
-        prev = ops.use("fp16" if zt.dtype == torch.float16 else "bf16")   # the projector output's 16-bit type picks the build
+        prev = ops.use(ops.precision_of(zt.dtype))   # the projector output's 16-bit type picks the build
         try:
             ops.cosine_fwd(zt, z, rowdot, loss, B, T, Z)
         finally:
@@ -81,7 +81,7 @@ class _Cosine(torch.autograd.Function):
         zt, z = ctx.saved_tensors
         B, T, Z = ctx.dims
         dzt = torch.empty_like(zt)
-        prev = ops.use("fp16" if zt.dtype == torch.float16 else "bf16")
+        prev = ops.use(ops.precision_of(zt.dtype))
         try:
             ops.cosine_bwd(zt, z, g.contiguous().float(), dzt, B, T, Z)
         finally:
@@ -182,8 +182,9 @@ class SILoss:
                 assert z_tilde.ndim == 2, "Pooling to 2D to align with text embeddings."
             if w == 0.0:
                 wts = torch.ones_like(wts)
-            if z_tilde.dtype not in (torch.bfloat16, torch.float16):  # foreign model returning fp32 projector outputs
-                z_tilde = z_tilde.to(torch.bfloat16)
+            if z_tilde.dtype not in (torch.bfloat16, torch.float16) and getattr(model, "precision", None) != "fp32":
+                z_tilde = z_tilde.to(torch.bfloat16)   # foreign model returning fp32 projector outputs (a reed_amd model
+                #                                          at precision "fp32" returns fp32 on purpose: --mixed-precision no)
             curr_loss = _Cosine.apply(z_tilde.contiguous(), z.to(images.device).contiguous().float())  # [B]
             weighted_loss = (curr_loss * wts).mean()  # [B] x [B,1,1,1] broadcast, as the reference
             proj_loss = proj_loss + weighted_loss

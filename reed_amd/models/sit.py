@@ -92,8 +92,10 @@ class SiT(nn.Module):
         self._build_tree(shapes)
         self.initialize_weights()
         self.force_drop_mask = None  # tests: bool [N] replacing LabelEmbedder's torch.rand draw
-        # 16-bit operand type of the kernels: "bf16" (training; the reference under accelerate bf16) or "fp16" (inference only:
-        # the sampling path at the mantissa of the reference's TF32, generate.py --sample-precision; csrc/common.hpp REED_FP16)
+        # operand type of the kernels = which build of the library evaluates this model (reed_amd/_lib.py): "bf16" (the reference
+        # under accelerate bf16), "fp16" (IEEE half: sampling at the mantissa of the reference's TF32, and --mixed-precision fp16
+        # training with the on-device GradScaler; csrc/common.hpp REED_FP16) or "fp32" (fp32 operands and activations on the
+        # fp32 MFMA: --mixed-precision no / generate.py --no-tf32; REED_FP32)
         self.precision = "bf16"
 
     # ------------------------------------------------------------------ structure

@@ -41,14 +41,24 @@ _PRECISION = "bf16"
 def use(precision):
     """Select the library build for the following calls; returns the previous selection."""
     global _PRECISION
-    if precision not in ("bf16", "fp16"):
-        raise ValueError(f"precision {precision!r}: 'bf16' or 'fp16'")
+    if precision not in _lib.PRECISIONS:
+        raise ValueError(f"precision {precision!r}: one of {_lib.PRECISIONS}")
     prev, _PRECISION = _PRECISION, precision
     return prev
 
 
+_HALF_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+_PREC_OF_DTYPE = {v: k for k, v in _HALF_DTYPE.items()}
+
+
 def half_dtype(precision=None):
-    return torch.float16 if (precision or _PRECISION) == "fp16" else torch.bfloat16
+    """torch dtype of the build's operand / activation arrays ("the 16-bit type"; float32 in the fp32-operand build)."""
+    return _HALF_DTYPE[precision or _PRECISION]
+
+
+def precision_of(dtype):
+    """The build whose operand type is `dtype` (a projector output's dtype names the build that produced it)."""
+    return _PREC_OF_DTYPE[dtype]
 
 
 def _call(name, *args):
@@ -152,6 +162,8 @@ def gemm_force_tile(tile):
     (tests and A/B timing).  Set in both builds of the library."""
     for prec in ("bf16", "fp16"):
         _lib.load(prec).reed_gemm_force_tile(int(tile))
+    if "fp32" in _lib.loaded():
+        _lib.load("fp32").reed_gemm_force_tile(int(tile))
 
 
 WGRAD_SLOTS = 512  # resident 128x128 blocks: 256 CUs x 2 (64 KiB LDS, <=128 VGPRs... see gemm.hip launch bounds)
@@ -162,14 +174,14 @@ def set_cu_reserve(n):
     """Plan the GEMM grids for n fewer CUs (RCCL's channels hold CUs while a gradient bucket is in flight)."""
     global _CU_RESERVE
     _CU_RESERVE = max(0, int(n))
-    for prec in ("bf16", "fp16"):
+    for prec in ("bf16", "fp16") + (("fp32",) if "fp32" in _lib.loaded() else ()):
         _lib.load(prec).reed_set_cu_reserve(_CU_RESERVE)
 
 
 def set_concurrent_comm(on):
     """Collectives run beside the GEMMs from now on (data-parallel training): the library keeps to kernels that degrade
     gracefully when RCCL's channels hold CUs (csrc/gemm256.hip:reed_set_concurrent_comm)."""
-    for prec in ("bf16", "fp16"):
+    for prec in ("bf16", "fp16") + (("fp32",) if "fp32" in _lib.loaded() else ()):
         _lib.load(prec).reed_set_concurrent_comm(1 if on else 0)
 
 
@@ -202,7 +214,7 @@ def wgrad_group_fits(shapes, min_fill=0.85):
     workgroup slots to at least min_fill (SiT-XL/2: exactly 512 of 512; SiT-L/2 fills 384 = 75 % and measured 2 % slower
     than its wave-quantised split-K plan; smaller models are far below)."""
     import os
-    if os.environ.get("REED_WGRAD_GROUP", "1") == "0":
+    if os.environ.get("REED_WGRAD_GROUP", "1") == "0" or _PRECISION == "fp32":   # the grouped launch is a 16-bit MFMA kernel
         return False
     n = wgrad_group_blocks(shapes)
     slots = wgrad_slots()

@@ -107,7 +107,7 @@ class FusedAdamWEMA:
                 for name, b, e in self._chunks:
                     nt = max(0, min(e, L.n_train) - b)
                     ops.adamw_ema(pp + 4 * b, gp + 4 * b if nt else None, mp + 4 * b if nt else None,
-                                  vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + 2 * b, nt,
+                                  vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + A.shadow.element_size() * b, nt,
                                   e - b, nc, self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay,
                                   scaler_state=st)
                     ev = torch.cuda.Event()

@@ -69,7 +69,9 @@ class GradReducer:
                binding (a per-rank decision would leave the ranks issuing mismatched collectives: a hang, not an error).
     Two forms of the reduction (`REED_COMM_ALGO`): `allreduce` (default) = one ncclAllReduce(avg) per bucket;
     `rsag` = ncclReduceScatter(avg) + ncclAllGather on the bucket, the direct form SURVEY.md §5 derives for the fully
-    connected xGMI node. Same values either way (fp32 sums in RCCL's own order)."""
+    connected xGMI node. Both average in fp32, but in RCCL's own summation order per form: the low bits of the averaged
+    gradients may differ between the two, so the form is FIXED for a run (and from run to run) unless the caller asks for the
+    run-time measurement with REED_COMM_ALGO=auto (trainer.TrainStep)."""
 
     def __init__(self, model, rank=None, world=None):
         self.rank = dist.get_rank() if rank is None else rank
@@ -87,8 +89,10 @@ class GradReducer:
         self._gbuf = {}
         mode = os.environ.get("REED_COMM", "torch")
         self.algo = os.environ.get("REED_COMM_ALGO", "allreduce")
+        if self.algo == "auto":     # trainer.TrainStep measures the two forms in its first steps; until then the default
+            self.algo = "allreduce"
         if self.algo not in ("allreduce", "rsag"):
-            raise ValueError(f"REED_COMM_ALGO={self.algo!r}: expected 'allreduce' or 'rsag'")
+            raise ValueError(f"REED_COMM_ALGO={self.algo!r}: expected 'allreduce', 'rsag' or 'auto'")
         self.timing = None       # per-bucket event pairs when bench.py asks for the exposed-communication diagnosis
         if mode == "native":
             err = None
@@ -127,11 +131,20 @@ class GradReducer:
     def _init_native(self):
         L = self._lib
         idbuf = ctypes.create_string_buffer(128)
+        obj = [b""]
+        id_err = None
         if self.rank == 0:
-            _lib.check(L.reed_comm_unique_id(idbuf), "comm_unique_id")
-        obj = [bytes(idbuf.raw)]
+            # a failure here must not leave the other ranks blocked in the broadcast below while rank 0 goes on to the
+            # agreement all-reduce: rank 0 still broadcasts, an EMPTY id, and every rank raises after it
+            try:
+                _lib.check(L.reed_comm_unique_id(idbuf), "comm_unique_id")
+                obj = [bytes(idbuf.raw)]
+            except RuntimeError as e:
+                id_err = e
         if self.world > 1:
             dist.broadcast_object_list(obj, src=0)
+        if len(obj[0]) != 128:
+            raise RuntimeError(f"rank 0 could not create an RCCL unique id ({id_err})")
         comm = ctypes.c_void_p()
         _lib.check(L.reed_comm_init(obj[0], self.rank, self.world, ctypes.byref(comm)), "comm_init")
         self.comm = comm

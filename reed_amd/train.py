@@ -6,9 +6,9 @@
 Same flag surface as image/train.py:483-555 (every flag name, default and choice kept), same per-step arithmetic
 (:349 sample_posterior, :363-385 schedules, :387-412 loss/clip/AdamW/EMA), same checkpoint dict
 {"model","ema","opt","args","steps"} (:418-429) and resume rule (:280-291). The accelerate/DDP machinery is replaced
-by reed_amd.parallel.GradReducer (RCCL over xGMI, bucketed, overlapped with backward); mixed precision is always the
-16-bit-MFMA/fp32-master scheme (`--mixed-precision bf16`, or "fp16" = IEEE-half operands + dynamic loss scaling; "no" is
-rejected: there is no fp32 GEMM path).
+by reed_amd.parallel.GradReducer (RCCL over xGMI, bucketed, overlapped with backward); mixed precision is the
+16-bit-MFMA/fp32-master scheme (`--mixed-precision bf16`, or "fp16" = IEEE-half operands + dynamic loss scaling) or, with
+`--mixed-precision no`, fp32 operands and activations on the fp32 matrix instruction (the fp32-operand build of the library).
 
 Deliberate fixes of reference defects: `--enc-type None` = alignment off (§9-4); the preview
 sampling at step 1 / every --sampling-steps runs only with --vae-ckpt (a local SD-VAE checkpoint, reed_amd/vae.py) and writes
@@ -172,10 +172,6 @@ def main(args):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=device)
     is_main = rank == 0
-    if args.mixed_precision == "no":
-        raise NotImplementedError("--mixed-precision no: the HIP path computes GEMMs with 16-bit operands (fp32 master "
-                                  "weights, fp32 accumulation): choose bf16 or fp16")
-
     curr_time = datetime.datetime.now().strftime("%Y%m%d_%H%M%S")
     exp_name = args.exp_name if args.resume_step > 0 else f"{args.exp_name}_{curr_time}"
     if world > 1:
@@ -241,7 +237,10 @@ def main(args):
     # accelerate's mixed_precision (train.py:141-151): "bf16" = bf16 operands (libreed_hip.so); "fp16" (the reference's default
     # and README recipe) = IEEE-half operands (libreed_hip_f16.so) with dynamic loss scaling (GradScaler defaults) in the
     # fused optimiser pass. Master weights, residual stream, LayerNorm, loss and optimiser state are fp32 either way.
-    model.precision = args.mixed_precision
+    # "no" (train.py:505) = no autocast at all: fp32 operands and activations on the fp32 matrix instruction
+    # (libreed_hip_f32.so, csrc/gemm_f32.hip: 1/16 of the 16-bit MFMA rate — the reference's own fp32 mode is as slow relative
+    # to its autocast modes).
+    model.precision = {"no": "fp32"}.get(args.mixed_precision, args.mixed_precision)
     ema = copy.deepcopy(model).to(device)
     ema.requires_grad_(False)
     loss_fn = SILoss(prediction=args.prediction, path_type=args.path_type, enc_names=enc_names,

@@ -68,24 +68,33 @@ class TrainStep:
         self._micro = 0
         # CU reserve for the GEMM grids under data parallelism (csrc/gemm256.hip:reed_num_cus): RCCL's channels hold CUs while
         # a bucket is in flight, and grids planned as exactly one round of all CUs then take two.  How many CUs RCCL takes
-        # depends on its version, topology and message size, so it is MEASURED: the first steps run with a reserve of
-        # 0 / 16 / 32 CUs (one settling step + one timed step each, events on the compute stream), the ranks agree on the
-        # fastest (MAX over ranks per candidate) and keep it.  REED_COMM_CUS=<n> fixes it, REED_COMM_CUS=off keeps 0.
-        # The same measurement then decides how a bucket is reduced when REED_COMM_ALGO is not set: one ncclAllReduce, or
-        # ncclReduceScatter + ncclAllGather (parallel.py) — two more steps at the reserve just chosen.
+        # depends on its version, topology and message size, so it can be MEASURED — opt-in (no 8-GPU run has
+        # validated it yet, and a measured choice makes runs differ in their kernel plans: any reserve > 0 leaves fewer than
+        # 512 workgroup slots, so the grouped weight-gradient launch gives way to the split-K path):
+        #   REED_COMM_CUS unset / off   reserve 0, nothing measured (the default; bit-reproducible run to run)
+        #   REED_COMM_CUS=<n>           reserve n
+        #   REED_COMM_CUS=auto          the first optimiser steps run with each candidate of REED_COMM_CUS_CANDIDATES (0,16,32):
+        #                               one settling step + REED_COMM_TUNE_STEPS (3) event-timed steps; per candidate the MEDIAN,
+        #                               MAX over ranks; the fastest is kept and logged on rank 0.  bench.py asks for this.
+        #   REED_COMM_ALGO=auto         afterwards the same measurement for the bucket form (ncclAllReduce vs ncclReduceScatter +
+        #                               ncclAllGather, parallel.py); otherwise the form stays what REED_COMM_ALGO names
+        #                               (default allreduce): the fp32 summation order is then fixed from run to run.
+        # Any failure inside the measurement's bookkeeping ends it with reserve 0 / allreduce on every rank (tune_error).
         self.cu_reserve = 0
         self.cu_tuning = None
+        self.tune_error = None
         self._tune = []
         self._tune_algo = False
-        mode = os.environ.get("REED_COMM_CUS", "auto")
+        mode = os.environ.get("REED_COMM_CUS", "off")
         if reducer is not None and reducer.active() and mode != "off":
             if mode == "auto":
                 cands = [int(v) for v in os.environ.get("REED_COMM_CUS_CANDIDATES", "0,16,32").split(",")]
-                self._tune = [(c, timed) for c in cands for timed in (False, True)]
+                nt = max(1, int(os.environ.get("REED_COMM_TUNE_STEPS", "3")))
+                self._tune = [(c, k) for c in cands for k in range(nt + 1)]   # k = 0: settling step, k >= 1: timed
                 self._tune_times = {}
-                self._tune_algo = "REED_COMM_ALGO" not in os.environ and hasattr(reducer, "algo")
+                self._tune_algo = os.environ.get("REED_COMM_ALGO") == "auto" and hasattr(reducer, "algo")
                 if self._tune_algo:
-                    self._tune += [("rsag", False), ("rsag", True)]
+                    self._tune += [("rsag", k) for k in range(nt + 1)]
             else:
                 self.cu_reserve = int(mode)
                 ops.set_cu_reserve(self.cu_reserve)
@@ -105,7 +114,7 @@ class TrainStep:
                 self.reducer.algo = "rsag"
             else:
                 ops.set_cu_reserve(tune[0])
-            if tune[1]:
+            if tune[1]:   # a timed step of this candidate (tune[1] == 0 is its settling step)
                 self._tune_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 self._tune_ev[0].record()
         if self.reducer is not None:
@@ -144,22 +153,50 @@ class TrainStep:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
+    def _tune_abort(self, err):
+        """Leave the measurement with the safe plan (reserve 0, all-reduce buckets).  Every rank runs the same bookkeeping
+        on the same schedule, so a deterministic failure ends it on all of them at the same step."""
+        self._tune = []
+        self.tune_error = repr(err)
+        self.cu_reserve = 0
+        ops.set_cu_reserve(0)
+        if self._tune_algo:
+            self.reducer.algo = "allreduce"
+
+    def _median_ms(self, cand):
+        ms = []
+        for e0, e1 in self._tune_times[cand]:
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        ms.sort()
+        return ms[len(ms) // 2]
+
     def _tune_step(self):
-        cand, timed = self._tune.pop(0)
-        if timed:
-            self._tune_ev[1].record()
-            self._tune_times[cand] = self._tune_ev
-        ms = lambda c: (self._tune_times[c][1].synchronize(), self._tune_times[c][0].elapsed_time(self._tune_times[c][1]))[1]  # noqa: E731
-        nxt = self._tune[0][0] if self._tune else None
-        if self.cu_tuning is None and (nxt is None or nxt == "rsag"):   # every reserve candidate is timed: keep the fastest
-            cands = sorted(c for c in self._tune_times if c != "rsag")
-            t = self._agree([ms(c) for c in cands])
-            best = min(range(len(cands)), key=lambda i: t[i])
-            self.cu_reserve = cands[best]
-            self.cu_tuning = {str(c): round(v, 3) for c, v in zip(cands, t)}
-            self._best_ms = t[best]
-            ops.set_cu_reserve(self.cu_reserve)
-        if not self._tune and self._tune_algo:                           # the bucket form at that reserve
-            t = self._agree([ms("rsag")])[0]
-            self.cu_tuning["rsag"] = round(t, 3)
-            self.reducer.algo = "rsag" if t < self._best_ms else "allreduce"
+        try:
+            cand, k = self._tune.pop(0)
+            if k:
+                self._tune_ev[1].record()
+                self._tune_times.setdefault(cand, []).append(self._tune_ev)
+            nxt = self._tune[0][0] if self._tune else None
+            if self.cu_tuning is None and (nxt is None or nxt == "rsag"):   # every reserve candidate is timed: keep the fastest
+                cands = sorted(c for c in self._tune_times if c != "rsag")
+                t = self._agree([self._median_ms(c) for c in cands])
+                best = min(range(len(cands)), key=lambda i: t[i])
+                self.cu_reserve = cands[best]
+                self.cu_tuning = {str(c): round(v, 3) for c, v in zip(cands, t)}
+                self._best_ms = t[best]
+                ops.set_cu_reserve(self.cu_reserve)
+                self._log(f"CU reserve {self.cu_reserve} kept (median ms per step, MAX over ranks: {self.cu_tuning})")
+            if not self._tune and self._tune_algo:                           # the bucket form at that reserve
+                t = self._agree([self._median_ms("rsag")])[0]
+                self.cu_tuning["rsag"] = round(t, 3)
+                self.reducer.algo = "rsag" if t < self._best_ms else "allreduce"
+                self._log(f"bucket form {self.reducer.algo} kept (rsag {t:.3f} ms vs allreduce {self._best_ms:.3f} ms)")
+        except Exception as e:   # never fatal: the safe plan on every rank
+            self._tune_abort(e)
+            self._log(f"measurement abandoned ({e!r}): CU reserve 0, all-reduce buckets")
+
+    def _log(self, msg):
+        if self.reducer is None or getattr(self.reducer, "rank", 0) == 0:
+            import sys
+            print(f"[reed_amd.TrainStep] {msg}", file=sys.stderr, flush=True)

@@ -76,7 +76,9 @@ def test_train_checkpoint_resume_generate(dev, tmp_path):
 def test_train_default_mixed_precision_is_fp16(dev, tmp_path):
     """No --mixed-precision flag = the reference's default "fp16" (image/train.py:458): IEEE-half operands with the loss
     scaler in the fused optimiser pass; checkpoint / resume keep working (the Adam step count comes from the scaler), the
-    EMA checkpoint samples, and "no" is refused rather than silently mapped."""
+    EMA checkpoint samples.  "no" (image/train.py:505) trains with fp32 operands through the fp32 build of the library, and
+    generate.py --no-tf32 (image/generate.py:41,183) samples with it: the same seed gives latents within fp16's distance of
+    the default (TF32-mantissa) run, and never a silent substitution (the model's precision is what the flag says)."""
     from reed_amd import generate, train
     out = str(tmp_path / "exps")
     common = ["--model", "SiT-S/2", "--output-dir", out, "--batch-size", "8", "--synthetic", "32", "--num-workers", "0",
@@ -98,14 +100,26 @@ def test_train_default_mixed_precision_is_fp16(dev, tmp_path):
     folder = generate.main(g)
     torch.set_grad_enabled(True)
     assert np.isfinite(np.load(folder + "_latents.npz")["arr_0"]).all()
-    with pytest.raises(NotImplementedError):
-        train.main(train.parse_args(["--exp-name", "n", "--max-train-steps", "1", "--mixed-precision", "no"] + common))
+    lat16 = np.load(folder + "_latents.npz")["arr_0"]
+    d32 = train.main(train.parse_args(["--exp-name", "n", "--max-train-steps", "2", "--mixed-precision", "no"] + common))
+    logs = [json.loads(l) for l in open(os.path.join(d32, "metrics.jsonl"))]
+    assert len(logs) == 2 and all(np.isfinite(r["training_denoising_loss"]) and np.isfinite(r["grad_norm"]) for r in logs)
+    g32 = generate.build_parser().parse_args(["--ckpt", os.path.join(d, "checkpoints", "0000004.pt"), "--model", "SiT-S/2",
+                                              "--sample-dir", str(tmp_path / "samples32"), "--per-proc-batch-size", "4",
+                                              "--num-fid-samples", "4", "--num-steps", "3", "--save-latents", "--no-tf32"])
+    assert generate.sample_precision(g32) == "fp32" and generate.sample_precision(g) == "fp16"
+    folder32 = generate.main(g32)
+    torch.set_grad_enabled(True)
+    lat32 = np.load(folder32 + "_latents.npz")["arr_0"]
+    assert np.isfinite(lat32).all() and np.abs(lat32 - lat16).max() < 5e-3 * np.abs(lat32).max()
 
 
 def test_cu_reserve_is_measured_under_a_reducer(dev):
-    """Data-parallel TrainStep (RCCL process group at world 1, forced): the first six optimiser steps run with a CU reserve of
-    0 / 16 / 32 for the GEMM grids (one settling + one timed step each), the fastest is kept and reported; without a reducer
-    nothing is tuned; REED_COMM_CUS=<n> fixes the reserve."""
+    """Data-parallel TrainStep (RCCL process group at world 1, forced).  The measurement is opt-in: without
+    REED_COMM_CUS nothing is tuned and the bucket form stays "allreduce".  With REED_COMM_CUS=auto the first optimiser steps
+    run with a CU reserve of 0 / 16 / 32 for the GEMM grids (one settling + three timed steps each, the median counts), the
+    fastest is kept and reported; REED_COMM_ALGO=auto then measures the reduce-scatter + all-gather bucket form the same way;
+    REED_COMM_CUS=<n> fixes the reserve; a failure inside the bookkeeping ends the measurement with the safe plan."""
     import copy
     import torch.distributed as dist
     from oracle import detfill
@@ -121,6 +135,8 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
         os.environ.setdefault("MASTER_PORT", "29741")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     os.environ["REED_FORCE_REDUCER"] = "1"
+    os.environ.pop("REED_COMM_CUS", None)
+    os.environ.pop("REED_COMM_ALGO", None)
     try:
         m = SiT(input_size=8, hidden_size=128, decoder_hidden_size=128, depth=3, num_heads=2, num_classes=10, z_dims=[128],
                 z_types=["i"], encoder_depth=2, projector_dim=128)
@@ -132,23 +148,43 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
         zs = [detfill.normal((4, 16, 128), 4).to(dev)]
         plain = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), None, diffusion_warm_up_steps=0)
         assert plain.tune_steps_left() == 0 and plain.cu_reserve == 0
+        red0 = GradReducer(m)
+        quiet = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red0, diffusion_warm_up_steps=0)
+        assert quiet.tune_steps_left() == 0 and quiet.cu_reserve == 0 and red0.algo == "allreduce"   # the default: nothing measured
+        red0.close()
+        os.environ["REED_COMM_CUS"] = "auto"
+        os.environ["REED_COMM_ALGO"] = "auto"
         red = GradReducer(m)
+        assert red.algo == "allreduce"
         ts = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red, diffusion_warm_up_steps=0)
-        assert ts.tune_steps_left() == 8          # 3 reserves + the reduce-scatter / all-gather bucket form, 2 steps each
+        assert ts.tune_steps_left() == 16         # 3 reserves + the reduce-scatter / all-gather bucket form, 1 + 3 steps each
         full = _lib.load().reed_planning_cus()
         seen, algos = [], []
-        for _ in range(9):
+        for _ in range(17):
             algos.append(red.algo)
             r = ts(x, y, zs)
             seen.append(_lib.load().reed_planning_cus())
         torch.cuda.synchronize()
-        assert torch.isfinite(r["loss"]).item()
-        assert seen[:5] == [full, full, full - 16, full - 16, full - 32]     # (read after each step: the sixth ends the reserve phase)
+        assert torch.isfinite(r["loss"]).item() and ts.tune_error is None
+        # (read after each step: the twelfth ends the reserve phase)
+        assert seen[:11] == [full] * 4 + [full - 16] * 4 + [full - 32] * 3
         assert ts.tune_steps_left() == 0 and set(ts.cu_tuning) == {"0", "16", "32", "rsag"} and ts.cu_reserve in (0, 16, 32)
-        assert seen[5] == seen[6] == seen[8] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
-        assert algos[:6] == ["allreduce"] * 6 and algos[6] == "allreduce" and algos[7] == "rsag" and red.algo in ("allreduce", "rsag")
+        assert seen[11] == seen[12] == seen[16] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
+        assert algos[:13] == ["allreduce"] * 13 and algos[13:16] == ["rsag"] * 3 and red.algo in ("allreduce", "rsag")
         assert red.algo == ("rsag" if ts.cu_tuning["rsag"] < ts.cu_tuning[str(ts.cu_reserve)] else "allreduce")
         red.close()
+        # a failure inside the bookkeeping is never fatal: reserve 0, all-reduce buckets, the error kept for the report
+        os.environ.pop("REED_COMM_ALGO", None)
+        red3 = GradReducer(m)
+        ts3 = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red3, diffusion_warm_up_steps=0)
+        assert ts3.tune_steps_left() == 12
+        ts3._agree = lambda times: (_ for _ in ()).throw(RuntimeError("injected"))
+        for _ in range(13):
+            r = ts3(x, y, zs)
+        torch.cuda.synchronize()
+        assert "injected" in ts3.tune_error and ts3.tune_steps_left() == 0 and ts3.cu_reserve == 0
+        assert _lib.load().reed_planning_cus() == full and red3.algo == "allreduce" and torch.isfinite(r["loss"]).item()
+        red3.close()
         os.environ["REED_COMM_CUS"] = "24"
         red2 = GradReducer(m)
         ts2 = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red2, diffusion_warm_up_steps=0)
@@ -157,6 +193,7 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
     finally:
         os.environ.pop("REED_FORCE_REDUCER", None)
         os.environ.pop("REED_COMM_CUS", None)
+        os.environ.pop("REED_COMM_ALGO", None)
         ops.set_cu_reserve(0)
 
 

@@ -1,0 +1,269 @@
+"""The fp32-operand build of the library (libreed_hip_f32.so, -DREED_FP32): the reference's `--mixed-precision no`
+(image/train.py:505) and `generate.py --no-tf32` (image/generate.py:41,183) arithmetic on the GPU.
+
+Kernel level: csrc/gemm_f32.hip (v_mfma_f32_32x32x2_f32; every layout, epilogue, ragged shape, split-K) and
+csrc/attention_f32.hip against fp64 torch.  Path level, against outputs of the reference itself in fp32 (tests/golden):
+the tiny cases' losses and per-parameter gradients, BASELINE's C1 configuration run literally (SiT-S/2, B = 64, 10 optimiser
+steps, fp32), the samplers, the two CLIs.  Tolerances are fp32 ones: what remains is summation order (MFMA tree vs the
+reference's BLAS), 1-ulp hardware exp / rcp in the activations, and rsqrt in LayerNorm.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detfill
+from tests.test_model_gpu import _hip_trainer, _run_traj, build_hip_model, cos
+from tests.test_oracle_golden import TINY_CASES, inputs, load, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def f32(dev):
+    from reed_amd import ops
+    prev = ops.use("fp32")
+    yield ops
+    ops.use(prev)
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x, approximate="tanh")
+
+
+@pytest.mark.parametrize("lay", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 132, 36), (1000, 1152, 1152), (64, 384, 8)])
+def test_gemm_f32_layouts_and_epilogues(dev, f32, lay, M, N, K):
+    """C = epilogue(sum_k P(m,k) Q(n,k)) for the three operand layouts on ragged shapes (nothing a multiple of the 128 x 128 x 16
+    tile), every epilogue the SiT step uses, vs fp64."""
+    ops = f32
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)            # P(m, k)
+    Bm = torch.randn(N, K, generator=g) / K ** 0.5  # Q(n, k)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ Bm.double().T
+    L = {"NT": ops.NT, "NN": ops.NN, "TN": ops.TN}[lay]
+    P = (A if lay != "TN" else A.T.contiguous()).to(dev)          # TN: P stored [K, M]
+    Q = (Bm if lay == "NT" else Bm.T.contiguous()).to(dev)        # NN / TN: Q stored [K, N]
+    ldp = K if lay != "TN" else M
+    ldq = K if lay == "NT" else N
+    tol = dict(rtol=2e-5, atol=2e-5 * max(1.0, float(ref.abs().max())))
+
+    def run(epi, **kw):
+        C = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(L, epi, P, Q, M, N, K, C, ldp, ldq, N, **kw)
+        return C
+
+    C = run(ops.EPI_BF16, bias=bias.to(dev))
+    torch.testing.assert_close(C.cpu().double(), ref + bias.double(), **tol)
+    # pre-activation + activation
+    C2 = torch.empty(M, N, device=dev)
+    C = run(ops.EPI_GELU, bias=bias.to(dev), C2=C2, ldc2=N)
+    torch.testing.assert_close(C.cpu().double(), ref + bias.double(), **tol)
+    torch.testing.assert_close(C2.cpu().double(), _gelu(ref + bias.double()), **tol)
+    C = run(ops.EPI_SILU, bias=bias.to(dev), C2=C2, ldc2=N)
+    torch.testing.assert_close(C2.cpu().double(), torch.nn.functional.silu(ref + bias.double()), **tol)
+    # gate * y + residual, gate per `rows` rows
+    rows = 8
+    gate = torch.randn((M + rows - 1) // rows, N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    Y = torch.empty(M, N, device=dev)
+    C = run(ops.EPI_GATE_RES, bias=bias.to(dev), C2=Y, ldc2=N, R=R.to(dev), ldr=N, gate=gate.to(dev), ldgate=N, rows_per_gate=rows)
+    y = ref + bias.double()
+    torch.testing.assert_close(Y.cpu().double(), y, **tol)
+    torch.testing.assert_close(C.cpu().double(), R.double() + gate.double().repeat_interleave(rows, 0)[:M] * y, **tol)
+    # activation gradients
+    pre = torch.randn(M, N, generator=g)
+    C = run(ops.EPI_DGELU, R=pre.to(dev), ldr=N)
+    pd = pre.double().requires_grad_(True)
+    _gelu(pd).sum().backward()
+    torch.testing.assert_close(C.cpu().double(), ref * pd.grad, **tol)
+    C = run(ops.EPI_DSILU, R=pre.to(dev), ldr=N)
+    pd = pre.double().requires_grad_(True)
+    torch.nn.functional.silu(pd).sum().backward()
+    torch.testing.assert_close(C.cpu().double(), ref * pd.grad, **tol)
+    # fp32 accumulate forms
+    base = torch.randn(M, N, generator=g)
+    C = base.clone().to(dev)
+    ops.gemm(L, ops.EPI_F32, P, Q, M, N, K, C, ldp, ldq, N, accumulate=True)
+    torch.testing.assert_close(C.cpu().double(), base.double() + ref, **tol)
+    C = base.clone().to(dev)
+    ops.gemm(L, ops.EPI_ADDF32_RB, P, Q, M, N, K, C, ldp, ldq, N)
+    torch.testing.assert_close(C.cpu().double(), base.double() + ref, **tol)
+
+
+@pytest.mark.parametrize("tokens,N,K,split", [(4096, 256, 384, 1), (4096, 256, 384, 4), (1000, 132, 64, 3), (8, 768, 128, 1)])
+def test_gemm_f32_weight_gradient_with_bias_and_split_k(dev, f32, tokens, N, K, split):
+    """dW = dY^T X with the fused bias gradient (column sums of dY), through ops.linear_wgrad as the engine calls it: split-K
+    slabs + the deterministic reduce, accumulate on and off; tokens = 8 is the adaLN weight gradient's K = local batch."""
+    ops = f32
+    g = torch.Generator().manual_seed(tokens + N)
+    dy = torch.randn(tokens, N, generator=g)
+    x = torch.randn(tokens, K, generator=g)
+    ref_w, ref_b = dy.double().T @ x.double(), dy.double().sum(0)
+    tol = dict(rtol=3e-5, atol=3e-5 * float(ref_w.abs().max()))
+    buf = torch.zeros(N * K + N, device=dev)     # bias right behind its weight, as in the gradient arena
+    dw, db = buf[:N * K], buf[N * K:]
+    for acc in (False, True):
+        ops.linear_wgrad(dy.to(dev), x.to(dev), dw, dbias=db, accumulate=acc, split_k=split, Mtok=tokens, N=N, K=K)
+        k = 2.0 if acc else 1.0
+        torch.testing.assert_close(dw.view(N, K).cpu().double(), k * ref_w, **tol)
+        torch.testing.assert_close(db.cpu().double(), k * ref_b, **tol)
+
+
+@pytest.mark.parametrize("hd", [64, 72])
+@pytest.mark.parametrize("B,T,H", [(2, 16, 2), (1, 256, 3), (1, 300, 2)])
+def test_attention_f32_vs_fp64(dev, f32, hd, B, T, H):
+    """softmax(q k^T / sqrt(hd)) v on the [B, T, 3, H, hd] layout, forward + log-sum-exp + backward, vs fp64 autograd;
+    T = 300 crosses the 256-row block and the 32-row staging tile."""
+    ops = f32
+    g = torch.Generator().manual_seed(hd + T)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g)
+    do = torch.randn(B, T, H * hd, generator=g)
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = qd.permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / hd ** 0.5
+    ref_o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, H * hd)
+    ref_lse = torch.logsumexp(s, -1)
+    ref_o.backward(do.double())
+    o = torch.empty(B, T, H * hd, device=dev)
+    lse = torch.empty(B, H, T, device=dev)
+    ops.attention_fwd(qkv.to(dev), o, lse, B, T, H, hd)
+    torch.testing.assert_close(o.cpu().double(), ref_o.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lse.cpu().double(), ref_lse.detach(), rtol=1e-5, atol=1e-5)
+    dqkv = torch.full((B, T, 3, H, hd), float("nan"), device=dev)
+    ops.attention_bwd(qkv.to(dev), o, do.to(dev), lse, dqkv, B, T, H, hd)
+    torch.testing.assert_close(dqkv.cpu().double(), qd.grad, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", [k for k, v in TINY_CASES.items() if v["hip"]] + ["hd72"])
+def test_tiny_fp32_vs_reference(dev, name):
+    """Every tiny case (both head sizes, both tap modes, qk_norm, unfused attention, patch 4 — and hd72, whose D = 144 the
+    16-bit tiles cannot take) at precision "fp32" against the REFERENCE's own fp32 outputs: losses to 2e-5, the norm of every
+    parameter's gradient to 1e-4, gradient elements at cosine 1 - 1e-6, the eval-mode forward to 2e-5."""
+    from reed_amd.loss import SILoss
+    g = load("tiny")
+    c = TINY_CASES[name]
+    cfg = c["cfg"]
+    T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 11, c["zspec"], T, cfg["num_classes"])
+    m = build_hip_model(cfg, dev, 11)
+    m.precision = "fp32"
+    m.train()
+    m.force_drop_mask = drop_u < cfg["class_dropout_prob"]
+    lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
+    out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+    total = out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+    total.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out["denoising_loss"].detach().cpu().numpy(), g[f"{name}.denoising_loss"], rtol=2e-5)
+    np.testing.assert_allclose(float(total), float(g[f"{name}.total"]), rtol=2e-5, atol=2e-6)
+    worst_n, worst_c = 0.0, 1.0
+    params = dict(m.named_parameters())
+    for k, p in params.items():
+        if not p.requires_grad:
+            continue
+        ref_n = float(g[f"{name}.gnorm.{k}"])
+        nh = p.grad.float().norm().item()
+        if ref_n < 5e-5:
+            assert nh < 5e-5, (k, nh, ref_n)
+            continue
+        worst_n = max(worst_n, abs(nh / ref_n - 1))
+        assert abs(nh / ref_n - 1) < 1e-4, (k, nh, ref_n)
+    for k in ("final_layer.linear.bias", "x_embedder.proj.bias", "projectors.0.4.bias", "final_layer.linear.weight",
+              "blocks.0.attn.qkv.bias", "x_embedder.proj.weight", "blocks.1.adaLN_modulation.1.bias", "blocks.2.mlp.fc1.bias"):
+        cs = cos(params[k].grad.detach().cpu(), torch.from_numpy(g[f"{name}.grad.{k}"]))
+        worst_c = min(worst_c, cs)
+        assert cs > 1 - 1e-6, (k, cs)
+    print(f"[{name}, fp32] worst |gradient norm ratio - 1| vs the fp32 reference {worst_n:.2e}, worst element cosine {worst_c:.8f}")
+    m.eval()
+    m.force_drop_mask = None
+    xi, _, ti, yi, _, _ = inputs(4, 4, cfg["input_size"], 11, [], 0, 10)
+    with torch.no_grad():
+        o, z = m(xi.to(dev), ti.to(dev), yi.to(dev))
+    ref = torch.from_numpy(g[f"{name}.infer"])
+    assert z is None and o.dtype == torch.float32
+    assert (o.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_c1_literal_fp32_trajectory(dev):
+    """BASELINE configs[0] run literally: SiT-S/2, 64 random 32x32x4 latents, fp32, 10 optimiser steps (clip 1.0, AdamW 1e-4,
+    EMA), alignment off.  Golden = the reference in fp32 (tests/golden/s2_c1.npz).  Per-step denoising loss within 1e-5."""
+    g = load("s2_c1")
+    m, ema, opt, lf = _hip_trainer("SiT-S/2", dict(z_dims=[], z_types=[]), dev, [], [])
+    m.precision = "fp32"
+    ema.precision = "fp32"
+    rec = _run_traj(m, opt, lf, dev, 64, 10, [], False)
+    print("HIP fp32:", [f"{v:.6f}" for v in rec["denoising_loss"]])
+    print("REF fp32:", [f"{v:.6f}" for v in g["denoising_loss"]])
+    np.testing.assert_allclose(rec["denoising_loss"], g["denoising_loss"], atol=1e-5)
+    np.testing.assert_allclose(rec["grad_norm"], g["grad_norm"], rtol=2e-4)
+    sd = m.state_dict()
+    for k in ("blocks.0.attn.qkv.weight", "final_layer.linear.weight", "t_embedder.mlp.2.bias"):
+        np.testing.assert_allclose(sd[k].flatten()[:64].cpu().numpy(), g["w." + k], atol=2e-5)
+        np.testing.assert_allclose(ema.state_dict()[k].flatten()[:64].cpu().numpy(), g["ema." + k], atol=1e-6)
+
+
+def test_samplers_fp32_vs_reference(dev):
+    """Euler / Heun / Euler-Maruyama with (interval) CFG, 6 steps on the tiny SiT with an fp32 model and fp64 state — the
+    reference's own arithmetic under --no-tf32 — within 1e-5 of the latents' scale of the reference's outputs."""
+    from reed_amd import samplers
+    g = load("samplers")
+    m = build_hip_model(tiny_cfg(num_classes=1000), dev, 5).eval()
+    m.precision = "fp32"
+    z = detfill.normal((3, 4, 8, 8), 41).to(dev)
+    y = torch.tensor([3, 500, 999], device=dev)
+    cfgs = {"euler": dict(heun=False, cfg_scale=1.0), "heun": dict(heun=True, cfg_scale=1.0),
+            "euler_cfg": dict(heun=False, cfg_scale=2.5), "heun_cfg": dict(heun=True, cfg_scale=1.5),
+            "heun_cfg_interval": dict(heun=True, cfg_scale=3.0, guidance_low=0.3, guidance_high=0.75)}
+    worst = 0.0
+    for name, c in cfgs.items():
+        out = samplers.euler_sampler(m, z, y, num_steps=6, prediction="v", **c)
+        ref = torch.from_numpy(g[name])
+        err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, err)
+        assert out.dtype == torch.float64 and err < 1e-5, (name, err)
+    eps = [detfill.normal((3, 4, 8, 8), 600 + i).double() for i in range(8)]
+    for name, c in {"sde": dict(cfg_scale=1.0), "sde_cfg": dict(cfg_scale=2.0, guidance_high=0.9),
+                    "sde_cosine": dict(cfg_scale=1.0, path_type="cosine")}.items():
+        out = samplers.euler_maruyama_sampler(m, z, y, num_steps=6, noises=eps, **c)
+        ref = torch.from_numpy(g[name])
+        err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, err)
+        assert err < 1e-5, (name, err)
+    print(f"fp32 samplers: worst deviation {worst:.2e} of the latents' scale")
+
+
+def test_fp32_switch_leaves_other_builds_alone(dev):
+    """A model at precision "fp32" between two steps of a bf16 model: the bf16 model's gradients are bit-identical with and
+    without it (the build selection is per call and restored), and changing the precision between forward and backward is
+    refused."""
+    from reed_amd.loss import SILoss
+    c = TINY_CASES["hd64"]
+    cfg = c["cfg"]
+    x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 3, c["zspec"], 16, cfg["num_classes"])
+    lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
+
+    def grads(m):
+        for p in m.parameters():
+            p.grad = None
+        m.engine().zero_grad()
+        m.force_drop_mask = drop_u < 0.1
+        out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+        (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+        torch.cuda.synchronize()
+        return m._arena.grad.clone()
+
+    a = build_hip_model(cfg, dev, 3).train()
+    b = build_hip_model(cfg, dev, 3).train()
+    b.precision = "fp32"
+    g0 = grads(a)
+    gb = grads(b)
+    g1 = grads(a)
+    assert torch.equal(g0, g1)
+    assert cos(g0.cpu(), gb.cpu()) > 0.999        # the same gradient at two precisions
+    out = lf(b, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+    b.precision = "bf16"
+    with pytest.raises(RuntimeError, match="precision changed"):
+        (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()

@@ -20,7 +20,8 @@ def test_library_exports_every_header_symbol():
     from reed_amd import _lib
     protos = _lib.parse_header()
     assert len(protos) >= 40
-    for prec, kind in (("bf16", 0), ("fp16", 1)):   # the product library and its IEEE-half build (the sampling path)
+    # the product library, its IEEE-half build (the sampling path) and its fp32-operand build (--mixed-precision no)
+    for prec, kind in (("bf16", 0), ("fp16", 1), ("fp32", 2)):
         lib = _lib.load(prec)
         assert lib._reed_missing == [], lib._reed_missing
         assert lib.reed_version() == 100 and lib.reed_half_kind() == kind
@@ -506,3 +507,43 @@ def test_sd_vae_decoder_two_restatements_agree(tmp_path):
     torch.save(legacy, path)
     re = rvae.load_sd_vae_decoder(str(tmp_path), block_out_channels=(16, 32, 32), layers_per_block=1, norm_num_groups=8)
     np.testing.assert_allclose(re.decode(z.float()).numpy(), got, rtol=2e-4, atol=2e-4)
+
+
+def test_mocov3_checkpoint_key_repair(tmp_path, monkeypatch):
+    """image/utils.py:27-52 fix_mocov3_state_dict: the published MoCo-v3 ViT-L file stores blocks.13.norm1 / mlp.fc1 as norm13 /
+    fc13 and blocks.14.norm2 / mlp.fc2 as norm14 / fc14, under `module.base_encoder.`, beside a momentum encoder, a predictor
+    and a projection head.  The loader must repair the four names, drop the rest, and fill every tower parameter."""
+    from reed_amd import encoders
+    assert encoders.mocov3_key("module.base_encoder.blocks.13.norm13.weight") == "blocks.13.norm1.weight"
+    assert encoders.mocov3_key("module.base_encoder.blocks.13.mlp.fc13.bias") == "blocks.13.mlp.fc1.bias"
+    assert encoders.mocov3_key("module.base_encoder.blocks.14.norm14.bias") == "blocks.14.norm2.bias"
+    assert encoders.mocov3_key("module.base_encoder.blocks.14.mlp.fc14.weight") == "blocks.14.mlp.fc2.weight"
+    assert encoders.mocov3_key("module.base_encoder.blocks.13.norm2.weight") == "blocks.13.norm2.weight"
+    assert encoders.mocov3_key("module.base_encoder.blocks.3.norm1.weight") == "blocks.3.norm1.weight"
+    assert encoders.mocov3_key("module.base_encoder.head.0.weight") is None
+    assert encoders.mocov3_key("module.momentum_encoder.blocks.0.norm1.weight") is None
+    assert encoders.mocov3_key("module.predictor.0.weight") is None
+    assert encoders.mocov3_key("blocks.2.attn.qkv.weight") == "blocks.2.attn.qkv.weight"     # a plain state dict passes
+    tiny = dict(embed=128, depth=15, heads=2, patch=16, image=64, cls=True, final_norm=True)
+    monkeypatch.setitem(encoders.VIT_TOWERS, "mocov3-vit-l", tiny)
+    ref = encoders.VitEncoder(**tiny)
+    g = torch.Generator().manual_seed(3)
+    want = {k: torch.randn(v.shape, generator=g) for k, v in ref.state_dict().items()}
+    bad = {"blocks.13.norm1": "blocks.13.norm13", "blocks.13.mlp.fc1": "blocks.13.mlp.fc13",
+           "blocks.14.norm2": "blocks.14.norm14", "blocks.14.mlp.fc2": "blocks.14.mlp.fc14"}
+    ck = {}
+    for k, v in want.items():
+        for good, wrong in bad.items():
+            if k.startswith(good + "."):
+                k = wrong + k[len(good):]
+        ck["module.base_encoder." + k] = v
+        ck["module.momentum_encoder." + k] = torch.zeros_like(v)
+    ck["module.base_encoder.head.0.weight"] = torch.zeros(4, 128)
+    ck["module.predictor.0.weight"] = torch.zeros(4, 4)
+    path = str(tmp_path / "mocov3_vitl.pth")
+    torch.save({"state_dict": ck, "epoch": 300}, path)
+    enc = encoders.load_vit_encoder("mocov3-vit-l", path, "cpu")
+    got = enc.state_dict()
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k

@@ -334,6 +334,53 @@ LONG_DRIFT_BAR = 3e-3
 LONG_DRIFT_BAR_FP16 = 5e-4
 
 
+# XL/2 bars: scaled from the S/2 curve by the printed measurements (the drift is the integral of the evaluation error over the
+# unit time interval, linear in t at either size; 28 blocks of width 1152 instead of 12 of 384 carry a larger evaluation error)
+LONG_DRIFT_BAR_XL = {"bf16": 6e-3, "fp16": 1e-3, "fp32": 2e-5}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32"])
+def test_long_horizon_heun_cfg_drift_xl2(dev, precision):
+    """The same pin at C5's real model size: SiT-XL/2, n = 2, 25-step Heun with CFG 1.5 over the whole
+    interval (49 evaluations at batch 4) against the reference with an fp32 model (tools/gen_golden.py:g_samplers_long_xl).
+    The state fed to every 6th evaluation is compared (the printed drift curve), the end point asserted relative to the
+    latents' scale; precision "fp32" = the reference's own arithmetic under --no-tf32."""
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.samplers import euler_sampler
+    g = load("samplers_long_xl")
+    m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8, use_cfg=True)
+    detfill.fill_state_dict(m.state_dict(), base_seed=0)
+    m = m.to(dev).eval()
+    m.precision = precision
+    z = detfill.normal((2, 4, 32, 32), 191).to(dev)
+    y = torch.tensor([207, 980], device=dev)
+    states = []
+
+    class Rec:
+        num_classes, class_dropout_prob = m.num_classes, m.class_dropout_prob
+
+        def engine(self):
+            return m.engine()
+
+        def __call__(self, xx, tt, **kw):
+            states.append(xx[:2].detach().cpu().clone())
+            return m(xx, tt, **kw)
+
+    with torch.no_grad():
+        out = euler_sampler(Rec(), z, y, num_steps=25, heun=True, cfg_scale=1.5).cpu()
+    assert len(states) == int(g["n_evals"]) == 49
+    ref_states = torch.from_numpy(g["states"])
+    curve = [(s - r).abs().max().item() for s, r in zip(states[::6], ref_states)]
+    ref = torch.from_numpy(g["final"])
+    scale = ref.abs().max().item()
+    end = (out - ref).abs().max().item()
+    print(f"XL/2 drift of the {precision}-operand sampler vs the fp32 reference, max abs, at evaluations 0, 6, ..., 48:",
+          " ".join(f"{c:.2e}" for c in curve), f"| final {end:.3e} (latent scale {scale:.2f}, rms "
+          f"{(out - ref).pow(2).mean().sqrt().item():.3e})")
+    assert curve[0] == 0.0
+    assert end <= LONG_DRIFT_BAR_XL[precision] * scale
+
+
 def test_wgrad_side_stream_bit_identical(dev):
     """The blocks' weight-gradient GEMMs on the second HIP stream (engine.wgrad_stream) are the same launches in a
     different interleaving: every gradient must be bit-identical to the single-stream backward, also when the step is

@@ -493,6 +493,27 @@ def g_samplers_long(ref_sit, ref_loss, ref_samplers):
     save("samplers_long", **out)
 
 
+def g_samplers_long_xl(ref_sit, ref_loss, ref_samplers):
+    """The same pin at C5's real model size: SiT-XL/2 (fp32 reference model), n = 2, 25-step Heun with
+    CFG 1.5 over the whole interval (49 evaluations at batch 4). The state fed to every 6th evaluation and the final latents."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[1024], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False,
+              use_cfg=True)
+    m = build_ref_model(ref_sit, "SiT-XL/2", seed=0, **kw).eval()
+    z = detfill.normal((2, 4, 32, 32), 191)
+    y = torch.tensor([207, 980])
+    states = []
+
+    def model(xx, tt, **kw):
+        states.append(xx[:2].detach().clone())
+        return m(xx, tt, **kw)
+
+    with torch.no_grad():
+        out = {"final": ref_samplers.euler_sampler(model, z, y, num_steps=25, heun=True, cfg_scale=1.5)}
+    out["n_evals"] = np.array(len(states))
+    out["states"] = torch.stack(states[::6])
+    save("samplers_long_xl", **out)
+
+
 def g_fp16(ref_sit, ref_loss, ref_samplers):
     """--mixed-precision fp16 (the reference's default and README recipe): the reference under torch.autocast(float16)
     with torch.amp.GradScaler at accelerate's defaults (init 65536, x2 after 2000 clean steps, x0.5 on overflow).
@@ -766,7 +787,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers, "dinov2": g_dinov2}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "samplers_long_xl": g_samplers_long_xl, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers, "dinov2": g_dinov2}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -778,7 +799,7 @@ if __name__ == "__main__":
     for name, fn in ALL.items():
         if a.only and name not in a.only:
             continue
-        if a.skip_xl and name.startswith("xl2"):
+        if a.skip_xl and (name.startswith("xl2") or name.endswith("_xl")):
             continue
         print(f"[gen_golden] {name}")
         t0 = time.time()
