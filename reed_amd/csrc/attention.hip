@@ -882,6 +882,231 @@ __global__ __launch_bounds__(1024 / QT, QT == 4 ? 1 : 2) void attn_bwd_kernel(co
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward, round 3: key-stationary, S and dP computed ONCE.
+//
+// The two-phase kernel above recomputes S = Q K^T, P and dP = dO V^T in both of its phases (7 matrix products and
+// 2 x 65536 exponentials per head: phase 1 queries-on-wave for dQ, phase 2 keys-on-wave for dK / dV).  Here a wave owns 32
+// keys for the whole item (K / V row fragments and the dK / dV accumulators in registers, exactly the old phase 2) and walks
+// the queries 32 at a time; the dS block it forms on the way — [32 queries x its 32 keys], already rounded to bf16 for the
+// dK product — is ALSO written to an LDS tile dS^T[key][query] (8 bytes per lane and MFMA tile: a lane owns 4 consecutive
+// queries of one key).  After every 64 queries the workgroup meets at a barrier and forms dQ^T = K^T dS^T for those 64
+// queries with the matrix pipe (A = K^T and B = dS^T both through ds_read_b64_tr_b16 with the same k-slot permutation;
+// 20 (16-query tile, 16-column tile) pairs over 8 waves: 3 or 2 per wave, 8 k-steps each in one accumulator, i.e. the old
+// phase 1's summation order over the keys).  5 products and 65536 exponentials per head: 448 MFMAs per wave and item instead
+// of 624, half the softmax VALU work, 108 KiB of tiles per item by LDS-DMA instead of 144 (V never goes through LDS: a wave
+// reads its own 32 rows from global memory straight into fragments).  dQ leaves through the Q tile's rows of the finished
+// chunk (dead after the barrier), dK / dV through the wave's own rows of the K / dO tiles at the end: whole 144-byte row
+// pieces.  Deterministic (no atomics; every output element has one owner and a fixed summation order).
+// LDS: Q | K | dS^T (64 queries wide) | dO tiles of 144-byte rows + lse / delta = the same 147 KiB.  T <= 256.
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_ks_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                             const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                             bf16* __restrict__ dqkv, int B, int T, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  constexpr int DTA = (DT + 1) / 2;          // 16-column tiles of dQ^T a wave of the first / second group forms (3 + 2 of 5)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int D = H * HD;
+  const int bh = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = bh / H, h = bh % H;
+  const long tok = 3l * D;
+  const bf16* base = qkv + (long)b * T * tok + h * HD;
+  bf16* dbase = dqkv + (long)b * T * tok + h * HD;
+  const bf16* gbase = d_o + (long)b * T * D + h * HD;
+  char* Qt = smem;
+  char* Kt = smem + TILE_B;
+  char* St = smem + 2 * TILE_B;   // dS^T[key][query - 64 chunk], bf16, ROWB-byte rows (64 of the 72 columns used)
+  char* Gt = smem + 3 * TILE_B;   // dO
+  float* lse2 = (float*)(smem + 4 * TILE_B + 256);
+  float* dlt = lse2 + 256;
+  const float scale = rsqrtf((float)HD);
+  const float sc2 = scale * LOG2E;
+  const int r0 = wave * 32;       // this wave's rows: its keys, and the queries whose delta / log-sum-exp it prepares
+
+  // ---- load phase: K, Q, dO tiles by LDS-DMA (36 pieces of 1 KiB each: waves 0..3 issue 5 of a tile, 4..7 issue 4) ----
+  auto issue_tile = [&](char* t, const bf16* s, int sb) {
+    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(s, tile_window<HD>(T, sb));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int I = wave + 8 * j;
+      const int vo = dma_voff<HD, ROWB>(I * 64 + lane, sb);
+      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(t + I * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  issue_tile(Kt, base + D, (int)(tok * 2));
+  issue_tile(Qt, base, (int)(tok * 2));
+  issue_tile(Gt, gbase, D * 2);
+  // the wave's own rows from global memory: V fragments (its keys) and, for its 32 QUERY rows, dO and O -> delta, lse
+  bf16x8 kf[2][KS], vf[2][KS];
+  {
+    bf16x8 gf[2][KS], of[2][KS];
+    float lq[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int row = r0 + 16 * t2 + i;
+      const bool ok = row < T;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        vf[t2][ks] = load_frag_global<HD>(base + 2 * D + (long)row * tok, ok, ks, lane);
+        gf[t2][ks] = load_frag_global<HD>(gbase + (long)row * D, ok, ks, lane);
+        of[t2][ks] = load_frag_global<HD>(o + ((long)b * T + row) * D + h * HD, ok, ks, lane);
+      }
+      lq[t2] = lse[((long)b * H + h) * T + min(row, T - 1)];
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += bf2f(gf[t2][ks][e]) * bf2f(of[t2][ks][e]);
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      if (g == 0) {
+        dlt[r0 + 16 * t2 + i] = acc;
+        lse2[r0 + 16 * t2 + i] = (r0 + 16 * t2 + i < T) ? lq[t2] * LOG2E : INFINITY;   // rows >= T: p = exp2(-inf) = 0
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
+  bool kvalid[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) kvalid[ct] = r0 + 16 * ct + i < T;
+
+  // whole 144-byte row pieces of `nrows` tile rows from row0 on -> global rows (16 bytes per lane)
+  auto store_rows = [&](const char* tile, bf16* gb, int row0, int nrows) {
+    const int nq = nrows * NCH;
+    for (int k = 0; k * 64 < nq; ++k) {
+      const int qi = lane + 64 * k;
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      if (qi < nq && row0 + rr < T)
+        *(uint4*)(gb + (long)(row0 + rr) * tok + c * 8) = *(const uint4*)(tile + (row0 + rr) * ROWB + c * 16);
+    }
+  };
+
+  f32x4 dk[2][DT], dv[2][DT];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
+  const int nblk = (T + 31) >> 5;          // 32-query blocks (and 32-key steps) that hold rows < T
+  const int nchunk = (nblk + 1) >> 1;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    // ---------------- phase A: this wave's 32 keys x the chunk's 64 queries ----------------
+#pragma unroll 1
+    for (int qh = 0; qh < 2; ++qh) {
+      const int qq0 = ch * 64 + qh * 32;
+      f32x4 st[2][2], dp[2][2];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 qa = frag_rows(Qt, qq0 + 16 * qt, ks, lane);
+          bf16x8 ga = frag_rows(Gt, qq0 + 16 * qt, ks, lane);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            st[qt][ct] = MFMA(qa, kf[ct][ks], st[qt][ct]);
+            dp[qt][ct] = MFMA(ga, vf[ct][ks], dp[qt][ct]);
+          }
+        }
+      f32x4 lq4[2], dl4[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
+        dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
+      }
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 p0, p1, s0, s1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
+          p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
+          s0[r] = kvalid[ct] ? p0[r] * (dp[0][ct][r] - dl4[0][r]) : 0.f;   // a key past T contributes nothing to dQ
+          s1[r] = kvalid[ct] ? p1[r] * (dp[1][ct][r] - dl4[1][r]) : 0.f;
+        }
+        pb[ct] = pack2(p0, p1);
+        dsb[ct] = pack2(s0, s1);
+        // dS^T[key = r0+16ct+i][query = qq0 + 16 qt + 4g + r]: the lane's 4 consecutive queries of each 16-query tile
+        char* sp = St + (r0 + 16 * ct + i) * ROWB + (qh * 32 + 4 * g) * 2;
+        *(bf16x4*)sp = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
+        *(bf16x4*)(sp + 32) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x8 gtf = frag_trT(Gt, qq0, 16 * dt, lane);
+        bf16x8 qtf = frag_trT(Qt, qq0, 16 * dt, lane);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          dv[ct][dt] = MFMA(gtf, pb[ct], dv[ct][dt]);
+          dk[ct][dt] = MFMA(qtf, dsb[ct], dk[ct][dt]);
+        }
+      }
+    }
+    __syncthreads();   // dS^T of the chunk is complete; the chunk's Q rows are dead (phase A of later chunks reads other rows)
+    // ---------------- phase B: dQ^T = K^T dS^T for the chunk's 64 queries ----------------
+    {
+      const int qtile = wave >> 1;                       // 16 queries of the chunk
+      const int dt0 = (wave & 1) ? DTA : 0;              // this wave's 16-column tiles of head_dim: [dt0, dt0 + ndt)
+      f32x4 dq[DTA];
+#pragma unroll
+      for (int k = 0; k < DTA; ++k) dq[k] = zero4();
+#pragma unroll 1
+      for (int ks = 0; ks < nblk; ++ks) {
+        const bf16x8 dsf = frag_trT(St, 32 * ks, 16 * qtile, lane);
+#pragma unroll
+        for (int k = 0; k < DTA; ++k) {
+          if (dt0 + k < DT) {
+            const bf16x8 ktf = frag_trT(Kt, 32 * ks, 16 * (dt0 + k), lane);
+            dq[k] = MFMA(ktf, dsf, dq[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DTA; ++k) {
+        const int d = 16 * (dt0 + k) + 4 * g;
+        if (dt0 + k < DT && d < HD) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[k][r] * scale);
+          *(bf16x4*)(Qt + (ch * 64 + 16 * qtile + i) * ROWB + d * 2) = v;
+        }
+      }
+    }
+    __syncthreads();   // dQ rows of the chunk are staged; dS^T is free for the next chunk
+    store_rows(Qt, dbase, ch * 64 + 8 * wave, 8);
+  }
+  // ---------------- dK, dV of the wave's keys leave through its own rows of the K / dO tiles ----------------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = 16 * dt + 4 * g;
+      if (d < HD) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = f2bf(dk[ct][dt][r] * scale); c[r] = f2bf(dv[ct][dt][r]); }
+        *(bf16x4*)(Kt + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
+        *(bf16x4*)(Gt + (r0 + 16 * ct + i) * ROWB + d * 2) = c;
+      }
+    }
+  store_rows(Kt, dbase + D, r0, 32);
+  store_rows(Gt, dbase + 2 * D, r0, 32);
+}
+
 int attn_fwd_oneshot() {   // REED_ATTN_FWD=oneshot: the round-1 forward also for T <= 256 (A/B)
   static int v = -1;
   if (v < 0) { const char* e = getenv("REED_ATTN_FWD"); v = (e && e[0] == 'o') ? 1 : 0; }
@@ -956,6 +1181,23 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
   const int lds = 4 * TILE_B + 256 + 2048;
   dim3 grid(B * H);
   static const bool w4 = getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1;   // experiment: 4 waves x 64 rows
+  // REED_ATTN_BWD=2p keeps the two-phase kernel (same-box A/B); default: the key-stationary kernel (S and dP once)
+  static const bool two_phase = getenv("REED_ATTN_BWD") && getenv("REED_ATTN_BWD")[0] == '2';
+  if (!two_phase && !w4) {
+    if (hd == 64) {
+      static int once = set_lds(attn_bwd_ks_kernel<64>, lds);
+      if (once) return once;
+      REED_KLAUNCH((attn_bwd_ks_kernel<64>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+                   (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+    } else {
+      static int once = set_lds(attn_bwd_ks_kernel<72>, lds);
+      if (once) return once;
+      REED_KLAUNCH((attn_bwd_ks_kernel<72>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+                   (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
+    }
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
   if (w4 && hd == 72) {
     static int once = set_lds(attn_bwd_kernel<72, 4>, lds);
     if (once) return once;
