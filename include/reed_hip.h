@@ -125,6 +125,13 @@ int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, int T, int H
                        void* stream);
 int reed_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
                        void* dqkv, int B, int T, int H, int hd, void* stream);
+/* The same backward with a caller-owned workspace of reed_attention_bwd_ws_floats(B, T, H) floats (delta = rowsum(dO * O) is
+ * formed there by a row kernel, which lets the main kernel run persistently with the next (batch, head) item's operands in
+ * flight under the current one: csrc/attention.hip); ws == NULL falls back to reed_attention_bwd.  Replaces the autograd of
+ * F.scaled_dot_product_attention inside timm Attention (image/models/sit.py:114-118). */
+int64_t reed_attention_bwd_ws_floats(int B, int T, int H);
+int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
+                          int B, int T, int H, int hd, void* stream);
 
 /* qk_norm (timm Attention(qk_norm=True); reference flag --qk-norm, sit.py:114-116): LayerNorm over head_dim (eps, affine
  * f32 [hd]) on the q and k thirds of qkv bf16 [M,3,H,hd]; v copied through; stats f32 [M,2,H,2] = (mean, rstd).

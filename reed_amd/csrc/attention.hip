@@ -1107,6 +1107,356 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ks_kernel(const bf16* __restr
   store_rows(Gt, dbase + 2 * D, r0, 32);
 }
 
+// ------------------------------------------------------------------------------------------
+// The key-stationary backward, persistent: one workgroup per CU walks the (batch, head) items and the NEXT item's operands
+// arrive while the current one computes.  Measured on the one-shot form above (and on the two-phase kernel before it): with the
+// compute skipped the kernel still takes half its time — every workgroup loads its 180 KiB in one burst at ~11 B/clk per CU
+// and waits, then computes with the memory system idle (one 147-KiB workgroup per CU: nothing to switch to).
+// What makes the overlap possible here is that in the key-stationary order the Q and dO tiles are STREAMS — the 64 rows of
+// chunk c are read in phase A of chunk c and never again — and only K is resident:
+//   * rows 0..127 of Q(n+1), dO(n+1) are issued (LDS-DMA, 36 pieces of 1 KiB) after the barrier that ends phase A of chunk 1
+//     of item n, rows 128..255 after the one that ends phase A of chunk 3: each lands a whole item before it is read;
+//   * the wave's own key rows of item n+1 — K and V as MFMA fragments — and the (log-sum-exp, delta) pairs of its 32 query
+//     rows are plain global loads into registers (inline asm: the compiler never waits for them) issued at that same point,
+//     into the registers of the current item's fragments (dead: phase A is over);
+//   * K(n+1) (the K^T operand of phase B) is issued when phase B of the last chunk is over and is first needed after
+//     phase A of chunk 0 of item n+1;
+//   * dQ leaves straight from the MFMA layout (8 bytes per lane; the Q tile's rows belong to the next item by then),
+//     dK / dV through the wave's own rows of the dS^T tile (dead after the last phase B), one after the other.
+// delta = rowsum(dO * O) comes from a row kernel in front (attn_delta_kernel: it reads the bytes of dO and O this kernel no
+// longer reads — the traffic is the same — and keeps 48 fragment registers per lane out of the pipeline).
+// Two waits per item, both counted when T = 256 (s_waitcnt vmcnt(N): loads, stores and LDS-DMA retire in issue order): after
+// the K(n+1) issue — everything older has landed, K itself stays in flight — and before the first phase B of the next item
+// (K landed; the 10 dK / dV stores stay in flight).  Ragged T: the same code with both waits as vmcnt(0).
+__device__ __forceinline__ bf16x8 gload128_asm(const void* p) {
+  bf16x8 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ float gload32_asm(const void* p) {
+  float r;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+
+// delta[b, h, t] = sum_d dO[b, t, h, d] * O[b, t, h, d]  (fp32): one thread per (token, head) segment of HD elements
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+                                                         float* __restrict__ delta, long nseg, int T, int H) {
+  const long seg = (long)blockIdx.x * 256 + threadIdx.x;   // (b * T + t) * H + h
+  if (seg >= nseg) return;
+  bf16x8 a[HD / 8], c[HD / 8];
+#pragma unroll
+  for (int k = 0; k < HD / 8; ++k) {
+    a[k] = *(const bf16x8*)(o + seg * HD + 8 * k);
+    c[k] = *(const bf16x8*)(d_o + seg * HD + 8 * k);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < HD / 8; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += bf2f(a[k][e]) * bf2f(c[k][e]);
+  const long tokn = seg / H;
+  const int h = (int)(seg - tokn * H);
+  const long b = tokn / T;
+  const int t = (int)(tokn - b * T);
+  delta[(b * H + h) * T + t] = acc;
+}
+
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              bf16* __restrict__ dqkv, int T, int H, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  constexpr int DTA = (DT + 1) / 2;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const long tok = 3l * D;
+  const int tokb = (int)(tok * 2), db = D * 2;
+  char* Qt = smem;
+  char* Kt = smem + TILE_B;
+  char* St = smem + 2 * TILE_B;
+  char* Gt = smem + 3 * TILE_B;
+  float* lse2 = (float*)(smem + 4 * TILE_B + 256);
+  float* dlt = lse2 + 256;
+  const float scale = rsqrtf((float)HD);
+  const float sc2 = scale * LOG2E;
+  const int r0 = wave * 32;
+  const bool full = T == 256;      // counted waits (the store counts below assume every row exists)
+  const int nblk = (T + 31) >> 5, nchunk = (nblk + 1) >> 1;
+
+  // 36 pieces of 1 KiB: rows 0..127 (half 0) / 128..255 (half 1) of two tiles, or (whole) one whole tile; waves 0..3 issue 5
+  // pieces, waves 4..7 issue 4
+  auto issue36 = [&](char* t0, const bf16* s0, int sb0, char* t1, const bf16* s1, int sb1, int half, bool whole, int ln) {
+    const __amdgpu_buffer_rsrc_t rs0 = mk_rsrc(s0, tile_window<HD>(T, sb0)), rs1 = mk_rsrc(s1, tile_window<HD>(T, sb1));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int pp = wave + 8 * j;                 // 0..35 (36..39: not issued)
+      const bool second = !whole && pp >= 18;
+      const int I = whole ? pp : (second ? pp - 18 : pp) + 18 * half;
+      const int vo = dma_voff<HD, ROWB>(I * 64 + ln, second ? sb1 : sb0);
+      if (pp < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {
+    const int b = item / H, h = item - b * H;
+    base = qkv + (long)b * T * tok + h * HD;
+    dbase = dqkv + (long)b * T * tok + h * HD;
+    gbase = d_o + (long)b * T * D + h * HD;
+    lbase = lse + ((long)b * H + h) * T;
+    dlbase = delta + ((long)b * H + h) * T;
+  };
+  // the wave's own rows of an item: K, V fragments of its 32 keys, and (lse, delta) of its 32 query rows (lane i + 16 g' of
+  // the first 32 lanes holds row r0 + i + 16 g') -> registers
+  bf16x8 kf[2][KS], vf[2][KS];
+  float lq, dq_;
+  auto own_rows = [&](const bf16* base, const float* lbase, const float* dlbase, int ln) {
+    const int i = ln & 15, g = ln >> 4;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int row = min(r0 + 16 * t2 + i, T - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int col = min(ks * 32 + 8 * g, HD - 8);      // clamped: the fragment is zeroed below when it does not exist
+        kf[t2][ks] = gload128_asm(base + D + (long)row * tok + col);
+        vf[t2][ks] = gload128_asm(base + 2 * D + (long)row * tok + col);
+      }
+    }
+    const int row = min(r0 + (ln & 31), T - 1);
+    lq = gload32_asm(lbase + row);
+    dq_ = gload32_asm(dlbase + row);
+  };
+  // after the loads landed: zero what does not exist; lse (in log2 units) and delta of the wave's 32 query rows -> LDS
+  auto own_rows_finish = [&](int ln) {
+    const int i = ln & 15, g = ln >> 4;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const bool rok = r0 + 16 * t2 + i < T;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (!(rok && ks * 32 + 8 * g < HD)) { kf[t2][ks] = zero_frag(); vf[t2][ks] = zero_frag(); }
+    }
+    if (ln < 32) {
+      const int row = r0 + ln;
+      dlt[row] = dq_;
+      lse2[row] = row < T ? lq * LOG2E : INFINITY;    // rows >= T: p = exp2(-inf) = 0
+    }
+  };
+
+  int it = xcd_contiguous(blockIdx.x, gridDim.x);
+  const bf16 *base, *gbase;
+  const float *lbase, *dlbase;
+  bf16* dbase;
+  if (it < nitems) {
+    bases(it, base, gbase, lbase, dlbase, dbase);
+    issue36(Kt, base + D, tokb, Kt, base + D, tokb, 0, true, lane0);
+    issue36(Qt, base, tokb, Gt, gbase, db, 0, false, lane0);
+    issue36(Qt, base, tokb, Gt, gbase, db, 1, false, lane0);
+    own_rows(base, lbase, dlbase, lane0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    own_rows_finish(lane0);
+  }
+  for (; it < nitems; it += gridDim.x) {
+    const int nxt = it + gridDim.x;
+    const bool has_next = nxt < nitems;
+    const bf16 *nbase = nullptr, *ngbase = nullptr;
+    const float *nlbase = nullptr, *ndlbase = nullptr;
+    bf16* ndbase = nullptr;
+    if (has_next) bases(nxt, nbase, ngbase, nlbase, ndlbase, ndbase);
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));   // per-item copy: lane-derived addresses are not hoisted out of the item loop (and spilled)
+    const int i = lane & 15, g = lane >> 4;
+    bool kvalid[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) kvalid[ct] = r0 + 16 * ct + i < T;
+    ATTN_BARRIER();    // item boundary: lse2 / dlt of this item are written, every wave is done with the previous item's tiles
+    f32x4 dk[2][DT], dv[2][DT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
+#pragma unroll 1
+    for (int ch = 0; ch < nchunk; ++ch) {
+      // ---------------- phase A: this wave's 32 keys x the chunk's 64 queries ----------------
+#pragma unroll 1
+      for (int qh = 0; qh < 2; ++qh) {
+        const int qq0 = ch * 64 + qh * 32;
+        f32x4 st[2][2], dp[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 qa = frag_rows(Qt, qq0 + 16 * qt, ks, lane);
+            bf16x8 ga = frag_rows(Gt, qq0 + 16 * qt, ks, lane);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              st[qt][ct] = MFMA(qa, kf[ct][ks], st[qt][ct]);
+              dp[qt][ct] = MFMA(ga, vf[ct][ks], dp[qt][ct]);
+            }
+          }
+        f32x4 lq4[2], dl4[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
+          dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
+        }
+        bf16x8 pb[2], dsb[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x4 p0, p1, s0, s1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
+            p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
+            s0[r] = kvalid[ct] ? p0[r] * (dp[0][ct][r] - dl4[0][r]) : 0.f;
+            s1[r] = kvalid[ct] ? p1[r] * (dp[1][ct][r] - dl4[1][r]) : 0.f;
+          }
+          pb[ct] = pack2(p0, p1);
+          dsb[ct] = pack2(s0, s1);
+          char* sp = St + (r0 + 16 * ct + i) * ROWB + (qh * 32 + 4 * g) * 2;
+          *(bf16x4*)sp = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
+          *(bf16x4*)(sp + 32) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
+        }
+        // dV^T += dO^T P, dK^T += Q^T dS: the transposing reads are inline asm (the builtin would drain the LDS-DMA queue),
+        // two groups of 16-column tiles, each waited for as a whole
+#pragma unroll
+        for (int d0 = 0; d0 < DT; d0 += 3) {
+          bf16x8 gtf[3], qtf[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (d0 + k < DT) {
+              gtf[k] = frag_trT_a<ROWB>(Gt, qq0, 16 * (d0 + k), lane);
+              qtf[k] = frag_trT_a<ROWB>(Qt, qq0, 16 * (d0 + k), lane);
+            }
+          ATTN_LDS_WAIT();
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (d0 + k < DT) {
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) {
+                dv[ct][d0 + k] = MFMA(gtf[k], pb[ct], dv[ct][d0 + k]);
+                dk[ct][d0 + k] = MFMA(qtf[k], dsb[ct], dk[ct][d0 + k]);
+              }
+            }
+        }
+      }
+      if (ch == 0) {   // K of this item (the K^T operand of phase B) landed; younger: the previous item's dK / dV row stores
+        if (full) {
+          if constexpr (2 * ((32 * NCH + 63) / 64) == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // hd 72: 2 x 5
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                   // hd 64: 2 x 4
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      ATTN_BARRIER();   // dS^T of the chunk complete; rows [64 ch, 64 ch + 64) of the Q and dO tiles are dead
+      const bool last = ch == nchunk - 1;
+      if (has_next && (ch == 1 || last)) {
+        // the next item's Q / dO rows: 0..127 once chunk 1 is through phase A; 128..255 (and, for short T, whatever was not
+        // issued yet) at the last chunk, together with the wave's own rows (kf / vf of this item are dead: phase A is over)
+        int ln = lane0;
+        asm volatile("" : "+v"(ln));   // fresh copy: the piece offsets and row addresses are computed here, not kept in registers
+        if (ch == 1) issue36(Qt, nbase, tokb, Gt, ngbase, db, 0, false, ln);
+        if (last) {
+          if (nchunk < 2) issue36(Qt, nbase, tokb, Gt, ngbase, db, 0, false, ln);
+          issue36(Qt, nbase, tokb, Gt, ngbase, db, 1, false, ln);
+          own_rows(nbase, nlbase, ndlbase, ln);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---------------- phase B: dQ^T = K^T dS^T for the chunk's 64 queries ----------------
+      {
+        const int qtile = wave >> 1;
+        const int dt0 = (wave & 1) ? DTA : 0;
+        f32x4 dq[DTA];
+#pragma unroll
+        for (int k = 0; k < DTA; ++k) dq[k] = zero4();
+#pragma unroll 1
+        for (int ks = 0; ks < nblk; ++ks) {
+          const bf16x8 dsf = frag_trT_a<ROWB>(St, 32 * ks, 16 * qtile, lane);
+          bf16x8 ktf[DTA];
+#pragma unroll
+          for (int k = 0; k < DTA; ++k) ktf[k] = frag_trT_a<ROWB>(Kt, 32 * ks, 16 * min(dt0 + k, DT - 1), lane);
+          ATTN_LDS_WAIT();
+#pragma unroll
+          for (int k = 0; k < DTA; ++k)
+            if (dt0 + k < DT) dq[k] = MFMA(ktf[k], dsf, dq[k]);
+        }
+        // straight from the MFMA layout: rows d = 16 dt + 4 g + r, column q = i -> 8 bytes per lane.  A wave whose group has
+        // one tile fewer stores its last tile twice (same bytes): every wave issues DTA stores per chunk
+        const int q = ch * 64 + 16 * qtile + i;
+#pragma unroll
+        for (int k = 0; k < DTA; ++k) {
+          const int kk = (dt0 + k < DT) ? k : DT - 1 - dt0;
+          const int d = 16 * (dt0 + kk) + 4 * g;
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[kk][r] * scale);
+          if (d < HD && q < T) *(bf16x4*)(dbase + (long)q * tok + d) = v;
+        }
+      }
+      ATTN_BARRIER();   // dS^T is free for the next chunk (after the last chunk: K and dS^T tiles are dead)
+    }
+    int le = lane0;
+    asm volatile("" : "+v"(le));
+    if (has_next) {
+      issue36(Kt, nbase + D, tokb, Kt, nbase + D, tokb, 0, true, le);
+      // everything older than that K issue has landed: the next item's Q / dO halves and the wave's own rows
+      if (full) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- dK, then dV, of the wave's keys through its own rows of the dS^T tile ----------------
+    auto stage_store = [&](const f32x4 (&acc)[2][DT], float mul, bf16* gb) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + 4 * g;
+          if (d < HD) {
+            bf16x4 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = f2bf(acc[ct][dt][r] * mul);
+            *(bf16x4*)(St + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
+          }
+        }
+      // (asm LDS reads: behind a plain read the compiler drains the LDS-DMA of the next item's K issued just above)
+      constexpr int NQ = 32 * NCH, NI = (NQ + 63) / 64;
+      uint4 piece[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int qi = min(le + 64 * k, NQ - 1);
+        const int rr = qi / NCH, c = qi - rr * NCH;
+        const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)(St + (r0 + rr) * ROWB + c * 16);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(piece[k]) : "v"(a) : "memory");
+      }
+      ATTN_LDS_WAIT();
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int qi = le + 64 * k;
+        const int rr = qi / NCH, c = qi - rr * NCH;
+        if (qi < NQ && r0 + rr < T) *(uint4*)(gb + (long)(r0 + rr) * tok + c * 8) = piece[k];
+      }
+    };
+    stage_store(dk, scale, dbase + D);
+    stage_store(dv, 1.f, dbase + 2 * D);
+    if (has_next) {
+      own_rows_finish(le);    // (the loads were waited for above) -> kf, vf, lse2, dlt of the next item
+      base = nbase; gbase = ngbase; lbase = nlbase; dlbase = ndlbase; dbase = ndbase;
+    }
+  }
+}
+
 int attn_fwd_oneshot() {   // REED_ATTN_FWD=oneshot: the round-1 forward also for T <= 256 (A/B)
   static int v = -1;
   if (v < 0) { const char* e = getenv("REED_ATTN_FWD"); v = (e && e[0] == 'o') ? 1 : 0; }
@@ -1219,3 +1569,38 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
 }
 
 // ------------------------------------------------------------------------------------------
+
+// Backward with a workspace (ws: reed_attention_bwd_ws_floats(B, T, H) floats, caller-owned): delta = rowsum(dO * O) by a row
+// kernel, then the persistent key-stationary kernel (attn_bwd_ksp_kernel).  REED_ATTN_BWD=2p / ks1 select the two-phase / the
+// one-shot key-stationary kernel of reed_attention_bwd instead (same-box A/B).
+extern "C" int64_t reed_attention_bwd_ws_floats(int B, int T, int H) { return (int64_t)B * T * H; }
+
+extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
+                                     int B, int T, int H, int hd, void* stream) {
+  static const bool other = getenv("REED_ATTN_BWD") != nullptr || (getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1);
+  if (other || !ws) return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
+  REED_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attention_bwd: null pointer");
+  REED_CHECK_ARG(hd == 64 || hd == 72, "attention: head_dim %d unsupported (64 or 72)", hd);
+  REED_CHECK_ARG(B > 0 && H > 0 && T > 0 && T <= 256, "attention_bwd: B=%d H=%d T=%d unsupported (training path is T <= 256)", B, H, T);
+  const int lds = 4 * TILE_B + 256 + 2048;
+  const int nitems = B * H;
+  const long nseg = (long)B * T * H;
+  int ncu = num_cus();
+  ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
+  const dim3 pgrid(nitems < ncu ? nitems : ncu);
+  hipStream_t s = (hipStream_t)stream;
+#define REED_BWD_KSP(HD)                                                                                                  \
+  do {                                                                                                                    \
+    static int once = set_lds(attn_bwd_ksp_kernel<HD>, lds);                                                              \
+    if (once) return once;                                                                                                \
+    REED_KLAUNCH(attn_delta_kernel<HD>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, ws, nseg, T, H); \
+    REED_LAUNCH_CHECK();                                                                                                  \
+    REED_KLAUNCH(attn_bwd_ksp_kernel<HD>, pgrid, dim3(512), lds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
+                 (bf16*)dqkv, T, H, nitems);                                                                              \
+  } while (0)
+  if (hd == 64) REED_BWD_KSP(64);
+  else REED_BWD_KSP(72);
+#undef REED_BWD_KSP
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}

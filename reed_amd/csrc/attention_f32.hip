@@ -280,3 +280,10 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
+
+// the workspace form of the 16-bit builds (their persistent backward wants delta = rowsum(dO * O) precomputed): no workspace here
+extern "C" int64_t reed_attention_bwd_ws_floats(int, int, int) { return 0; }
+extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float*, int B,
+                                     int T, int H, int hd, void* stream) {
+  return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
+}

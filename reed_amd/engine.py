@@ -373,6 +373,8 @@ class Engine:
             return torch.empty(s, dtype=torch.float32, device=dev)
 
         group_wgrad = ops.wgrad_group_fits([(D, Hm), (Hm, D), (D, D), (3 * D, D)])
+        nws = ops.attention_bwd_ws_floats(B, T, H)       # delta = rowsum(dO * O) of the persistent attention backward
+        attn_ws = f32(nws) if nws else None
         side = None
         if self.wgrad_stream or (self.wgrad_stream is None and M <= self.wgrad_stream_max_tokens):
             if self._side is None:
@@ -508,7 +510,7 @@ class Engine:
             do = bf(M, D)
             self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
             dqkv = bf(M, 3 * D)
-            ops.attention_bwd(bk.qkv_a, bk.o, do, bk.lse, dqkv, B, T, H, hd)
+            ops.attention_bwd(bk.qkv_a, bk.o, do, bk.lse, dqkv, B, T, H, hd, ws=attn_ws)
             if m.qk_norm:  # back through the per-head LayerNorm of q and k; parameter grads via per-block partials
                 nb = (M * 3 * H + 255) // 256
                 part = f32(nb, 4 * hd)

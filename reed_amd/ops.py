@@ -335,8 +335,17 @@ def attention_fwd(qkv, o, lse, B, T, H, hd):
     _call("reed_attention_fwd", _p(qkv), _p(o), _p(lse), B, T, H, hd, _stream())
 
 
-def attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd):
-    _call("reed_attention_bwd", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream())
+def attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd, ws=None):
+    """ws: f32 workspace of attention_bwd_ws_floats(B, T, H) elements -> the persistent backward (delta by a row kernel in
+    front); None -> the workspace-free kernels."""
+    if ws is None:
+        _call("reed_attention_bwd", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream())
+    else:
+        _call("reed_attention_bwd_ws", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), _p(ws), B, T, H, hd, _stream())
+
+
+def attention_bwd_ws_floats(B, T, H):
+    return int(_lib.load(_PRECISION).reed_attention_bwd_ws_floats(B, T, H))
 
 
 def qk_norm_fwd(qkv, qw, qb, kw, kb, out, stats, M, H, hd, eps=1e-5):

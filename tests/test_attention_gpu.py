@@ -56,7 +56,10 @@ def test_attention_fwd_exact_pattern(dev):
 
 @pytest.mark.parametrize("B,T,H,hd", [(2, 256, 16, 72), (2, 256, 6, 64), (2, 64, 4, 72), (1, 16, 2, 64), (1, 100, 2, 72),
                                        (3, 200, 5, 72), (2, 129, 3, 64), (5, 128, 4, 72), (20, 256, 16, 72)])
-def test_attention_bwd(dev, B, T, H, hd):
+@pytest.mark.parametrize("form", ["ws", "plain"])
+def test_attention_bwd(dev, B, T, H, hd, form):
+    """form "ws": the persistent key-stationary backward behind reed_attention_bwd_ws (delta by a row kernel, the next item's
+    operands in flight under the current one) — what the engine calls; "plain": the workspace-free entry point."""
     from reed_amd import ops
     g = torch.Generator().manual_seed(5 + T)
     qkv = (torch.randn(B, T, 3, H, hd, generator=g)).to(torch.bfloat16).to(dev)
@@ -65,7 +68,8 @@ def test_attention_bwd(dev, B, T, H, hd):
     lse = torch.zeros(B, H, T, device=dev)
     ops.attention_fwd(qkv, o, lse, B, T, H, hd)
     dqkv = torch.full_like(qkv, float("nan"))
-    ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd)
+    ws = torch.full((ops.attention_bwd_ws_floats(B, T, H),), float("nan"), device=dev) if form == "ws" else None
+    ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd, ws=ws)
     q32 = qkv.float().requires_grad_(True)
     ro, _ = _ref(q32, B, T, H, hd)
     ro.backward(do.float())
@@ -80,24 +84,27 @@ def test_attention_bwd(dev, B, T, H, hd):
 
 
 def test_attention_deterministic_and_forms_agree(dev):
-    """Same inputs twice -> identical bits, forward and backward (no atomics, fixed summation order); and the split backward
-    (four workgroups per (batch, head), csrc/attention.hip) agrees with the round-1 fused form to bf16 resolution."""
-    import os
-    import subprocess
-    import sys
+    """Same inputs twice -> identical bits, forward and backward (no atomics, fixed summation order), with more (batch, head)
+    items than CUs so that the persistent kernels' item loops, prefetches and counted waits are in play (a tile overwritten
+    before its last reader, or read before it landed, shows up as run-to-run differences); and the persistent backward agrees
+    with the workspace-free one to bf16 resolution (the same products; delta summed in another order)."""
     from reed_amd import ops
-    B, T, H, hd = 6, 256, 16, 72
+    B, T, H, hd = 40, 256, 16, 72
     g = torch.Generator().manual_seed(11)
     qkv = torch.randn(B, T, 3, H, hd, generator=g).to(torch.bfloat16).to(dev)
     do = torch.randn(B, T, H * hd, generator=g).to(torch.bfloat16).to(dev)
     outs = []
-    for _ in range(2):
+    for rep in range(3):
         o = torch.zeros(B, T, H * hd, dtype=torch.bfloat16, device=dev)
         lse = torch.zeros(B, H, T, device=dev)
         dqkv = torch.zeros_like(qkv)
         ops.attention_fwd(qkv, o, lse, B, T, H, hd)
-        ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd)
+        ws = torch.empty(ops.attention_bwd_ws_floats(B, T, H), device=dev) if rep < 2 else None
+        ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd, ws=ws)
         torch.cuda.synchronize()
         outs.append((o.clone(), lse.clone(), dqkv.clone()))
-    for a, b in zip(*outs):
+    for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+    a, b = outs[0][2].float(), outs[2][2].float()
+    assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+    assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.99999

@@ -31,8 +31,10 @@ for b in [int(a) for a in sys.argv[1:]] or [32, 256]:
     do = torch.randn(M, D, device=dev).to(torch.bfloat16)
     dqkv = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(b, H, T, device=dev)
+    import os
+    ws = None if os.environ.get("REED_ATTN_BWD") else torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
     tf = timeit(lambda: ops.attention_fwd(qkv, o, lse, b, T, H, hd))
-    tb = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd))
+    tb = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd, ws=ws))
     ff, fb = 4.0 * T * T * hd * b * H, 10.0 * T * T * hd * b * H
     bytes_f, bytes_b = M * D * 2 * 4, M * D * 2 * 8
     print(f"b={b:4d} fwd {tf*1e6:8.1f} us {ff/tf/1e12:7.1f} TFLOP/s {bytes_f/tf/1e12:5.2f} TB/s | "
