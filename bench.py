@@ -371,6 +371,12 @@ def main():
 
     # W untimed warm-up steps — more when the data-parallel step still measures its CU reserve (trainer.py): that
     # measurement (two steps per candidate) stays out of the timed region
+    # REED_MAIN_PRIO=1 (experiment): run the steps on a high-priority stream (the device has two levels; the optimiser's and the
+    # weight-gradient side streams stay at the default level)
+    if os.environ.get("REED_MAIN_PRIO", "0") == "1":
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     n_warm = max(args.warmup, step.tune_steps_left() + 1 if step.tune_steps_left() else 0)
     for _ in range(n_warm):
         res = step(None, labels, zs, moments=moments)

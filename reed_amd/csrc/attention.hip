@@ -922,6 +922,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ks_kernel(const bf16* __restr
   char* Gt = smem + 3 * TILE_B;   // dO
   float* lse2 = (float*)(smem + 4 * TILE_B + 256);
   float* dlt = lse2 + 256;
+  // the 256 bytes behind the dO tile are read (x 0) by the k-step that covers columns 64..95 of the tile's last row: keep them
+  // zero — LDS is not cleared between kernels, and a NaN bit pattern left there by another kernel times zero is a NaN
+  if (tid < 16) *(uint4*)(smem + 4 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
   const int r0 = wave * 32;       // this wave's rows: its keys, and the queries whose delta / log-sum-exp it prepares
@@ -1114,8 +1117,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ks_kernel(const bf16* __restr
 // and waits, then computes with the memory system idle (one 147-KiB workgroup per CU: nothing to switch to).
 // What makes the overlap possible here is that in the key-stationary order the Q and dO tiles are STREAMS — the 64 rows of
 // chunk c are read in phase A of chunk c and never again — and only K is resident:
-//   * rows 0..127 of Q(n+1), dO(n+1) are issued (LDS-DMA, 36 pieces of 1 KiB) after the barrier that ends phase A of chunk 1
-//     of item n, rows 128..255 after the one that ends phase A of chunk 3: each lands a whole item before it is read;
+//   * the 64 rows of chunk c of Q(n+1), dO(n+1) are issued (LDS-DMA, 18 pieces of 1 KiB) after the barrier that ends phase A of
+//     chunk c of item n: each lands a whole item before it is read;
 //   * the wave's own key rows of item n+1 — K and V as MFMA fragments — and the (log-sum-exp, delta) pairs of its 32 query
 //     rows are plain global loads into registers (inline asm: the compiler never waits for them) issued at that same point,
 //     into the registers of the current item's fragments (dead: phase A is over);
@@ -1125,9 +1128,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ks_kernel(const bf16* __restr
 //     dK / dV through the wave's own rows of the dS^T tile (dead after the last phase B), one after the other.
 // delta = rowsum(dO * O) comes from a row kernel in front (attn_delta_kernel: it reads the bytes of dO and O this kernel no
 // longer reads — the traffic is the same — and keeps 48 fragment registers per lane out of the pipeline).
-// Two waits per item, both counted when T = 256 (s_waitcnt vmcnt(N): loads, stores and LDS-DMA retire in issue order): after
-// the K(n+1) issue — everything older has landed, K itself stays in flight — and before the first phase B of the next item
-// (K landed; the 10 dK / dV stores stay in flight).  Ragged T: the same code with both waits as vmcnt(0).
+// Two waits per item, both counted when T = 256 (s_waitcnt vmcnt(N): loads, stores and LDS-DMA retire in issue order): at the
+// end of the item — everything older than the K(n+1) issue has landed, K itself and the dK / dV row stores behind it stay in
+// flight — and before the first phase B of the next item (K landed; the stores stay in flight).  Ragged T: the same code with
+// both waits as vmcnt(0).
 __device__ __forceinline__ bf16x8 gload128_asm(const void* p) {
   bf16x8 r;
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 template <int HD>
 __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              bf16* __restrict__ dqkv, int T, int H, int nitems) {
+                                                              bf16* __restrict__ dqkv, int T, int H, int nitems, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
   constexpr int DTA = (DT + 1) / 2;
@@ -1181,6 +1185,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
   char* Gt = smem + 3 * TILE_B;
   float* lse2 = (float*)(smem + 4 * TILE_B + 256);
   float* dlt = lse2 + 256;
+  if (tid < 16) *(uint4*)(smem + 4 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);   // read (x 0) behind the dO tile's last row
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
   const int r0 = wave * 32;
@@ -1198,6 +1203,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
       const int I = whole ? pp : (second ? pp - 18 : pp) + 18 * half;
       const int vo = dma_voff<HD, ROWB>(I * 64 + ln, second ? sb1 : sb0);
       if (pp < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  // the 64 rows of chunk c of the Q and dO tiles (9 + 9 pieces): wave w issues pieces w and w + 8, waves 0 / 1 also 16 / 17
+  auto issue_chunk = [&](const bf16* qb, const bf16* gb2, int c, int ln) {
+    const __amdgpu_buffer_rsrc_t rs0 = mk_rsrc(qb, tile_window<HD>(T, tokb)), rs1 = mk_rsrc(gb2, tile_window<HD>(T, db));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int pp = wave + 8 * j;                 // 0..17 (18..23: not issued)
+      const bool second = pp >= 9;
+      const int I = 9 * c + (second ? pp - 9 : pp);
+      const int vo = dma_voff<HD, ROWB>(I * 64 + ln, second ? db : tokb);
+      if (pp < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? Gt : Qt) + I * 1024), 16, vo, 0, 0, 0);
     }
   };
   auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {
@@ -1282,7 +1299,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
     for (int ch = 0; ch < nchunk; ++ch) {
       // ---------------- phase A: this wave's 32 keys x the chunk's 64 queries ----------------
 #pragma unroll 1
-      for (int qh = 0; qh < 2; ++qh) {
+      for (int qh = 0; qh < ((dbg & 1) ? 0 : 2); ++qh) {   // dbg bit 0 (diagnosis only, tools/time_attn.py): skip phase A
         const int qq0 = ch * 64 + qh * 32;
         f32x4 st[2][2], dp[2][2];
 #pragma unroll
@@ -1357,15 +1374,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
       }
       ATTN_BARRIER();   // dS^T of the chunk complete; rows [64 ch, 64 ch + 64) of the Q and dO tiles are dead
       const bool last = ch == nchunk - 1;
-      if (has_next && (ch == 1 || last)) {
-        // the next item's Q / dO rows: 0..127 once chunk 1 is through phase A; 128..255 (and, for short T, whatever was not
-        // issued yet) at the last chunk, together with the wave's own rows (kf / vf of this item are dead: phase A is over)
+      if (has_next) {
+        // the next item's Q / dO rows of this chunk (dead from here on) — a whole item before they are read; at the last chunk
+        // also whatever rows a short T never reached, and the wave's own rows (kf / vf of this item are dead: phase A is over)
         int ln = lane0;
         asm volatile("" : "+v"(ln));   // fresh copy: the piece offsets and row addresses are computed here, not kept in registers
-        if (ch == 1) issue36(Qt, nbase, tokb, Gt, ngbase, db, 0, false, ln);
+        issue_chunk(nbase, ngbase, ch, ln);
         if (last) {
-          if (nchunk < 2) issue36(Qt, nbase, tokb, Gt, ngbase, db, 0, false, ln);
-          issue36(Qt, nbase, tokb, Gt, ngbase, db, 1, false, ln);
+          for (int c2 = ch + 1; c2 < 4; ++c2) issue_chunk(nbase, ngbase, c2, ln);
           own_rows(nbase, nlbase, ndlbase, ln);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1378,7 +1394,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
 #pragma unroll
         for (int k = 0; k < DTA; ++k) dq[k] = zero4();
 #pragma unroll 1
-        for (int ks = 0; ks < nblk; ++ks) {
+        for (int ks = 0; ks < ((dbg & 2) ? 0 : nblk); ++ks) {   // dbg bit 1: skip phase B's products
           const bf16x8 dsf = frag_trT_a<ROWB>(St, 32 * ks, 16 * qtile, lane);
           bf16x8 ktf[DTA];
 #pragma unroll
@@ -1407,13 +1423,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
     asm volatile("" : "+v"(le));
     if (has_next) {
       issue36(Kt, nbase + D, tokb, Kt, nbase + D, tokb, 0, true, le);
-      // everything older than that K issue has landed: the next item's Q / dO halves and the wave's own rows
-      if (full) {
-        if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---------------- dK, then dV, of the wave's keys through its own rows of the dS^T tile ----------------
@@ -1451,7 +1460,344 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
     stage_store(dk, scale, dbase + D);
     stage_store(dv, 1.f, dbase + 2 * D);
     if (has_next) {
-      own_rows_finish(le);    // (the loads were waited for above) -> kf, vf, lse2, dlt of the next item
+      // everything older than the K issue has landed — the next item's Q / dO chunks and the wave's own rows; younger and still
+      // in flight: K's pieces (5 for waves 0..3, 4 for 4..7) and the dK / dV row stores issued since
+      __builtin_amdgcn_sched_barrier(0);
+      if (full) {
+        constexpr int NST = 2 * ((32 * NCH + 63) / 64);
+        if constexpr (NST == 10) {
+          if (wave < 4) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        } else {
+          if (wave < 4) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      own_rows_finish(le);    // -> kf, vf, lse2, dlt of the next item
+      base = nbase; gbase = ngbase; lbase = nlbase; dlbase = ndlbase; dbase = ndbase;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The persistent key-stationary backward for T = 256 with the operand traffic SPREAD over the item (the form the engine runs).
+// attn_bwd_ksp_kernel above still asks for half of an item's bytes at its very end — the wave's own K / V rows (72 KiB per
+// CU), the last Q / dO rows and K(n+1) can only be issued when phase A of the last chunk has released their registers and
+// tile rows — and the memory system serves that burst at ~3.5 TB/s while every CU waits: with the products skipped the kernel
+// takes 340 us, and the products' 190 us ADD to it (REED_ATTN_KSP_DBG).  Here nothing but the wave's own 32 V
+// rows is asked for late:
+//   * Q and dO are STREAMS (the 64 rows of a chunk are read in its phase A and never again): two 64-row ring slots each
+//     instead of whole tiles, chunk G + 2 issued into the slot phase A of chunk G has just released — across item boundaries;
+//   * the 36 KiB that frees hold a second K tile: K(n+1) is issued during chunk 0 of item n and serves both as the K^T operand
+//     of phase B and, through plain fragment reads at the start of item n+1, as the wave's own K rows;
+//   * only the V fragments of the wave's 32 keys (and the lse / delta scalars of its 32 query rows) come straight from global
+//     memory into registers, issued when phase A of the last chunk is over.
+// Every wait of the item is a counted s_waitcnt vmcnt(N) (loads, stores and LDS-DMA retire in issue order).  A chunk of Q + dO is
+// 20 pieces of 1 KiB (64 rows of 160 bytes, twice) and a K tile 36: waves 0..3 issue 3 of a chunk and 5 of a K tile, waves 4..7
+// issue 2 and 4, so N depends on the wave's half.  Per item and wave, in issue order:
+//   c=0: X0[3|2] K(n+1)[5|4] dQ[3] | c=1: X1[3|2] dQ[3] | c=2: X2[3|2] dQ[3] | c=3: X3[3|2] own[8] dQ[3] | dK, dV rows[2 NI]
+//   (X0, X1 = chunks 2, 3 of this item; X2, X3 = chunks 0, 1 of the next).  Chunk 2 is needed when chunk 1 ends: X0 landed <=>
+//   at most K + X + 6 younger operations outstanding (14 / 12); chunk 3 when chunk 2 ends: X1 <=> X + 6 (9 / 8); the
+//   item-end wait (the own rows landed: at most 3 + 2 NI younger, the same for every wave) covers X2, X3 and K(n+1).
+// The ring slots use 160-byte rows (ROWF: conflict-free ds_read_b128 and transposing reads; with 144-byte rows 7 of the 8 rows
+// a ds_read_b128 lane group takes at g = 1 share banks with its g = 0 rows), the K and dS^T tiles keep 144 (LDS budget).
+// LDS: Q ring 20 | dO ring 20 | K x 2 72 | dS^T 36 | lse, delta x 2 4 = 152 KiB.
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16* __restrict__ dqkv, int H, int nitems, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = 256;
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  constexpr int DTA = (DT + 1) / 2;
+  constexpr int CHB = 64 * ROWF;                    // one ring slot: 64 rows of 160 bytes (conflict-free ds_read_b128, see ROWF)
+  constexpr int NI = (32 * NCH + 63) / 64;          // row-store instructions per wave for dK (and for dV)
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const long tok = 3l * D;
+  const int tokb = (int)(tok * 2), db = D * 2;
+  char* Qr = smem;
+  char* Gr = smem + 2 * CHB;
+  char* Kb = smem + 4 * CHB;                        // two K tiles
+  char* St = Kb + 2 * TILE_B;
+  float* ld2 = (float*)(St + TILE_B);               // [2 items][lse2[256] | dlt[256]]
+  const float scale = rsqrtf((float)HD);
+  const float sc2 = scale * LOG2E;
+  const int r0 = wave * 32;
+
+  // chunk `c` (64 rows) of the Q and dO tiles of an item -> ring slot c & 1: 10 + 10 pieces of 1 KiB (16-byte lanes; a 12-byte
+  // lane — buffer_load_dwordx3 ... lds — would give every wave the same piece count, but the hardware puts each lane's 12 bytes
+  // in a 16-byte LDS slot: tools/micro/dma12.hip).  Wave w issues pieces w and w + 8, waves 0..3 also 16..19
+  auto issue_chunk = [&](const bf16* qb, const bf16* gb2, int c, int ln) {
+    const __amdgpu_buffer_rsrc_t rs0 = mk_rsrc(qb, tile_window<HD>(T, tokb)), rs1 = mk_rsrc(gb2, tile_window<HD>(T, db));
+    char* q = Qr + (c & 1) * CHB;
+    char* g2 = Gr + (c & 1) * CHB;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int pp = wave + 8 * j;                  // 0..19 (20..23: not issued)
+      const bool second = pp >= 10;
+      const int I = second ? pp - 10 : pp;          // piece inside the chunk
+      const int sb = second ? db : tokb;
+      const int vo = dma_voff<HD, ROWF>(I * 64 + ln, sb);
+      const int v2 = vo == DMA_OOB ? DMA_OOB : vo + c * 64 * sb;
+      if (pp < 20) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? g2 : q) + I * 1024), 16, v2, 0, 0, 0);
+    }
+  };
+  // a whole K tile: 36 pieces, waves 0..3 issue 5, waves 4..7 issue 4
+  auto issue_k = [&](const bf16* kb, char* dst, int ln) {
+    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(kb, tile_window<HD>(T, tokb));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int I = wave + 8 * j;
+      const int vo = dma_voff<HD, ROWB>(I * 64 + ln, tokb);   // (not inside the builtin's argument list: clang's host pass then drops the kernel)
+      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {
+    const int b = item / H, h = item - b * H;
+    base = qkv + (long)b * T * tok + h * HD;
+    dbase = dqkv + (long)b * T * tok + h * HD;
+    gbase = d_o + (long)b * T * D + h * HD;
+    lbase = lse + ((long)b * H + h) * T;
+    dlbase = delta + ((long)b * H + h) * T;
+  };
+  bf16x8 kf[2][KS], vf[2][KS];
+  float lq, dq_;
+  // the wave's own rows of an item that do not come through LDS: V fragments of its 32 keys, (lse, delta) of its 32 query rows
+  auto own_rows = [&](const bf16* base, const float* lbase, const float* dlbase, int ln) {
+    const int i = ln & 15, g = ln >> 4;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        vf[t2][ks] = gload128_asm(base + 2 * D + (long)(r0 + 16 * t2 + i) * tok + min(ks * 32 + 8 * g, HD - 8));
+    lq = gload32_asm(lbase + r0 + (ln & 31));
+    dq_ = gload32_asm(dlbase + r0 + (ln & 31));
+  };
+  auto own_rows_finish = [&](int ln, float* ld) {
+    const int g = ln >> 4;
+    if (HD % 32 != 0) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+        if ((KS - 1) * 32 + 8 * g >= HD) vf[t2][KS - 1] = zero_frag();
+    }
+    if (ln < 32) {
+      ld[r0 + ln] = lq * LOG2E;
+      ld[256 + r0 + ln] = dq_;
+    }
+  };
+
+  int it = xcd_contiguous(blockIdx.x, gridDim.x);
+  const bf16 *base, *gbase;
+  const float *lbase, *dlbase;
+  bf16* dbase;
+  if (it < nitems) {
+    bases(it, base, gbase, lbase, dlbase, dbase);
+    issue_k(base + D, Kb, lane0);
+    issue_chunk(base, gbase, 0, lane0);
+    issue_chunk(base, gbase, 1, lane0);
+    own_rows(base, lbase, dlbase, lane0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    own_rows_finish(lane0, ld2);
+  }
+  int par = 0;     // item parity: K tile and lse / delta set of the current item
+  for (; it < nitems; it += gridDim.x, par ^= 1) {
+    const int nxt = it + gridDim.x;
+    const bool has_next = nxt < nitems;
+    const bf16 *nbase = nullptr, *ngbase = nullptr;
+    const float *nlbase = nullptr, *ndlbase = nullptr;
+    bf16* ndbase = nullptr;
+    if (has_next) bases(nxt, nbase, ngbase, nlbase, ndlbase, ndbase);
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));   // per-item copy: lane-derived addresses are not hoisted out of the item loop (and spilled)
+    const int i = lane & 15, g = lane >> 4;
+    const char* Kt = Kb + par * TILE_B;
+    const float* lse2 = ld2 + par * 512;
+    const float* dlt = lse2 + 256;
+    ATTN_BARRIER();    // item boundary: K, lse / delta of this item are in LDS (every wave waited for its pieces and wrote its rows)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
+    f32x4 dk[2][DT], dv[2][DT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {
+      const char* Qs = Qr + (ch & 1) * CHB;
+      const char* Gs = Gr + (ch & 1) * CHB;
+      // ---------------- phase A: this wave's 32 keys x the chunk's 64 queries ----------------
+#pragma unroll 1
+      for (int qh = 0; qh < ((dbg & 1) ? 0 : 2); ++qh) {   // dbg bit 0 (diagnosis only): skip phase A
+        const int ql = qh * 32;                // row inside the ring slot
+        const int qq0 = ch * 64 + ql;          // query index inside the item
+        f32x4 st[2][2], dp[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            // (hd 72, last k-step: columns 64..79 exist in a 160-byte row, 72..79 zero; lanes g >= 2 re-read them — their
+            // partner slots in kf / vf are zero)
+            bf16x8 qa = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Qs, ql + 16 * qt, ks, lane) : frag_rows_f<false>(Qs, ql + 16 * qt, ks, lane);
+            bf16x8 ga = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Gs, ql + 16 * qt, ks, lane) : frag_rows_f<false>(Gs, ql + 16 * qt, ks, lane);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              st[qt][ct] = MFMA(qa, kf[ct][ks], st[qt][ct]);
+              dp[qt][ct] = MFMA(ga, vf[ct][ks], dp[qt][ct]);
+            }
+          }
+        f32x4 lq4[2], dl4[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
+          dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
+        }
+        bf16x8 pb[2], dsb[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x4 p0, p1, s0, s1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
+            p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
+            s0[r] = p0[r] * (dp[0][ct][r] - dl4[0][r]);
+            s1[r] = p1[r] * (dp[1][ct][r] - dl4[1][r]);
+          }
+          pb[ct] = pack2(p0, p1);
+          dsb[ct] = pack2(s0, s1);
+          char* sp = St + (r0 + 16 * ct + i) * ROWB + (ql + 4 * g) * 2;
+          *(bf16x4*)sp = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
+          *(bf16x4*)(sp + 32) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int d0 = 0; d0 < DT; d0 += 3) {
+          bf16x8 gtf[3], qtf[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (d0 + k < DT) {
+              gtf[k] = frag_trT_a<ROWF>(Gs, ql, 16 * (d0 + k), lane);
+              qtf[k] = frag_trT_a<ROWF>(Qs, ql, 16 * (d0 + k), lane);
+            }
+          ATTN_LDS_WAIT();
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (d0 + k < DT) {
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) {
+                dv[ct][d0 + k] = MFMA(gtf[k], pb[ct], dv[ct][d0 + k]);
+                dk[ct][d0 + k] = MFMA(qtf[k], dsb[ct], dk[ct][d0 + k]);
+              }
+            }
+        }
+      }
+      ATTN_BARRIER();   // dS^T of the chunk complete; the ring slot is released
+      if (ch < 2 || has_next) {
+        int ln = lane0;
+        asm volatile("" : "+v"(ln));   // fresh copy: piece offsets and row addresses are computed here, not kept in registers
+        if (ch < 2) issue_chunk(base, gbase, ch + 2, ln);
+        else issue_chunk(nbase, ngbase, ch - 2, ln);
+        if (has_next && ch == 0) issue_k(nbase + D, Kb + (par ^ 1) * TILE_B, ln);
+        if (has_next && ch == 3) own_rows(nbase, nlbase, ndlbase, ln);   // vf of this item is dead: phase A is over
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---------------- phase B: dQ^T = K^T dS^T for the chunk's 64 queries ----------------
+      {
+        const int qtile = wave >> 1;
+        const int dt0 = (wave & 1) ? DTA : 0;
+        f32x4 dq[DTA];
+#pragma unroll
+        for (int k = 0; k < DTA; ++k) dq[k] = zero4();
+#pragma unroll 1
+        for (int ks = 0; ks < ((dbg & 2) ? 0 : 8); ++ks) {   // dbg bit 1: skip phase B's products
+          const bf16x8 dsf = frag_trT_a<ROWB>(St, 32 * ks, 16 * qtile, lane);
+          bf16x8 ktf[DTA];
+#pragma unroll
+          for (int k = 0; k < DTA; ++k) ktf[k] = frag_trT_a<ROWB>(Kt, 32 * ks, 16 * min(dt0 + k, DT - 1), lane);
+          ATTN_LDS_WAIT();
+#pragma unroll
+          for (int k = 0; k < DTA; ++k)
+            if (dt0 + k < DT) dq[k] = MFMA(ktf[k], dsf, dq[k]);
+        }
+        const int q = ch * 64 + 16 * qtile + i;
+#pragma unroll
+        for (int k = 0; k < DTA; ++k) {
+          const int kk = (dt0 + k < DT) ? k : DT - 1 - dt0;
+          const int d = 16 * (dt0 + kk) + 4 * g;
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[kk][r] * scale);
+          if (d < HD) *(bf16x4*)(dbase + (long)q * tok + d) = v;
+        }
+      }
+      // the next chunk's Q / dO rows (issued one chunk ago) have landed: counted, see the table in the header
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) {
+        if (ch == 1) {          // chunk 2 (X0) landed; younger: K(n+1) 5 | 4, dQ 3, X1 3 | 2, dQ 3
+          if (wave < 4) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else if (ch == 2) {   // chunk 3 (X1) landed; younger: dQ 3, X2 3 | 2, dQ 3
+          if (wave < 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+      } else if (ch == 1 || ch == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the last item: nothing is issued behind it
+      }
+      ATTN_BARRIER();   // dS^T is free for the next chunk; the next chunk's ring slot is complete
+    }
+    // ---------------- dK, then dV, of the wave's keys through its own rows of the dS^T tile ----------------
+    int le = lane0;
+    asm volatile("" : "+v"(le));
+    auto stage_store = [&](const f32x4 (&acc)[2][DT], float mul, bf16* gb) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + 4 * g;
+          if (d < HD) {
+            bf16x4 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = f2bf(acc[ct][dt][r] * mul);
+            *(bf16x4*)(St + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
+          }
+        }
+      constexpr int NQ = 32 * NCH;
+      uint4 piece[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int qi = min(le + 64 * k, NQ - 1);
+        const int rr = qi / NCH, c = qi - rr * NCH;
+        const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)(St + (r0 + rr) * ROWB + c * 16);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(piece[k]) : "v"(a) : "memory");
+      }
+      ATTN_LDS_WAIT();
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int qi = le + 64 * k;
+        const int rr = qi / NCH, c = qi - rr * NCH;
+        if (qi < NQ) *(uint4*)(gb + (long)(r0 + rr) * tok + c * 8) = piece[k];
+      }
+    };
+    stage_store(dk, scale, dbase + D);
+    stage_store(dv, 1.f, dbase + 2 * D);
+    if (has_next) {
+      // the wave's own rows of the next item have landed (and with them everything older: X3, K(n+1)); younger and still in
+      // flight: the last chunk's dQ stores and the dK / dV row stores
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      own_rows_finish(le, ld2 + (par ^ 1) * 512);
       base = nbase; gbase = ngbase; lbase = nlbase; dlbase = ndlbase; dbase = ndbase;
     }
   }
@@ -1589,6 +1935,7 @@ extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void*
   ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
   const dim3 pgrid(nitems < ncu ? nitems : ncu);
   hipStream_t s = (hipStream_t)stream;
+  static const int dbg = getenv("REED_ATTN_KSP_DBG") ? atoi(getenv("REED_ATTN_KSP_DBG")) : 0;   // diagnosis: skip parts of the work
 #define REED_BWD_KSP(HD)                                                                                                  \
   do {                                                                                                                    \
     static int once = set_lds(attn_bwd_ksp_kernel<HD>, lds);                                                              \
@@ -1596,8 +1943,26 @@ extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void*
     REED_KLAUNCH(attn_delta_kernel<HD>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, ws, nseg, T, H); \
     REED_LAUNCH_CHECK();                                                                                                  \
     REED_KLAUNCH(attn_bwd_ksp_kernel<HD>, pgrid, dim3(512), lds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
-                 (bf16*)dqkv, T, H, nitems);                                                                              \
+                 (bf16*)dqkv, T, H, nitems, dbg);                                                                              \
   } while (0)
+  static const bool noring = getenv("REED_ATTN_RING") && atoi(getenv("REED_ATTN_RING")) == 0;   // A/B: the tile form at T = 256 too
+  if (T == 256 && !noring) {
+    const int rlds = 4 * 64 * ROWF + 3 * TILE_B + 4096;
+#define REED_BWD_RING(HD)                                                                                                 \
+  do {                                                                                                                    \
+    static int once = set_lds(attn_bwd_ring_kernel<HD>, rlds);                                                            \
+    if (once) return once;                                                                                                \
+    REED_KLAUNCH(attn_delta_kernel<HD>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, ws, nseg, T, H); \
+    REED_LAUNCH_CHECK();                                                                                                  \
+    REED_KLAUNCH(attn_bwd_ring_kernel<HD>, pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
+                 (bf16*)dqkv, H, nitems, dbg);                                                                            \
+  } while (0)
+    if (hd == 64) REED_BWD_RING(64);
+    else REED_BWD_RING(72);
+#undef REED_BWD_RING
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
   if (hd == 64) REED_BWD_KSP(64);
   else REED_BWD_KSP(72);
 #undef REED_BWD_KSP

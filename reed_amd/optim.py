@@ -37,7 +37,10 @@ class FusedAdamWEMA:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.partial = torch.empty(_NB, dtype=torch.float32, device=dev)
-        self.norm_clip = torch.zeros(2, dtype=torch.float32, device=dev)  # [||g||, clip coefficient]
+        # [||g||, clip coefficient] of the last step — two buffers used in turn, so that the norm a caller took from step k
+        # (grad_norm below: a view, no copy kernel) stays valid until step k + 2 writes it again
+        self._norm_clips = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.norm_clip = self._norm_clips[0]
         # fp16 training (model.precision == "fp16"; the reference's README recipe): dynamic loss scaling with
         # torch.amp.GradScaler's defaults, as accelerate builds it — [scale, growth_tracker, found_inf, steps_taken] on the
         # device. TrainStep multiplies the loss by scaler_state[0]; step() unscales inside the clip coefficient, skips the
@@ -52,7 +55,8 @@ class FusedAdamWEMA:
 
     @property
     def grad_norm(self):
-        """0-d device tensor: the pre-clip global gradient norm of the last step (no host sync until .item())."""
+        """0-d device tensor: the pre-clip global gradient norm of the last step (no host sync until .item()); a view that the
+        step after next overwrites."""
         return self.norm_clip[0]
 
     @torch.no_grad()
@@ -70,6 +74,7 @@ class FusedAdamWEMA:
 
     def _step(self, m, A, L, prec):
         A.ensure_shadow(prec)
+        self.norm_clip = self._norm_clips[(self.step_count + 1) & 1]
         nc = None
         st = self.scaler_state
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0

@@ -74,7 +74,8 @@ def test_attention_bwd(dev, B, T, H, hd, form):
     ro, _ = _ref(q32, B, T, H, hd)
     ro.backward(do.float())
     ref = q32.grad
-    assert torch.isfinite(dqkv.float()).all()
+    nf = ~torch.isfinite(dqkv.float())
+    assert not nf.any(), (int(nf.sum()), nf.nonzero()[:6].tolist())
     for w, name in enumerate("qkv"):
         a, r = dqkv[:, :, w].float(), ref[:, :, w]
         err = (a - r).abs().max().item()

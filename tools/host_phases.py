@@ -36,7 +36,7 @@ marks = []
 
 
 def mark(name):
-    ev = torch.cuda.Event()
+    ev = torch.cuda.Event(enable_timing=True)
     ev.record()
     marks.append((name, time.perf_counter(), ev))
 
@@ -66,7 +66,11 @@ for _ in range(4):
     step(None, labels, zs, moments=moments)
 torch.cuda.synchronize()
 marks.clear()
+e0 = torch.cuda.Event(enable_timing=True)
+e0.record()
+torch.cuda.synchronize()
 t0 = time.perf_counter()
+t0_gpu = 0.0   # e0 completed (about) now: GPU time of a later event = e0.elapsed_time(ev), host time = perf_counter - t0
 rows = []
 for _ in range(K):
     step(None, labels, zs, moments=moments)
@@ -85,3 +89,12 @@ for n in names:
     v = per[n][1:]
     if v:
         print(f"  host ms up to '{n}': mean {sum(v) / len(v):7.3f}  min {min(v):7.3f}  max {max(v):7.3f}")
+# how far ahead of the GPU the host is at each mark: (GPU time at which the stream reaches the mark) - (host time of the mark);
+# near zero or negative = the GPU had nothing queued there (the host is the limit at that point of the step)
+lead = {n: [] for n in names}
+for n, th, ev in marks:
+    lead[n].append(e0.elapsed_time(ev) - (th - t0) * 1e3)
+for n in names:
+    v = lead[n][2:]
+    if v:
+        print(f"  host lead at '{n}' (ms): mean {sum(v) / len(v):7.3f}  min {min(v):7.3f}  max {max(v):7.3f}")
