@@ -243,6 +243,8 @@ def dp_consistency(reducer, opt, model, world, b):
     """Data-parallel consistency after the timed steps: identical optimiser steps on all-reduced (and factor-gathered)
     gradients must leave every rank with the same parameters bit for bit — two checksums per rank, compared on rank 0."""
     import torch.distributed as dist
+    if hasattr(opt, "sync_replicas"):
+        opt.sync_replicas()     # (sharded update, REED_OPT_SHARD=1: the owners' master weights to every rank first)
     if hasattr(opt, "flush"):
         opt.flush()
     A = model._arena
@@ -408,6 +410,7 @@ def main():
           "largest_bucket_bytes": int(4 * max(e - b0 for _, (b0, e) in bk)),
           # CUs the GEMM grids leave to RCCL's channels: measured by the first steps (reserve -> ms per step, MAX over ranks)
           "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning, "algo_in_use": getattr(reducer, "algo", None),
+          "tune_error": step.tune_error, "optimizer_sharded": bool(getattr(opt, "_shard", False)),
           "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}
     if reducer is not None:
         try:

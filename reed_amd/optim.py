@@ -26,6 +26,11 @@ class FusedAdamWEMA:
         self._stream = None
         self._chunks = None
         self._params = None
+        # REED_OPT_SHARD=1 (data-parallel runs, opt-in): every rank updates only its share of the parameter ranges and the
+        # 16-bit shadows travel by broadcast (see _shard_plan / sync_replicas); decided at the first step
+        self._want_shard = os.environ.get("REED_OPT_SHARD", "0") == "1"
+        self._shard = None       # [(chunk name, [(begin, end, owner rank), ...]), ...] once decided; False = replicated
+        self._rank = 0
         self.lr, self.betas, self.weight_decay, self.eps = lr, tuple(betas), weight_decay, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.step_count = 0
@@ -92,7 +97,7 @@ class FusedAdamWEMA:
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
         ema_buf = self.ema._arena.master if self.ema is not None else None
-        if not self.overlap:
+        if not self.overlap and not self._want_shard:
             ops.adamw_ema(A.master, A.grad, self.exp_avg, self.exp_avg_sq, ema_buf, A.shadow, L.n_train, L.n_total, nc,
                           self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay, scaler_state=st)
         else:
@@ -102,27 +107,113 @@ class FusedAdamWEMA:
                 self._stream = torch.cuda.Stream(device=A.master.device)
                 eng = m.engine()
                 self._chunks = L.update_chunks(list(eng.tap_depth) if m.z_dims else ())
+            if self._shard is None:
+                self._shard = self._shard_plan(L) if self._want_shard else False
             side = self._stream
             side.wait_stream(main)  # grads, clip coefficient
             pp, gp, sp = A.master.data_ptr(), A.grad.data_ptr(), A.shadow.data_ptr()
+            hb = A.shadow.element_size()
             mp, vp = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
             ep = ema_buf.data_ptr() if ema_buf is not None else None
             ev = None
+
+            def update(b, e):
+                nt = max(0, min(e, L.n_train) - b)
+                ops.adamw_ema(pp + 4 * b, gp + 4 * b if nt else None, mp + 4 * b if nt else None,
+                              vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + hb * b, nt,
+                              e - b, nc, self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay,
+                              scaler_state=st)
+
             with torch.cuda.stream(side):
-                for name, b, e in self._chunks:
-                    nt = max(0, min(e, L.n_train) - b)
-                    ops.adamw_ema(pp + 4 * b, gp + 4 * b if nt else None, mp + 4 * b if nt else None,
-                                  vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + A.shadow.element_size() * b, nt,
-                                  e - b, nc, self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay,
-                                  scaler_state=st)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    A.pending[name] = ev
+                if self._shard:
+                    import torch.distributed as dist
+                    sh32 = A.shadow.view(torch.int32)   # bit patterns (every backend carries int32; pieces are 4-element aligned)
+                    per = 4 // hb                        # shadow elements per int32
+                    for name, subs in self._shard:
+                        for b, e, owner in subs:
+                            if owner == self._rank:
+                                update(b, e)
+                            dist.broadcast(sh32[b // per:e // per], src=owner)   # the operand copy every rank's next forward reads
+                            for fb, fe in self._f32_read:    # ... and the few parameters the forward reads from the fp32 master
+                                lo, hi = max(b, fb), min(e, fe)
+                                if hi > lo:
+                                    dist.broadcast(A.master[lo:hi], src=owner)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        A.pending[name] = ev
+                else:
+                    for name, b, e in self._chunks:
+                        update(b, e)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        A.pending[name] = ev
             if self.ema is not None:
                 self.ema._arena.pending["all"] = ev
         A.mark_shadow_fresh()
         if self.ema is not None:
             self.ema._arena.shadow_version = -1  # EMA master changed behind torch's back: re-cast on next use
+
+    def _shard_plan(self, L, world=None, rank=None):
+        """Sharded update (REED_OPT_SHARD=1).  The fused pass moves 38 bytes per parameter whatever
+        the batch: at b = 32 per GPU it is 13 % of the step and every rank of a data-parallel run repeats it identically.
+        Here the update chunks (ArenaLayout.update_chunks: next-forward order) are cut into pieces of at most
+        n_total / (2 world) elements and dealt, in that order, to the least loaded rank; a rank runs the fused kernel on ITS
+        pieces only (master, Adam moments, EMA, 16-bit shadow) and the shadow of every piece is broadcast from its owner on the
+        optimiser's stream, piece by piece in the same order, the forward waiting per chunk as before — 2 bytes per parameter
+        on the wire instead of 38 through HBM on seven of eight ranks.  The gradients are still all-reduced (every rank holds
+        the averaged gradient and computes the same norm and clip coefficient), the arithmetic of a piece is the replicated
+        step's, so the shadows — what the forward computes with — are bit-identical to the replicated run's on every rank.
+        What a non-owner does NOT have is the fp32 master / moments / EMA of the pieces it does not own: sync_replicas()
+        (collective) brings them up to date before anything reads them (checkpoints, EMA sampling, state_dict)."""
+        if world is None:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+                return False
+            world, rank = dist.get_world_size(), dist.get_rank()
+        self._rank = rank
+        # parameters the forward reads in fp32 straight from the master arena (the label table, the q / k LayerNorm affines):
+        # their owners broadcast them with the shadows
+        self._f32_read = []
+        for name, (off, shp) in L.seg.items():
+            if name == "y_embedder.embedding_table.weight" or ".q_norm." in name or ".k_norm." in name:
+                n = 1
+                for d in shp:
+                    n *= d
+                self._f32_read.append((off, off + n))
+        limit = max(4, (L.n_total // (2 * world)) // 4 * 4)
+        load = [0] * world
+        plan = []
+        for name, b, e in self._chunks:
+            parts = max(1, -(-(e - b) // limit))
+            step = (-(-(e - b) // parts) + 3) // 4 * 4
+            subs, s0 = [], b
+            while s0 < e:
+                s1 = min(e, s0 + step)
+                owner = load.index(min(load))
+                load[owner] += s1 - s0
+                subs.append((s0, s1, owner))
+                s0 = s1
+            plan.append((name, subs))
+        return plan
+
+    def sync_replicas(self):
+        """Collective (every rank must call it).  After a sharded step only a piece's owner holds its fp32 master weights,
+        Adam moments and EMA: broadcast them from the owners so that every rank is a full replica again — before a checkpoint,
+        an EMA forward, state_dict() or any torch read of the parameters.  No-op for the replicated update."""
+        if not self._shard:
+            return
+        import torch.distributed as dist
+        self.flush()
+        A, L = self.model._arena, self.model._layout
+        bufs = [A.master, self.exp_avg, self.exp_avg_sq] + ([self.ema._arena.master] if self.ema is not None else [])
+        for _, subs in self._shard:
+            for b, e, owner in subs:
+                for t in bufs:
+                    hi = min(e, t.numel())
+                    if hi > b:
+                        dist.broadcast(t[b:hi], src=owner)
+        if self.ema is not None:
+            self.ema._arena.shadow_version = -1
 
     def flush(self):
         """Order the current stream after an overlapped update (before reading parameters / EMA with torch ops)."""

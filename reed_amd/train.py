@@ -341,10 +341,14 @@ def main(args):
             if "grad_norm" not in res:
                 continue  # accumulation micro-step
             global_step = step_fn.global_step
-            if previews is not None and (global_step == 1 or (global_step % args.sampling_steps == 0 and global_step > 0)):
+            want_preview = previews is not None and (global_step == 1 or (global_step % args.sampling_steps == 0 and global_step > 0))
+            want_ckpt = global_step % args.checkpointing_steps == 0 and global_step > 0
+            if want_preview or want_ckpt:
+                optimizer.sync_replicas()   # collective; a no-op unless the update is sharded (REED_OPT_SHARD=1): every rank a full replica
+            if want_preview:
                 previews(model, global_step)
                 logger.info("Generating EMA samples done.")
-            if global_step % args.checkpointing_steps == 0 and global_step > 0 and is_main:
+            if want_ckpt and is_main:
                 ckpt = {"model": model.state_dict(), "ema": ema.state_dict(), "opt": optimizer.state_dict(),
                         "args": args, "steps": global_step}
                 path = f"{checkpoint_dir}/{global_step:07d}.pt"

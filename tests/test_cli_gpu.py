@@ -390,6 +390,29 @@ torch.testing.assert_close(got_ema[:nt], ref_ema[:nt], rtol=1e-4, atol=3e-6)
 allg = [torch.empty(nt) for _ in range(world)]
 dist.all_gather(allg, got[:nt].cpu())
 assert all(torch.equal(allg[0], a) for a in allg), "parameters differ between the ranks after two steps"
+# the sharded update (REED_OPT_SHARD=1): every rank runs the fused pass on its share of the ranges only, the 16-bit shadows travel
+# by broadcast; after sync_replicas() master weights, EMA and Adam moments are bit-identical to the replicated run's, on both ranks
+os.environ["REED_OPT_SHARD"] = "1"
+m2, ema2, opt2 = make()
+red2 = GradReducer(m2, rank=rank, world=world)
+red2.broadcast_params(0)
+step2 = TrainStep(m2, lf, opt2, red2, proj_coeff=0.5, diffusion_warm_up_steps=0)
+for k in range(2):
+    x, y, zs, t, n = data(rank, k)
+    m2.force_drop_mask = torch.tensor([False, True, False, False])
+    step2(x, y, zs, time_input=t, noises=n)
+assert opt2._shard and {o for _, subs in opt2._shard for _, _, o in subs} == {0, 1}, "both ranks own pieces"
+torch.cuda.synchronize()
+assert torch.equal(m2._arena.shadow, m._arena.shadow), "the operand copies differ from the replicated run's"
+owned = torch.zeros(m2._layout.n_total, dtype=torch.bool)
+for _, subs in opt2._shard:
+    for b, e, o in subs:
+        if o == rank: owned[b:e] = True
+assert not torch.equal(m2._arena.master, got), "a non-owner's master weights are stale before sync_replicas()"
+assert torch.equal(m2._arena.master[owned.to(dev)], got[owned.to(dev)])
+opt2.sync_replicas(); torch.cuda.synchronize()
+assert torch.equal(m2._arena.master, got) and torch.equal(ema2._arena.master, got_ema)
+assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)
 '''
@@ -398,7 +421,9 @@ print("OK", rank)
 def test_two_ranks_train_steps_match_global_batch(dev, tmp_path):
     """Two optimiser steps of TrainStep with two real ranks (local batch 4 each, gloo through the torch binding, adaLN
     factor gather on) against the same two steps in one process on the global batch of 8: the reference's DDP contract
-    (train.py:263,293-295) — parameters and EMA equal to fp32 noise, bit-identical on both ranks."""
+    (train.py:263,293-295) — parameters and EMA equal to fp32 noise, bit-identical on both ranks.  Then the same two steps with
+    the sharded optimiser pass (REED_OPT_SHARD=1): operand copies bit-identical to the replicated run's after every step, a
+    non-owner's master stale until sync_replicas(), everything bit-identical after it."""
     script = tmp_path / "w2t.py"
     script.write_text(_TWO_RANK_TRAIN_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29747", WORLD_SIZE="2", REED_COMM="torch",

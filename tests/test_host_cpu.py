@@ -547,3 +547,29 @@ def test_mocov3_checkpoint_key_repair(tmp_path, monkeypatch):
     assert set(got) == set(want)
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_sharded_optimizer_plan_covers_arena_and_balances():
+    """REED_OPT_SHARD=1 (reed_amd/optim.py:_shard_plan): the update chunks cut into pieces and dealt to the ranks — every
+    element of the arena in exactly one piece, in next-forward order, 4-element aligned, every rank's share within one piece of
+    the mean, the same plan on every rank."""
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.optim import FusedAdamWEMA
+    m = SiT_models["SiT-B/2"](z_dims=[768], z_types=["i"], encoder_depth=4)
+    L = m._layout
+    opt = FusedAdamWEMA.__new__(FusedAdamWEMA)
+    opt._chunks = L.update_chunks([4])
+    for world in (2, 4, 8):
+        plans = [opt._shard_plan(L, world=world, rank=r) for r in range(world)]
+        assert all(p == plans[0] for p in plans)
+        pieces = [(b, e, o) for _, subs in plans[0] for b, e, o in subs]
+        covered = np.zeros(L.n_total, dtype=np.int32)
+        load = [0] * world
+        for b, e, o in pieces:
+            assert b % 4 == 0 and e % 4 == 0 and e > b and 0 <= o < world
+            covered[b:e] += 1
+            load[o] += e - b
+        assert (covered == 1).all()
+        assert [n for n, _ in plans[0]] == [n for n, _, _ in opt._chunks]
+        limit = max(4, (L.n_total // (2 * world)) // 4 * 4)
+        assert max(load) - min(load) <= limit + 4, (world, load)
