@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -567,3 +568,24 @@ def test_bench_stdout_is_one_line_under_a_reducer(dev):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["data_parallel"]["world"] == 1 and d["data_parallel"]["cu_reserve_tuning_ms"] is not None
+
+
+def test_bench_self_launch(dev):
+    """The driver's command form: `python bench.py --gpus N ...` with NO rank environment.  N = 1 runs in-process and prints one
+    JSON line with the C3 per-GPU leg; N = 2 on this one-GPU box must exit non-zero with a one-line message, promptly (no hang,
+    no rank started)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "only 1 GPU" in r.stderr and time.time() - t0 < 60
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1", "--model", "SiT-XL/2", "--global-batch", "64",
+                        "--no-cpu-baseline", "--no-kernel-table"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["local_batch"] == 64
+    leg = d["c3_per_gpu_leg"]
+    assert leg["local_batch"] == 32 and leg["images_per_sec_per_gpu"] > 0 and np.isfinite(leg["final_loss"])

@@ -573,3 +573,23 @@ def test_sharded_optimizer_plan_covers_arena_and_balances():
         assert [n for n, _ in plans[0]] == [n for n, _, _ in opt._chunks]
         limit = max(4, (L.n_total // (2 * world)) // 4 * 4)
         assert max(load) - min(load) <= limit + 4, (world, load)
+
+
+def test_bench_launcher_argv(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own ranks: the child
+    command is torch.distributed.run with one rank per GPU, rendezvous on 127.0.0.1, this script and its arguments unchanged; with
+    fewer devices than ranks the launcher returns 2 without starting anything (and without touching the GPU)."""
+    import bench
+    argv = ["--gpus", "8", "--steps", "7", "--warmup", "2"]
+    args = bench.parse(argv)
+    cmd = bench.launcher_argv(args, argv, 29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    k = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[k + 1:] == argv
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    started = []
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("started")))
+    assert bench.self_launch(args, argv) == 2 and not started
