@@ -267,3 +267,40 @@ def test_fp32_switch_leaves_other_builds_alone(dev):
     b.precision = "bf16"
     with pytest.raises(RuntimeError, match="precision changed"):
         (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
+
+
+def test_c2_xl2_fp32_trajectory_and_gradient_probes(dev):
+    """C2's model at the reference's fp32 arithmetic (`--mixed-precision no`): SiT-XL/2 + 1024-d alignment, B = 8, 5 optimiser steps on
+    injected draws against the reference's own fp32 run (`xl2_c2.npz`, keys fp32.*): per-step total loss within 2e-5, gradient norm
+    within 1e-4, and at step 1 the norm of 22 probed gradient tensors within 1e-5 with their 64-element slices at cosine 1 - 1e-7."""
+    g = load("xl2_c2")
+    m, ema, opt, lf = _hip_trainer("SiT-XL/2", dict(z_dims=[1024], z_types=["i"], encoder_depth=8), dev, ["dinov2"], [1.0])
+    m.precision = "fp32"
+    ema.precision = "fp32"
+    probes = {}
+
+    def grab(step):
+        if step == 0:
+            torch.cuda.synchronize()
+            named = dict(m.named_parameters())
+            for k in [k[len("fp32.gnorm."):] for k in g.files if k.startswith("fp32.gnorm.")]:
+                f = named[k].grad.detach().flatten()
+                probes[k] = (f.double().norm().item(), f[:: max(1, f.numel() // 64)][:64].float().cpu().numpy())
+
+    rec = _run_traj(m, opt, lf, dev, 8, 5, [(1024, "i")], True, after_backward=grab)
+    print("HIP fp32 loss:", [f"{v:.6f}" for v in rec["loss"]])
+    print("REF fp32 loss:", [f"{v:.6f}" for v in g["fp32.loss"]])
+    np.testing.assert_allclose(rec["loss"], g["fp32.loss"], atol=2e-5)
+    np.testing.assert_allclose(rec["proj_loss"], g["fp32.proj_loss"], atol=2e-5)
+    np.testing.assert_allclose(rec["grad_norm"], g["fp32.grad_norm"], rtol=1e-4)
+    assert len(probes) >= 20
+    worst_n, worst_c = 0.0, 1.0
+    for k, (nh, sl) in probes.items():
+        nf, rf = float(g["fp32.gnorm." + k]), g["fp32.gslice." + k]
+        worst_n = max(worst_n, abs(nh / nf - 1))
+        assert abs(nh / nf - 1) <= 1e-5, (k, nh, nf)
+        if np.any(rf):
+            c = cos(torch.from_numpy(sl), torch.from_numpy(rf))
+            worst_c = min(worst_c, c)
+            assert c >= 1 - 1e-7, (k, c)
+    print(f"XL/2 fp32 gradient probes: worst |norm ratio - 1| {worst_n:.2e}, worst slice cosine {worst_c:.9f}")
