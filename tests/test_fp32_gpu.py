@@ -269,38 +269,47 @@ def test_fp32_switch_leaves_other_builds_alone(dev):
         (out["denoising_loss"].mean() + 0.5 * out["proj_loss"]).backward()
 
 
-def test_c2_xl2_fp32_trajectory_and_gradient_probes(dev):
+def test_c2_xl2_fp32_trajectory_and_every_gradient(dev):
     """C2's model at the reference's fp32 arithmetic (`--mixed-precision no`): SiT-XL/2 + 1024-d alignment, B = 8, 5 optimiser steps on
-    injected draws against the reference's own fp32 run (`xl2_c2.npz`, keys fp32.*): per-step total loss within 2e-5, gradient norm
-    within 1e-4, and at step 1 the norm of 22 probed gradient tensors within 1e-5 with their 64-element slices at cosine 1 - 1e-7."""
-    g = load("xl2_c2")
+    injected draws against the reference's own fp32 run (`xl2_c2.npz` keys fp32.*, `xl2_c2_gnorms.npz`).  Step 1 (same weights in both
+    runs): total loss within 2e-6, the norm of EVERY parameter's gradient (297 tensors) within 1e-5, the 64-element slices of the 22
+    probed ones at cosine 1 - 1e-7.  Steps 2-5: loss within 1e-4 relative."""
+    g, ga = load("xl2_c2"), load("xl2_c2_gnorms")
     m, ema, opt, lf = _hip_trainer("SiT-XL/2", dict(z_dims=[1024], z_types=["i"], encoder_depth=8), dev, ["dinov2"], [1.0])
     m.precision = "fp32"
     ema.precision = "fp32"
-    probes = {}
+    norms, slices = {}, {}
 
     def grab(step):
         if step == 0:
             torch.cuda.synchronize()
-            named = dict(m.named_parameters())
-            for k in [k[len("fp32.gnorm."):] for k in g.files if k.startswith("fp32.gnorm.")]:
-                f = named[k].grad.detach().flatten()
-                probes[k] = (f.double().norm().item(), f[:: max(1, f.numel() // 64)][:64].float().cpu().numpy())
+            for k, p in m.named_parameters():
+                if p.grad is None:
+                    continue
+                f = p.grad.detach().flatten()
+                norms[k] = f.double().norm().item()
+                if "fp32.gslice." + k in g.files:
+                    slices[k] = f[:: max(1, f.numel() // 64)][:64].float().cpu().numpy()
 
     rec = _run_traj(m, opt, lf, dev, 8, 5, [(1024, "i")], True, after_backward=grab)
     print("HIP fp32 loss:", [f"{v:.6f}" for v in rec["loss"]])
     print("REF fp32 loss:", [f"{v:.6f}" for v in g["fp32.loss"]])
-    np.testing.assert_allclose(rec["loss"], g["fp32.loss"], atol=2e-5)
-    np.testing.assert_allclose(rec["proj_loss"], g["fp32.proj_loss"], atol=2e-5)
-    np.testing.assert_allclose(rec["grad_norm"], g["fp32.grad_norm"], rtol=1e-4)
-    assert len(probes) >= 20
-    worst_n, worst_c = 0.0, 1.0
-    for k, (nh, sl) in probes.items():
-        nf, rf = float(g["fp32.gnorm." + k]), g["fp32.gslice." + k]
-        worst_n = max(worst_n, abs(nh / nf - 1))
-        assert abs(nh / nf - 1) <= 1e-5, (k, nh, nf)
-        if np.any(rf):
-            c = cos(torch.from_numpy(sl), torch.from_numpy(rf))
-            worst_c = min(worst_c, c)
-            assert c >= 1 - 1e-7, (k, c)
-    print(f"XL/2 fp32 gradient probes: worst |norm ratio - 1| {worst_n:.2e}, worst slice cosine {worst_c:.9f}")
+    np.testing.assert_allclose(rec["loss"][0], g["fp32.loss"][0], atol=2e-6)
+    np.testing.assert_allclose(rec["proj_loss"][0], g["fp32.proj_loss"][0], atol=2e-6)
+    ref_names = [k[len("gnorm."):] for k in ga.files if k.startswith("gnorm.")]
+    assert sorted(ref_names) == sorted(norms) and len(norms) == 297
+    worst_n = max(abs(norms[k] / float(ga["gnorm." + k]) - 1) for k in ref_names)
+    worst_c = min(cos(torch.from_numpy(sl), torch.from_numpy(g["fp32.gslice." + k])) for k, sl in slices.items() if np.any(g["fp32.gslice." + k]))
+    print(f"XL/2 fp32, step 1: worst |gradient norm ratio - 1| over {len(norms)} tensors {worst_n:.2e}, worst slice cosine {worst_c:.9f}")
+    assert worst_n <= 1e-5 and worst_c >= 1 - 1e-7 and len(slices) >= 20
+    # the clip norm: ours equals the root of the reference's own per-tensor squares (fp64) to 1e-6; the value the reference's
+    # clip_grad_norm_ REPORTS is 2e-4 below that (its fp32 reduction over 675 M elements), so that one is pinned at 3e-4 only
+    exact = sum(float(ga["gnorm." + k]) ** 2 for k in ref_names) ** 0.5
+    print(f"clip norm: HIP {rec['grad_norm'][0]:.6f}, reference gradients in fp64 {exact:.6f}, reference clip_grad_norm_ {g['fp32.grad_norm'][0]:.6f}")
+    np.testing.assert_allclose(rec["grad_norm"][0], exact, rtol=1e-6)
+    np.testing.assert_allclose(rec["grad_norm"][0], g["fp32.grad_norm"][0], rtol=3e-4)
+    # from step 2 on the two runs' weights differ: Adam's first update is lr * g / |g| element-wise, so a gradient element whose
+    # sign is decided by rounding moves its weight by +lr in one run and -lr in the other; the loss follows to ~5e-5 relative
+    np.testing.assert_allclose(rec["loss"], g["fp32.loss"], rtol=1e-4)
+    np.testing.assert_allclose(rec["proj_loss"], g["fp32.proj_loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(rec["grad_norm"], g["fp32.grad_norm"], rtol=2e-3)

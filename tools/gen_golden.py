@@ -453,6 +453,17 @@ def g_xl(ref_sit, ref_loss, ref_samplers):
     save("xl2_c2", **out)
 
 
+def g_xl_gnorms(ref_sit, ref_loss, ref_samplers):
+    """C2, fp32, step 1 only: the norm of EVERY parameter's gradient (the 22 probes of xl2_c2 leave the biases, the other blocks'
+    adaLN and t_embedder.mlp.2 unpinned) and the clip norm."""
+    kw = dict(input_size=32, num_classes=1000, z_dims=[1024], z_types=["i"], encoder_depth=8, fused_attn=True, qk_norm=False)
+    names = [k for k, p in build_ref_model(ref_sit, "SiT-XL/2", seed=0, **kw).named_parameters() if p.requires_grad]
+    gp = {}
+    rec, _, _ = ref_train_traj(ref_sit, ref_loss, "SiT-XL/2", kw, 8, 1, [(1024, "i")], ["dinov2"], [1.0], False, grad_probes=(names, gp))
+    save("xl2_c2_gnorms", grad_norm=np.array(rec["grad_norm"]), loss=np.array(rec["loss"]),
+         **{k: v for k, v in gp.items() if k.startswith("gnorm.")})
+
+
 def g_xl_infer(ref_sit, ref_loss, ref_samplers):
     """C5 at its real size: one CFG-doubled evaluation of SiT-XL/2 in eval mode as samplers.py:66-78 issues it
     ([x; x], labels [y; 1000]), n = 2, fp32 and bf16-autocast; plus 3 Heun steps with CFG 1.5 on the fp32 model
@@ -787,7 +798,7 @@ def g_init(ref_sit, ref_loss, ref_samplers):
 
 
 ALL = {"init": g_init, "static": g_static, "tiny": g_tiny, "loss_units": g_loss_units, "samplers": g_samplers, "optim_toy": g_sched,
-       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "samplers_long_xl": g_samplers_long_xl, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers, "dinov2": g_dinov2}
+       "s2_c1": g_s2, "b2_align": g_b2, "xl2_c2": g_xl, "xl2_c2_gnorms": g_xl_gnorms, "xl2_c4": g_xl_c4, "xl2_infer": g_xl_infer, "samplers_long": g_samplers_long, "samplers_long_xl": g_samplers_long_xl, "fp16": g_fp16, "clip": g_clip, "dataset": g_dataset, "towers": g_towers, "dinov2": g_dinov2}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
