@@ -298,6 +298,35 @@ int reed_vit_tokens(const void* patches, const float* cls, int nprefix, const fl
 int reed_preprocess_image(const uint8_t* raw, float* out, int B, int R, int S, const float* mean3, const float* std3,
                           int order, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SD-VAE decoder: `vae.decode(latents / 0.18215).sample` of image/generate.py:87,156 and
+ * image/train.py:446-447 (diffusers' AutoencoderKL, not vendored in the reference: reed_amd/vae.py restates its decoder).
+ * Activations are fp32 NHWC = the token matrix [B*H*W, C]; every convolution / Linear is a reed_gemm call on it (NT, epilogue 6:
+ * fp32 + bias, accumulate = the residual connection); these are the passes around the contractions (csrc/vae.hip).
+ * ------------------------------------------------------------------------------------------- */
+/* doubles of workspace reed_groupnorm_stats needs for x f32 [B, hw, C] */
+int64_t reed_groupnorm_ws_doubles(int B, int64_t hw, int C);
+/* stats f32 [B, G, 2] = (mean, 1 / sqrt(biased var + eps)) of x f32 [B, hw, C] per (image, group of C / G channels);
+ * fp64 sums in a fixed order.  C % 4 == 0, C <= 1024. */
+int reed_groupnorm_stats(const float* x, int B, int64_t hw, int C, int G, float eps, double* ws, float* stats, void* stream);
+/* The row operand of a convolution as a GEMM: out (operand type) [nrows, ldo], row r - row0 = output position r = (b, y, x) of
+ * the [B, Hi << upsample, Wi << upsample] grid, columns tap * C + c = a(b, y + tap / 3 - 1, x + tap % 3 - 1, c) for taps = 9
+ * (zero outside the grid: padding 1) or a(b, y, x, c) for taps = 1, columns [taps * C, kcols) zero; a = x f32 [B, Hi, Wi, C]
+ * read through nearest x2 upsampling when `upsample`, GroupNorm-ed with `stats` f32 [B, G, 2] and gamma / beta f32 [C] when
+ * stats != NULL, SiLU-ed when `silu`.  C, kcols, ldo multiples of 4. */
+int reed_conv_rows(const float* x, const float* stats, const float* gamma, const float* beta, int B, int Hi, int Wi, int C,
+                   int G, int silu, int upsample, int taps, int64_t row0, int64_t nrows, int kcols, void* out, int64_t ldo,
+                   void* stream);
+/* 3x3 convolution, padding 1, as an implicit GEMM on the 16-bit matrix cores (csrc/conv.hip; the fp32-operand build returns 1002:
+ * use reed_conv_rows with taps = 9 + reed_gemm there): out f32 [B*Ho*Wo, ldc] (+)= conv(a) + bias, a (operand type) NHWC
+ * [B, Hi, Wi, C] read through nearest x2 upsampling when `upsample` (Ho = Hi << upsample), w (operand type) [N, 9 C] in
+ * (ky, kx, ci) order, bias f32 [N] or NULL; accumulate != 0 adds onto what `out` holds (the residual connection, in place).
+ * C % 64 == 0, N % 128 == 0, B*Hi*Wi*C*2 bytes < 2 GiB. */
+int reed_conv3x3(const void* a, const void* w, const float* bias, float* out, int64_t ldc, int B, int Hi, int Wi, int C, int N,
+                 int upsample, int accumulate, void* stream);
+/* p (operand type) [rows, ldp] = softmax over the first `cols` columns of scale * s f32 [rows, lds] */
+int reed_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int rows, int cols, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

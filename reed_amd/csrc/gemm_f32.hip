@@ -228,6 +228,12 @@ int reed_gemm_tn_group_launch(int, const GemmArgs*, hipStream_t) {
   return REED_ERR_UNSUPPORTED;
 }
 
+// The implicit-GEMM convolution is a 16-bit MFMA kernel (conv.hip); fp32 operands take reed_conv_rows (taps = 9) + reed_gemm.
+extern "C" int reed_conv3x3(const void*, const void*, const float*, float*, int64_t, int, int, int, int, int, int, int, void*) {
+  reed_set_error("reed_conv3x3: not built for fp32 operands (reed_conv_rows with taps = 9 + reed_gemm instead)");
+  return REED_ERR_UNSUPPORTED;
+}
+
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
   REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   REED_CHECK_ARG(a.ldp % 4 == 0 && a.ldq % 4 == 0 && a.N % 4 == 0, "reed_gemm(fp32): leading dims and N must be multiples of 4 elements");

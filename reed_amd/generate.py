@@ -109,6 +109,24 @@ def sample_precision(args):
     return "fp16" if args.tf32 else "fp32"
 
 
+def decode_latents(vae, z, args):
+    """`vae.decode(z).sample` (generate.py:156).  The in-repo decoder runs on the HIP kernels with the operand type the
+    reference's flags mean here: fp16 operands + fp32 accumulation and activations under --tf32 (TF32's mantissa; the reference's
+    convolutions are TF32 there), exact fp32 under --no-tf32.  A non-finite fp16 result (half saturates at 65504, TF32 does
+    not) is decoded again with fp32 operands."""
+    from .vae import SDVAEDecoder
+    if not isinstance(vae, SDVAEDecoder):
+        img = vae.decode(z)
+        return getattr(img, "sample", img)        # diffusers returns a DecoderOutput
+    prec = "fp32" if sample_precision(args) == "fp32" else "fp16"
+    img = vae.decode(z, precision=prec)
+    if prec != "fp32" and not bool(torch.isfinite(img).all()):
+        import warnings
+        warnings.warn("reed_amd.generate: non-finite images from the fp16-operand VAE decoder; decoding this batch with fp32 operands")
+        img = vae.decode(z, precision="fp32")
+    return img
+
+
 def finite_or_retry(sampler, kw, model):
     """Run one batch.  IEEE half saturates at 65504 where bf16 and the reference's TF32 do not: a checkpoint with large
     activation outliers would give inf / nan latents silently.  One isfinite reduction per batch (one host
@@ -221,8 +239,7 @@ def main(args):
             raise NotImplementedError()
         if vae is not None:
             from PIL import Image
-            img = vae.decode(samples / 0.18215)
-            img = getattr(img, "sample", img)     # diffusers returns a DecoderOutput, reed_amd.vae the tensor
+            img = decode_latents(vae, samples / 0.18215, args)
             img = torch.clamp(255. * ((img + 1) / 2.), 0, 255).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8).numpy()
             for i, s in enumerate(img):
                 Image.fromarray(s).save(f"{sample_folder_dir}/{sample_index(i, world, rank, total):06d}.png")

@@ -495,3 +495,30 @@ def sampler_update(x_cur, model_out, d_prev, d_store, x_next, n, cfg, cfg_scale,
 def sde_update(x_cur, model_out, eps, x_next, n, cfg, cfg_scale, t_cur, dt, path_type, last):
     _call("reed_sde_update", _p(x_cur), _p(model_out), _p(eps), _p(x_next), n, int(cfg), float(cfg_scale),
           float(t_cur), float(dt), path_type, int(last), _stream())
+
+
+# ---------------- SD-VAE decoder passes (csrc/vae.hip) ----------------
+def groupnorm_stats(x, B, hw, C, G, eps, stats, ws=None):
+    """stats f32 [B, G, 2] = (mean, rstd) of x f32 [B, hw, C] per (image, group)."""
+    L = _lib.load(_PRECISION)
+    need = int(L.reed_groupnorm_ws_doubles(B, hw, C))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float64, device=x.device)
+    _call("reed_groupnorm_stats", _p(x), B, hw, C, G, float(eps), _p(ws), _p(stats), _stream())
+    return ws
+
+
+def conv_rows(x, out, B, Hi, Wi, C, taps, row0, nrows, kcols, ldo, stats=None, gamma=None, beta=None, G=0, silu=False,
+              upsample=False):
+    """out (operand type) [nrows, ldo] = the rows [row0, row0 + nrows) of the convolution's GEMM operand (reed_conv_rows)."""
+    _call("reed_conv_rows", _p(x), _p(stats), _p(gamma), _p(beta), B, Hi, Wi, C, G, int(silu), int(upsample), taps, row0, nrows,
+          kcols, _p(out), ldo, _stream())
+
+
+def softmax_rows(s, lds, p, ldp, rows, cols, scale):
+    _call("reed_softmax_rows", _p(s), lds, _p(p), ldp, rows, cols, float(scale), _stream())
+
+
+def conv3x3(a, w, bias, out, ldc, B, Hi, Wi, C, N, upsample=False, accumulate=False):
+    """out f32 [B*Ho*Wo, ldc] (+)= conv3x3(a operand-type NHWC [B, Hi, Wi, C]; w [N, 9C]) + bias f32 (reed_conv3x3, 16-bit builds)."""
+    _call("reed_conv3x3", _p(a), _p(w), _p(bias), _p(out), ldc, B, Hi, Wi, C, N, int(upsample), int(accumulate), _stream())

@@ -9,14 +9,22 @@ nearest x2 upsampling + 3x3 conv after the first three), GroupNorm(32, eps 1e-6)
 names of the published checkpoints, so that `diffusion_pytorch_model.safetensors` / `.bin` of sd-vae-ft-ema / -mse loads
 directly (`--vae-ckpt` of generate.py). Parity: UNPINNED — there is no diffusers and no checkpoint in this container to compare
 against; `oracle/vae.py` restates the same published algorithm a second, independent way and the tests hold the two together
-on random weights (tests/test_host_cpu.py). SURVEY.md §8f N4: one decode per 499-998 SiT evaluations, < 1 % of the sampling
-wall clock, so it runs on torch's own convolution kernels (MIOpen) — plumbing, not a hot path.
+on random weights (tests/test_host_cpu.py, tests/test_vae_gpu.py).
+
+Two forms of the same network over one set of parameters.  `decode(z)` is the product: z on the GPU -> HIP kernels only
+(`_HipDecode`: fp32 NHWC activations = token matrices, every convolution / Linear a `reed_gemm` call, GroupNorm statistics,
+GroupNorm-apply + SiLU + padding + nearest-x2 + im2col in one pass, softmax rows: csrc/vae.hip; no torch / MIOpen operator, and it
+raises without the library).  `decode_torch(z)` is the module tree's plain torch forward, kept for the CPU-side cross-check of
+the two restatements and as the GPU tests' second witness; nothing in the product calls it.
 """
 import os
+import types
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ops
 
 SD_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
                      norm_num_groups=32, scaling_factor=0.18215)
@@ -119,10 +127,188 @@ class SDVAEDecoder(nn.Module):
         self.decoder = _Decoder(latent_channels, out_channels, tuple(block_out_channels), layers_per_block, norm_num_groups)
 
     @torch.no_grad()
-    def decode(self, z):
+    def decode_torch(self, z):
+        """The module tree evaluated with torch operators (tests only: the CPU cross-check against oracle/vae.py)."""
         return self.decoder(self.post_quant_conv(z))
 
+    @torch.no_grad()
+    def decode(self, z, precision="fp32"):
+        """z [B, 4, h, w] on the GPU -> images f32 [B, 3, 8h, 8w], on the HIP kernels.  precision = the GEMM operand type:
+        "fp32" (default: exact fp32 products, the reference's `--no-tf32` arithmetic and a superset of its TF32 default),
+        "fp16" / "bf16" (the 16-bit MFMA kernels; channel counts must then be multiples of 128, as the published config's are)."""
+        ops.require_cuda(z, "latents")
+        if getattr(self, "_hip", None) is None:
+            self._hip = _HipDecode(self)
+        return self._hip.decode(z, precision)
+
     forward = decode
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class _HipDecode:
+    """`SDVAEDecoder.decode` on the library.  Activations: fp32 NHWC, i.e. the row-major matrix [B*H*W, C].  A convolution is
+    reed_conv_rows (its row operand: GroupNorm apply + SiLU + zero padding + nearest x2 + the 9 taps, one pass) followed by
+    reed_gemm NT with epilogue 6 (fp32 + bias; `accumulate` adds onto the residual in place); the rows are produced in chunks of
+    at most `WS_BYTES` so the operand never exceeds that, whatever the batch.  Weights are repacked once per precision to
+    [Cout, 9*Cin] in (ky, kx, ci) order, K / N zero-padded to the kernels' granules (K 64, N 128 for the 16-bit builds; 4 / 4
+    for fp32)."""
+    WS_BYTES = 1 << 30
+
+    def __init__(self, vae):
+        self.vae = vae
+        self.packs = {}
+        self.bias32 = {}
+        self.ws = None
+        self.gn_ws = None
+
+    # ---- weights ----
+    def _pack(self, name, mod, prec):
+        key = (name, prec)
+        w, b = mod.weight, mod.bias
+        ver = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        hit = self.packs.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        hd = ops.half_dtype(prec)
+        km, nm = (4, 4) if prec == "fp32" else (64, 128)
+        w2 = w.detach().float()
+        w2 = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1) if w2.ndim == 4 else w2
+        co, k = w2.shape
+        wm = torch.zeros(_round_up(co, nm), _round_up(k, km), dtype=hd, device=w.device)
+        wm[:co, :k] = w2.to(hd)
+        bm = torch.zeros(wm.shape[0], dtype=hd, device=w.device)
+        bm[:co] = b.detach().float().to(hd)
+        self.bias32[key] = torch.zeros(wm.shape[0], dtype=torch.float32, device=w.device)
+        self.bias32[key][:co] = b.detach().float()
+        pack = (wm, bm, co, k)
+        self.packs[key] = (ver, pack)
+        return pack
+
+    def _workspace(self, nbytes, dev):
+        if self.ws is None or self.ws.numel() < nbytes or self.ws.device != dev:
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self.ws
+
+    # ---- passes ----
+    def _stats(self, x, norm):
+        B, H, W, C = x.shape
+        st = torch.empty(B, norm.num_groups, 2, dtype=torch.float32, device=x.device)
+        self.gn_ws = ops.groupnorm_stats(x, B, H * W, C, norm.num_groups, norm.eps, st, self.gn_ws)
+        return st
+
+    def _conv(self, x, name, mod, prec, taps, norm=None, silu=False, up=False, out=None, accumulate=False):
+        """x f32 [B, Hi, Wi, C] -> f32 [B, Ho, Wo, Cout_padded] (+= when accumulate) = conv(act(norm(upsample(x))))"""
+        B, Hi, Wi, C = x.shape
+        wm, bm, co, k = self._pack(name, mod, prec)
+        assert k == taps * C, (name, k, taps, C)
+        npad, kcols = wm.shape
+        Ho, Wo = (Hi * 2, Wi * 2) if up else (Hi, Wi)
+        M = B * Ho * Wo
+        if out is None:
+            out = torch.empty(B, Ho, Wo, npad, dtype=torch.float32, device=x.device)
+        assert out.shape == (B, Ho, Wo, npad) and out.is_contiguous()
+        st = self._stats(x, norm) if norm is not None else None
+        gamma = norm.weight.detach().float().contiguous() if norm is not None else None
+        beta = norm.bias.detach().float().contiguous() if norm is not None else None
+        G = norm.num_groups if norm is not None else 0
+        es = ops.half_dtype(prec).itemsize
+        if prec != "fp32" and taps == 9 and C % 64 == 0:
+            # 16-bit builds: the activation once in the operand type (norm + SiLU + rounding, 6 B / element), then the implicit GEMM
+            per = Hi * Wi * C * es
+            bc = max(1, min(B, 0x7FFF0000 // per))
+            act = self._workspace(bc * per, x.device)
+            for b0 in range(0, B, bc):
+                nb = min(bc, B - b0)
+                ops.conv_rows(x, act, B, Hi, Wi, C, 1, b0 * Hi * Wi, nb * Hi * Wi, C, C, stats=st, gamma=gamma, beta=beta, G=G, silu=silu)
+                ops.conv3x3(act, wm, self.bias32[(name, prec)], out.data_ptr() + b0 * Ho * Wo * npad * 4, npad, nb, Hi, Wi, C, npad,
+                            upsample=up, accumulate=accumulate)
+            return out
+        direct = prec == "fp32" and taps == 1 and norm is None and not silu and not up and kcols == C
+        chunk = M if direct else min(M, max(1024, (self.WS_BYTES // (kcols * es)) // 1024 * 1024))
+        cols = None if direct else self._workspace(chunk * kcols * es, x.device)
+        for r0 in range(0, M, chunk):
+            n = min(chunk, M - r0)
+            if direct:
+                P = x.data_ptr() + r0 * C * 4
+            else:
+                ops.conv_rows(x, cols, B, Hi, Wi, C, taps, r0, n, kcols, kcols, stats=st, gamma=gamma, beta=beta, G=G, silu=silu,
+                              upsample=up)
+                P = cols
+            ops.gemm(ops.NT, ops.EPI_F32, P, wm, n, npad, kcols, out.data_ptr() + r0 * npad * 4, kcols, kcols, npad, bias=bm,
+                     accumulate=accumulate)
+        return out
+
+    def _resnet(self, x, name, r, prec):
+        h = self._conv(x, name + ".conv1", r.conv1, prec, 9, norm=r.norm1, silu=True)
+        if r.conv_shortcut is not None:
+            x = self._conv(x, name + ".conv_shortcut", r.conv_shortcut, prec, 1)
+        return self._conv(h, name + ".conv2", r.conv2, prec, 9, norm=r.norm2, silu=True, out=x, accumulate=True)   # x += ...
+
+    def _attention(self, x, name, a, prec):
+        B, H, W, C = x.shape
+        T, hd = H * W, ops.half_dtype(prec)
+        src = tuple((p.data_ptr(), p._version) for p in (a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_q.bias, a.to_k.bias, a.to_v.bias))
+        if getattr(a, "_qkv_src", None) != src:      # q, k, v as one [3C, C] contraction
+            a._qkv = types.SimpleNamespace(weight=torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]).detach(),
+                                           bias=torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias]).detach())
+            a._qkv_src = src
+        wm, bm, co, k = self._pack(name + ".qkv", a._qkv, prec)
+        kcols = wm.shape[1]
+        assert wm.shape[0] == 3 * C, "attention width must be a multiple of the GEMM's column granule"
+        st = self._stats(x, a.group_norm)
+        t = torch.empty(B * T, kcols, dtype=hd, device=x.device)
+        ops.conv_rows(x, t, B, H, W, C, 1, 0, B * T, kcols, kcols, stats=st, gamma=a.group_norm.weight.detach().float().contiguous(),
+                      beta=a.group_norm.bias.detach().float().contiguous(), G=a.group_norm.num_groups)
+        Tp = _round_up(T, 4 if prec == "fp32" else 128)      # rows of an image's q / k / v block: the score GEMM's N and the
+        qkv = (torch.zeros if Tp != T else torch.empty)(B * Tp, 3 * C, dtype=hd, device=x.device)   # P V GEMM's K granule
+        es = hd.itemsize
+        if Tp == T:
+            ops.gemm(ops.NT, ops.EPI_BF16, t, wm, B * T, 3 * C, kcols, qkv, kcols, kcols, 3 * C, bias=bm)
+        else:
+            for b in range(B):
+                ops.gemm(ops.NT, ops.EPI_BF16, t.data_ptr() + b * T * kcols * es, wm, T, 3 * C, kcols,
+                         qkv.data_ptr() + b * Tp * 3 * C * es, kcols, kcols, 3 * C, bias=bm)
+        s = torch.empty(T, Tp, dtype=torch.float32, device=x.device)
+        pm = torch.zeros(T, Tp, dtype=hd, device=x.device)          # pad columns stay zero
+        o = torch.empty(B * T, C, dtype=hd, device=x.device)
+        for b in range(B):
+            q = qkv.data_ptr() + b * Tp * 3 * C * es
+            ops.gemm(ops.NT, ops.EPI_F32, q, q + C * es, T, Tp, C, s, 3 * C, 3 * C, Tp)                     # S = Q K^T
+            ops.softmax_rows(s, Tp, pm, Tp, T, T, C ** -0.5)
+            ops.gemm(ops.NN, ops.EPI_BF16, pm, q + 2 * C * es, T, C, Tp, o.data_ptr() + b * T * C * es, Tp, 3 * C, C)   # O = P V
+        wo, bo, _, ko = self._pack(name + ".to_out.0", a.to_out[0], prec)
+        assert wo.shape == (C, C)
+        ops.gemm(ops.NT, ops.EPI_F32, o, wo, B * T, C, C, x, C, C, C, bias=bo, accumulate=True)           # x += out(O)
+        return x
+
+    def decode(self, z, precision="fp32"):
+        v, d = self.vae, self.vae.decoder
+        prev = ops.use(precision)
+        try:
+            x = z.detach().float().permute(0, 2, 3, 1).contiguous()                       # NHWC
+            if x.shape[-1] % 4:
+                raise ValueError("latent channels must be a multiple of 4")
+            lc = x.shape[-1]
+            x = self._conv(x, "post_quant_conv", v.post_quant_conv, precision, 1)[..., :lc].contiguous()
+            x = self._conv(x, "decoder.conv_in", d.conv_in, precision, 9)
+            if x.shape[-1] != d.conv_in.out_channels:
+                raise ValueError(f"precision {precision!r} needs channel counts that are multiples of 128")
+            m = d.mid_block
+            x = self._resnet(x, "decoder.mid_block.resnets.0", m.resnets[0], precision)
+            x = self._attention(x, "decoder.mid_block.attentions.0", m.attentions[0], precision)
+            x = self._resnet(x, "decoder.mid_block.resnets.1", m.resnets[1], precision)
+            for i, u in enumerate(d.up_blocks):
+                for j, r in enumerate(u.resnets):
+                    x = self._resnet(x, f"decoder.up_blocks.{i}.resnets.{j}", r, precision)
+                if u.upsamplers is not None:
+                    x = self._conv(x, f"decoder.up_blocks.{i}.upsamplers.0.conv", u.upsamplers[0].conv, precision, 9, up=True)
+            y = self._conv(x, "decoder.conv_out", d.conv_out, precision, 9, norm=d.conv_norm_out, silu=True)
+            return y[..., :d.conv_out.out_channels].permute(0, 3, 1, 2).contiguous()
+        finally:
+            ops.use(prev)
 
 
 # attention parameters of the checkpoints published before diffusers renamed them (its loader converts these names too)

@@ -479,7 +479,7 @@ def test_sd_vae_decoder_two_restatements_agree(tmp_path):
     for p in small.parameters():
         p.data.normal_(0, 0.15)
     z = torch.randn(2, 4, 5, 6, dtype=torch.float64)
-    got = small.decode(z).numpy()
+    got = small.decode_torch(z).numpy()
     want = ovae.Decoder({k: v.numpy() for k, v in small.state_dict().items()}, groups=8).decode(z.numpy())
     assert got.shape == (2, 3, 20, 24)          # two upsamplers for three blocks: x4
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
@@ -506,7 +506,7 @@ def test_sd_vae_decoder_two_restatements_agree(tmp_path):
     path = str(tmp_path / "diffusion_pytorch_model.bin")
     torch.save(legacy, path)
     re = rvae.load_sd_vae_decoder(str(tmp_path), block_out_channels=(16, 32, 32), layers_per_block=1, norm_num_groups=8)
-    np.testing.assert_allclose(re.decode(z.float()).numpy(), got, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(re.decode_torch(z.float()).numpy(), got, rtol=2e-4, atol=2e-4)
 
 
 def test_mocov3_checkpoint_key_repair(tmp_path, monkeypatch):
