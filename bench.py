@@ -45,6 +45,7 @@ def parse(argv=None):
                          "operands with dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--no-vae-leg", action="store_true", help="skip the SD-VAE decode leg (SURVEY.md N4) the N = 1 run appends")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the b = 32 per-GPU leg (the 8-GPU shape) the N = 1 run appends")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("REED_BENCH_LAUNCH_TIMEOUT", "2400")),
                     help="seconds the self-launcher lets its ranks run before it ends them (a hung collective must not hang the caller)")
@@ -293,6 +294,29 @@ def c3_leg(step, dev, z_dim, b=32, steps=10, warmup=3):
             "note": "one GPU, no gradient all-reduce: the compute side of the 8-GPU run (b = 256 / 8 per GPU)"}
 
 
+def n4_vae_leg(dev, batch=8, reps=3):
+    """SURVEY.md §8f N4 beside the headline: the SD-VAE decoder of generate.py / the previews (published sd-vae-ft configuration,
+    random weights, 32x32 latents -> 256x256 images) on the HIP kernels, fp16 operands = what generate.py uses under the
+    reference's default --tf32.  After the timed region; ~1 s including building the 49.5 M-parameter module."""
+    from reed_amd.vae import SDVAEDecoder
+    torch.manual_seed(0)
+    dec = SDVAEDecoder()
+    for p in dec.parameters():
+        p.data.normal_(0, 0.02)
+    dec = dec.to(dev)
+    z = torch.randn(batch, 4, 32, 32, device=dev)
+    dec.decode(z, precision="fp16")              # warm-up: weights packed, workspaces allocated
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        img = dec.decode(z, precision="fp16")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"images_per_sec": round(batch / dt, 1), "ms_per_image": round(dt / batch * 1e3, 3), "operands": "fp16", "batch": batch,
+            "finite": bool(torch.isfinite(img).all()),
+            "note": "reed_amd/vae.py on csrc/vae.hip + csrc/conv.hip (implicit-GEMM 3x3 convolutions); parity unpinned vs diffusers"}
+
+
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
@@ -502,6 +526,11 @@ def main():
                 out["c3_per_gpu_leg"] = c3_leg(step, dev, args.z_dim)
             except Exception as e:   # a reported leg, never a reason to lose the headline line
                 out["c3_per_gpu_leg"] = {"error": repr(e)}
+        if world == 1 and not args.no_vae_leg:
+            try:
+                out["n4_vae_decode"] = n4_vae_leg(dev)
+            except Exception as e:
+                out["n4_vae_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -306,17 +306,19 @@ int reed_preprocess_image(const uint8_t* raw, float* out, int B, int R, int S, c
  * ------------------------------------------------------------------------------------------- */
 /* doubles of workspace reed_groupnorm_stats needs for x f32 [B, hw, C] */
 int64_t reed_groupnorm_ws_doubles(int B, int64_t hw, int C);
-/* stats f32 [B, G, 2] = (mean, 1 / sqrt(biased var + eps)) of x f32 [B, hw, C] per (image, group of C / G channels);
- * fp64 sums in a fixed order.  C % 4 == 0, C <= 1024. */
-int reed_groupnorm_stats(const float* x, int B, int64_t hw, int C, int G, float eps, double* ws, float* stats, void* stream);
+/* stats f32 [B, G, 2] (optional) = (mean, rstd = 1 / sqrt(biased var + eps)) of x f32 [B, hw, C] per (image, group of C / G
+ * channels), fp64 sums in a fixed order; table f32 [B, 3, C] (optional; needs gamma, beta f32 [C]) = per channel
+ * (mean of its group, rstd * gamma[c], beta[c]) for reed_conv_rows.  C % 4 == 0, C <= 1024. */
+int reed_groupnorm_stats(const float* x, int B, int64_t hw, int C, int G, float eps, const float* gamma, const float* beta,
+                         double* ws, float* stats, float* table, void* stream);
 /* The row operand of a convolution as a GEMM: out (operand type) [nrows, ldo], row r - row0 = output position r = (b, y, x) of
  * the [B, Hi << upsample, Wi << upsample] grid, columns tap * C + c = a(b, y + tap / 3 - 1, x + tap % 3 - 1, c) for taps = 9
  * (zero outside the grid: padding 1) or a(b, y, x, c) for taps = 1, columns [taps * C, kcols) zero; a = x f32 [B, Hi, Wi, C]
- * read through nearest x2 upsampling when `upsample`, GroupNorm-ed with `stats` f32 [B, G, 2] and gamma / beta f32 [C] when
- * stats != NULL, SiLU-ed when `silu`.  C, kcols, ldo multiples of 4. */
-int reed_conv_rows(const float* x, const float* stats, const float* gamma, const float* beta, int B, int Hi, int Wi, int C,
-                   int G, int silu, int upsample, int taps, int64_t row0, int64_t nrows, int kcols, void* out, int64_t ldo,
-                   void* stream);
+ * read through nearest x2 upsampling when `upsample`, GroupNorm-ed as fma(x - mean, rstd * gamma, beta) with reed_groupnorm_stats'
+ * table when table != NULL, SiLU-ed when `silu`.  taps = 1 is the activation pass in front of reed_conv3x3 and of the
+ * attention's Linear layers.  C, kcols, ldo multiples of 4; fewer than 2^31 output positions. */
+int reed_conv_rows(const float* x, const float* table, int B, int Hi, int Wi, int C, int silu, int upsample, int taps,
+                   int64_t row0, int64_t nrows, int kcols, void* out, int64_t ldo, void* stream);
 /* 3x3 convolution, padding 1, as an implicit GEMM on the 16-bit matrix cores (csrc/conv.hip; the fp32-operand build returns 1002:
  * use reed_conv_rows with taps = 9 + reed_gemm there): out f32 [B*Ho*Wo, ldc] (+)= conv(a) + bias, a (operand type) NHWC
  * [B, Hi, Wi, C] read through nearest x2 upsampling when `upsample` (Ho = Hi << upsample), w (operand type) [N, 9 C] in

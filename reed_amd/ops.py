@@ -498,21 +498,21 @@ def sde_update(x_cur, model_out, eps, x_next, n, cfg, cfg_scale, t_cur, dt, path
 
 
 # ---------------- SD-VAE decoder passes (csrc/vae.hip) ----------------
-def groupnorm_stats(x, B, hw, C, G, eps, stats, ws=None):
-    """stats f32 [B, G, 2] = (mean, rstd) of x f32 [B, hw, C] per (image, group)."""
+def groupnorm_stats(x, B, hw, C, G, eps, stats=None, ws=None, gamma=None, beta=None, table=None):
+    """stats f32 [B, G, 2] = (mean, rstd) of x f32 [B, hw, C] per (image, group); table f32 [B, 3, C] = the per-channel
+    (mean, rstd * gamma, beta) that conv_rows applies.  Returns the fp64 workspace for re-use."""
     L = _lib.load(_PRECISION)
     need = int(L.reed_groupnorm_ws_doubles(B, hw, C))
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float64, device=x.device)
-    _call("reed_groupnorm_stats", _p(x), B, hw, C, G, float(eps), _p(ws), _p(stats), _stream())
+    _call("reed_groupnorm_stats", _p(x), B, hw, C, G, float(eps), _p(gamma), _p(beta), _p(ws), _p(stats), _p(table), _stream())
     return ws
 
 
-def conv_rows(x, out, B, Hi, Wi, C, taps, row0, nrows, kcols, ldo, stats=None, gamma=None, beta=None, G=0, silu=False,
-              upsample=False):
+def conv_rows(x, out, B, Hi, Wi, C, taps, row0, nrows, kcols, ldo, table=None, silu=False, upsample=False):
     """out (operand type) [nrows, ldo] = the rows [row0, row0 + nrows) of the convolution's GEMM operand (reed_conv_rows)."""
-    _call("reed_conv_rows", _p(x), _p(stats), _p(gamma), _p(beta), B, Hi, Wi, C, G, int(silu), int(upsample), taps, row0, nrows,
-          kcols, _p(out), ldo, _stream())
+    _call("reed_conv_rows", _p(x), _p(table), B, Hi, Wi, C, int(silu), int(upsample), taps, row0, nrows, kcols, _p(out), ldo,
+          _stream())
 
 
 def softmax_rows(s, lds, p, ldp, rows, cols, scale):

@@ -193,11 +193,14 @@ class _HipDecode:
         return self.ws
 
     # ---- passes ----
-    def _stats(self, x, norm):
+    def _table(self, x, norm):
+        """f32 [B, 3, C]: per channel (group mean, rstd * gamma, beta) of GroupNorm(x)"""
         B, H, W, C = x.shape
-        st = torch.empty(B, norm.num_groups, 2, dtype=torch.float32, device=x.device)
-        self.gn_ws = ops.groupnorm_stats(x, B, H * W, C, norm.num_groups, norm.eps, st, self.gn_ws)
-        return st
+        tb = torch.empty(B, 3, C, dtype=torch.float32, device=x.device)
+        self.gn_ws = ops.groupnorm_stats(x, B, H * W, C, norm.num_groups, norm.eps, ws=self.gn_ws,
+                                         gamma=norm.weight.detach().float().contiguous(), beta=norm.bias.detach().float().contiguous(),
+                                         table=tb)
+        return tb
 
     def _conv(self, x, name, mod, prec, taps, norm=None, silu=False, up=False, out=None, accumulate=False):
         """x f32 [B, Hi, Wi, C] -> f32 [B, Ho, Wo, Cout_padded] (+= when accumulate) = conv(act(norm(upsample(x))))"""
@@ -210,10 +213,7 @@ class _HipDecode:
         if out is None:
             out = torch.empty(B, Ho, Wo, npad, dtype=torch.float32, device=x.device)
         assert out.shape == (B, Ho, Wo, npad) and out.is_contiguous()
-        st = self._stats(x, norm) if norm is not None else None
-        gamma = norm.weight.detach().float().contiguous() if norm is not None else None
-        beta = norm.bias.detach().float().contiguous() if norm is not None else None
-        G = norm.num_groups if norm is not None else 0
+        tb = self._table(x, norm) if norm is not None else None
         es = ops.half_dtype(prec).itemsize
         if prec != "fp32" and taps == 9 and C % 64 == 0:
             # 16-bit builds: the activation once in the operand type (norm + SiLU + rounding, 6 B / element), then the implicit GEMM
@@ -222,7 +222,7 @@ class _HipDecode:
             act = self._workspace(bc * per, x.device)
             for b0 in range(0, B, bc):
                 nb = min(bc, B - b0)
-                ops.conv_rows(x, act, B, Hi, Wi, C, 1, b0 * Hi * Wi, nb * Hi * Wi, C, C, stats=st, gamma=gamma, beta=beta, G=G, silu=silu)
+                ops.conv_rows(x, act, B, Hi, Wi, C, 1, b0 * Hi * Wi, nb * Hi * Wi, C, C, table=tb, silu=silu)
                 ops.conv3x3(act, wm, self.bias32[(name, prec)], out.data_ptr() + b0 * Ho * Wo * npad * 4, npad, nb, Hi, Wi, C, npad,
                             upsample=up, accumulate=accumulate)
             return out
@@ -234,8 +234,7 @@ class _HipDecode:
             if direct:
                 P = x.data_ptr() + r0 * C * 4
             else:
-                ops.conv_rows(x, cols, B, Hi, Wi, C, taps, r0, n, kcols, kcols, stats=st, gamma=gamma, beta=beta, G=G, silu=silu,
-                              upsample=up)
+                ops.conv_rows(x, cols, B, Hi, Wi, C, taps, r0, n, kcols, kcols, table=tb, silu=silu, upsample=up)
                 P = cols
             ops.gemm(ops.NT, ops.EPI_F32, P, wm, n, npad, kcols, out.data_ptr() + r0 * npad * 4, kcols, kcols, npad, bias=bm,
                      accumulate=accumulate)
@@ -258,10 +257,8 @@ class _HipDecode:
         wm, bm, co, k = self._pack(name + ".qkv", a._qkv, prec)
         kcols = wm.shape[1]
         assert wm.shape[0] == 3 * C, "attention width must be a multiple of the GEMM's column granule"
-        st = self._stats(x, a.group_norm)
         t = torch.empty(B * T, kcols, dtype=hd, device=x.device)
-        ops.conv_rows(x, t, B, H, W, C, 1, 0, B * T, kcols, kcols, stats=st, gamma=a.group_norm.weight.detach().float().contiguous(),
-                      beta=a.group_norm.bias.detach().float().contiguous(), G=a.group_norm.num_groups)
+        ops.conv_rows(x, t, B, H, W, C, 1, 0, B * T, kcols, kcols, table=self._table(x, a.group_norm))
         Tp = _round_up(T, 4 if prec == "fp32" else 128)      # rows of an image's q / k / v block: the score GEMM's N and the
         qkv = (torch.zeros if Tp != T else torch.empty)(B * Tp, 3 * C, dtype=hd, device=x.device)   # P V GEMM's K granule
         es = hd.itemsize

@@ -25,7 +25,9 @@ def test_groupnorm_stats(dev, lib, B, hw, C, G):
     g = torch.Generator().manual_seed(hw + C)
     x = torch.randn(B, hw, C, generator=g) * 3 + torch.randn(1, 1, C, generator=g) * 5
     st = torch.full((B, G, 2), float("nan"), device=dev)
-    lib.groupnorm_stats(x.to(dev), B, hw, C, G, 1e-6, st)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    tb = torch.full((B, 3, C), float("nan"), device=dev)
+    lib.groupnorm_stats(x.to(dev), B, hw, C, G, 1e-6, st, gamma=gamma.to(dev), beta=beta.to(dev), table=tb)
     xg = x.double().view(B, hw, G, C // G).permute(0, 2, 1, 3).reshape(B, G, -1)
     mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
     np.testing.assert_allclose(st[..., 0].cpu().numpy(), mean.numpy(), rtol=1e-6, atol=1e-6)
@@ -33,6 +35,9 @@ def test_groupnorm_stats(dev, lib, B, hw, C, G):
     st2 = torch.empty_like(st)
     lib.groupnorm_stats(x.to(dev), B, hw, C, G, 1e-6, st2)
     assert torch.equal(st, st2)          # fixed summation order
+    rep = lambda v: v.repeat_interleave(C // G, dim=1)   # noqa: E731
+    assert torch.equal(tb[:, 0], rep(st[..., 0])) and torch.equal(tb[:, 2].cpu(), beta.expand(B, C))
+    assert torch.equal(tb[:, 1].cpu(), rep(st[..., 1]).cpu() * gamma)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
@@ -61,18 +66,17 @@ def test_conv_rows(dev, prec, taps, up, norm, silu):
     xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
     prev = ops.use(prec)
     try:
-        st = None
+        tb = None
         if norm:
-            st = torch.empty(B, G, 2, device=dev)
-            ops.groupnorm_stats(xn, B, Hi * Wi, C, G, 1e-6, st)
+            tb = torch.empty(B, 3, C, device=dev)
+            ops.groupnorm_stats(xn, B, Hi * Wi, C, G, 1e-6, gamma=gamma.to(dev), beta=beta.to(dev), table=tb)
         kcols = taps * C + 8
         M = B * Ho * Wo
         out = torch.full((M, kcols + 4), 7.0, dtype=ops.half_dtype(), device=dev)
         half = M // 2 + 3
         for r0, n in ((0, half), (half, M - half)):
             ops.conv_rows(xn, out.data_ptr() + r0 * (kcols + 4) * out.element_size(), B, Hi, Wi, C, taps, r0, n, kcols, kcols + 4,
-                          stats=st, gamma=gamma.to(dev) if norm else None, beta=beta.to(dev) if norm else None, G=G if norm else 0,
-                          silu=silu, upsample=up)
+                          table=tb, silu=silu, upsample=up)
     finally:
         ops.use(prev)
     got = out.double().cpu()
