@@ -59,6 +59,13 @@ def launcher_argv(args, argv, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+# REED_BENCH_REHEARSE=gloo: a rehearsal of the N > 1 run on a box with fewer GPUs — the ranks share the visible devices
+# (LOCAL_RANK modulo their count) and the collectives go over gloo (RCCL refuses two ranks on one device).  Everything else
+# is the real path: self-launch, rendezvous, the reducer's buckets fired from backward, the barriers, MAX over ranks, the one
+# JSON line.  The record says "rehearsal" and its value is not a measurement.
+REHEARSE = os.environ.get("REED_BENCH_REHEARSE", "") == "gloo"
+
+
 def _free_port():
     import socket
     with socket.socket() as s_:
@@ -73,7 +80,7 @@ def self_launch(args, argv):
     import signal
     import subprocess
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not REHEARSE:
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible on this node", file=sys.stderr, flush=True)
         return 2
     env = dict(os.environ)
@@ -333,6 +340,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment (unset it to let bench.py start "
                          f"its own ranks, or launch with torch.distributed.run --nproc-per-node {args.gpus})")
+    if REHEARSE:
+        local_rank %= max(1, torch.cuda.device_count())
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -346,7 +355,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         # this image exports NCCL_DEBUG=VERSION, which makes RCCL print its banner on STDOUT: keep stdout to the one JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/reed_rccl.%h.%p.log")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if REHEARSE:
+            os.environ["REED_COMM"] = "torch"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import copy
     from reed_amd.loss import SILoss
@@ -474,7 +487,8 @@ def main():
             "metric": "SiT-XL/2 ImageNet-256 train images/sec", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.mixed_precision == "bf16" else "f16",
-            "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)",
+            "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)" +
+                    (" — REHEARSAL: ranks share the visible GPUs, collectives over gloo; not a measurement" if REHEARSE else ""),
             "config": {"workload": f"C{'2' if world == 1 else '3'}: {args.model} + {args.z_dim}-d alignment projector (REED loss), "
                                    f"global batch {args.global_batch} (b={b}/GPU), full train step "
                                    "(fwd+bwd+clip+AdamW+EMA), bf16 MFMA / fp32 master",

@@ -589,3 +589,22 @@ def test_bench_self_launch(dev):
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["local_batch"] == 64
     leg = d["c3_per_gpu_leg"]
     assert leg["local_batch"] == 32 and leg["images_per_sec_per_gpu"] > 0 and np.isfinite(leg["final_loss"])
+
+
+def test_bench_two_ranks_rehearsal(dev):
+    """`python bench.py --gpus 2` end to end on a one-GPU box (REED_BENCH_REHEARSE=gloo: both ranks on the one device,
+    collectives over gloo): the self-launch, the rendezvous, broadcast of the parameters, the reducer's buckets fired from
+    backward with the run-time CU-reserve tuning, the barriers, MAX over ranks and the single relayed JSON line — every line of
+    the N > 1 bench path except RCCL itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["REED_BENCH_REHEARSE"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "SiT-S/2",
+                        "--global-batch", "16", "--no-cpu-baseline", "--no-kernel-table"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["local_batch"] == 8 and d["config"]["global_batch"] == 16
+    assert d["data_parallel"]["world"] == 2 and "REHEARSAL" in d["data"] and np.isfinite(d["final_loss"])
+    assert "c3_per_gpu_leg" not in d and d["scaling"] == "strong"
