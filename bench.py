@@ -384,6 +384,8 @@ def main():
     # data-parallel run unless the caller fixed it.  The bucket form stays "allreduce" unless REED_COMM_ALGO says otherwise.
     if reducer is not None:
         os.environ.setdefault("REED_COMM_CUS", "auto")
+        if world > 1:
+            os.environ.setdefault("REED_OPT_SHARD", "auto")   # measured against the replicated pass, kept only if faster
     step = TrainStep(model, loss_fn, opt, reducer, proj_coeff=0.5, diffusion_warm_up_steps=0)
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -448,6 +450,7 @@ def main():
           # CUs the GEMM grids leave to RCCL's channels: measured by the first steps (reserve -> ms per step, MAX over ranks)
           "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning, "algo_in_use": getattr(reducer, "algo", None),
           "tune_error": step.tune_error, "optimizer_sharded": bool(getattr(opt, "_shard", False)),
+          "optimizer_shard_tuning": step.shard_tuning,
           "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}
     if reducer is not None:
         try:

@@ -79,6 +79,10 @@ class TrainStep:
         #   REED_COMM_ALGO=auto         afterwards the same measurement for the bucket form (ncclAllReduce vs ncclReduceScatter +
         #                               ncclAllGather, parallel.py); otherwise the form stays what REED_COMM_ALGO names
         #                               (default allreduce): the fp32 summation order is then fixed from run to run.
+        #   REED_OPT_SHARD=auto         last, the sharded optimiser pass (optim.py:_shard_plan: 1 / world of every chunk per rank +
+        #                               an in-place all-gather of the 16-bit shadows) against the best replicated time, after a
+        #                               collective self-test of its gather path; kept only where it measured faster (the
+        #                               arithmetic and the operand copies are identical either way).  bench.py asks for this.
         # Any failure inside the measurement's bookkeeping ends it with reserve 0 / allreduce on every rank (tune_error).
         self.cu_reserve = 0
         self.cu_tuning = None
@@ -86,18 +90,24 @@ class TrainStep:
         self._tune = []
         self._tune_algo = False
         mode = os.environ.get("REED_COMM_CUS", "off")
-        if reducer is not None and reducer.active() and mode != "off":
-            if mode == "auto":
-                cands = [int(v) for v in os.environ.get("REED_COMM_CUS_CANDIDATES", "0,16,32").split(",")]
+        self._tune_shard = (os.environ.get("REED_OPT_SHARD") == "auto" and reducer is not None and reducer.active()
+                            and hasattr(optimizer, "set_sharded") and getattr(optimizer, "overlap", False))
+        self.shard_tuning = None
+        if reducer is not None and reducer.active() and (mode != "off" or self._tune_shard):
+            if mode not in ("off", "auto"):
+                self.cu_reserve = int(mode)
+                ops.set_cu_reserve(self.cu_reserve)
+            if mode == "auto" or self._tune_shard:
+                cands = ([int(v) for v in os.environ.get("REED_COMM_CUS_CANDIDATES", "0,16,32").split(",")] if mode == "auto"
+                         else [self.cu_reserve])          # (only the sharded pass is measured: its replicated baseline)
                 nt = max(1, int(os.environ.get("REED_COMM_TUNE_STEPS", "3")))
                 self._tune = [(c, k) for c in cands for k in range(nt + 1)]   # k = 0: settling step, k >= 1: timed
                 self._tune_times = {}
                 self._tune_algo = os.environ.get("REED_COMM_ALGO") == "auto" and hasattr(reducer, "algo")
                 if self._tune_algo:
                     self._tune += [("rsag", k) for k in range(nt + 1)]
-            else:
-                self.cu_reserve = int(mode)
-                ops.set_cu_reserve(self.cu_reserve)
+                if self._tune_shard:
+                    self._tune += [("shard", k) for k in range(nt + 1)]
 
     def __call__(self, x, labels, zs, moments=None, **inject):
         """x: latents [b,4,32,32] (or pass moments=[b,8,32,32] to run sample_posterior). Returns device scalars."""
@@ -112,8 +122,12 @@ class TrainStep:
         if tune is not None:
             if tune[0] == "rsag":
                 self.reducer.algo = "rsag"
+            elif tune[0] == "shard":
+                if tune[1] == 0 and not self._shard_start():      # self-test failed somewhere: the candidate is dropped
+                    tune = None
             else:
                 ops.set_cu_reserve(tune[0])
+        if tune is not None:
             if tune[1]:   # a timed step of this candidate (tune[1] == 0 is its settling step)
                 self._tune_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 self._tune_ev[0].record()
@@ -156,15 +170,37 @@ class TrainStep:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
+    def _shard_start(self):
+        """First step of the sharded-pass candidate: collective self-test of its gather path, then switch the optimiser over.
+        False (on every rank alike) drops the candidate."""
+        ok = False
+        try:
+            ok = self.opt.shard_selftest()
+            if ok:
+                self.opt.set_sharded(True)
+        except Exception as e:
+            ok = False
+            self.tune_error = repr(e)
+        if not ok:
+            self._tune = [t for t in self._tune if t[0] != "shard"]
+            self.shard_tuning = {"kept": False, "reason": "self-test of the in-place all-gather failed"}
+            self._log("sharded optimiser pass not measured: the self-test of its all-gather failed on some rank")
+        return ok
+
     def _tune_abort(self, err):
-        """Leave the measurement with the safe plan (reserve 0, all-reduce buckets).  Every rank runs the same bookkeeping
-        on the same schedule, so a deterministic failure ends it on all of them at the same step."""
+        """Leave the measurement with the safe plan (reserve 0, all-reduce buckets, replicated optimiser pass).  Every rank runs
+        the same bookkeeping on the same schedule, so a deterministic failure ends it on all of them at the same step."""
         self._tune = []
         self.tune_error = repr(err)
         self.cu_reserve = 0
         ops.set_cu_reserve(0)
         if self._tune_algo:
             self.reducer.algo = "allreduce"
+        if self._tune_shard:
+            try:
+                self.opt.set_sharded(False)
+            except Exception:
+                pass
 
     def _median_ms(self, cand):
         ms = []
@@ -181,8 +217,8 @@ class TrainStep:
                 self._tune_ev[1].record()
                 self._tune_times.setdefault(cand, []).append(self._tune_ev)
             nxt = self._tune[0][0] if self._tune else None
-            if self.cu_tuning is None and (nxt is None or nxt == "rsag"):   # every reserve candidate is timed: keep the fastest
-                cands = sorted(c for c in self._tune_times if c != "rsag")
+            if self.cu_tuning is None and (nxt is None or nxt in ("rsag", "shard")):   # every reserve candidate is timed: keep the fastest
+                cands = sorted(c for c in self._tune_times if c not in ("rsag", "shard"))
                 t = self._agree([self._median_ms(c) for c in cands])
                 best = min(range(len(cands)), key=lambda i: t[i])
                 self.cu_reserve = cands[best]
@@ -190,11 +226,20 @@ class TrainStep:
                 self._best_ms = t[best]
                 ops.set_cu_reserve(self.cu_reserve)
                 self._log(f"CU reserve {self.cu_reserve} kept (median ms per step, MAX over ranks: {self.cu_tuning})")
-            if not self._tune and self._tune_algo:                           # the bucket form at that reserve
+            if self._tune_algo and "rsag" in self._tune_times and nxt != "rsag" and "rsag" not in self.cu_tuning:   # the bucket form
                 t = self._agree([self._median_ms("rsag")])[0]
                 self.cu_tuning["rsag"] = round(t, 3)
                 self.reducer.algo = "rsag" if t < self._best_ms else "allreduce"
                 self._log(f"bucket form {self.reducer.algo} kept (rsag {t:.3f} ms vs allreduce {self._best_ms:.3f} ms)")
+                self._best_ms = min(t, self._best_ms)
+            if not self._tune and "shard" in self._tune_times:                # the sharded optimiser pass at that plan
+                t = self._agree([self._median_ms("shard")])[0]
+                keep = t < self._best_ms
+                self.shard_tuning = {"kept": keep, "sharded_ms": round(t, 3), "replicated_ms": round(self._best_ms, 3)}
+                if not keep:
+                    self.opt.set_sharded(False)
+                self._log(f"optimiser pass {'sharded' if keep else 'replicated'} kept (sharded {t:.3f} ms vs replicated "
+                          f"{self._best_ms:.3f} ms per step)")
         except Exception as e:   # never fatal: the safe plan on every rank
             self._tune_abort(e)
             self._log(f"measurement abandoned ({e!r}): CU reserve 0, all-reduce buckets")
