@@ -38,7 +38,9 @@ int reed_half_kind(void);
  *   layout 3 / 4: TN on a 256x128 / 128x256 output tile (128x64 / 64x128 per wave; epilogue 6 only; 4 needs N%256==0)
  * epilogue codes: see reed_amd/csrc/gemm.h (11 = exact GELU(erf) with the layout of 9; 0 bf16, 1 gelu, 2 silu, 3 gate+residual, 4 dgelu,
  *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual, 12 LayerScale + fp32 residual:
- *   C f32 = R f32 + gamma[n] * float(bf16(acc + bias)) with `gate` = the fp32 gamma vector, NT only).  N%128==0 (NT/NN with a
+ *   C f32 = R f32 + gamma[n] * float(bf16(acc + bias)) with `gate` = the fp32 gamma vector, NT only; 13 = 0 plus the per-row,
+ *   per-head partial dot products with R for reed_attention_bwd_dp (NN; returns 1002 without launching where the shape's
+ *   kernel has no such epilogue).  N%128==0 (NT/NN with a
  *   bf16-output epilogue also N%144==0: the 256x144 tile of csrc/gemm144.hip); K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
  *   dbias likewise holds split_k slabs of M floats AT THE SAME slab_stride — put slab 0 of dbias right behind slab 0
@@ -131,6 +133,12 @@ int reed_attention_bwd(const void* qkv, const void* o, const void* d_o, const fl
  * F.scaled_dot_product_attention inside timm Attention (image/models/sit.py:114-118). */
 int64_t reed_attention_bwd_ws_floats(int B, int T, int H);
 int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
+                          int B, int T, int H, int hd, void* stream);
+/* The same with delta taken from dpart f32 [H, S, B*T] (S = 1 for hd 64, 2 for hd 72): the per-row, per-head partial dot
+ * products dO . O that reed_gemm's epilogue 13 leaves when it PRODUCES dO (the input gradient of the attention output
+ * projection, layout NN, R = O, C2 = dpart, rows_per_gate = hd) — the 302 MB row pass over dO and O (b = 256) becomes a
+ * 12 MB one, and O is not read by the backward at all.  16-bit builds; the fp32 build returns 1002. */
+int reed_attention_bwd_dp(const void* qkv, const void* d_o, const float* lse, const float* dpart, void* dqkv, float* ws,
                           int B, int T, int H, int hd, void* stream);
 
 /* qk_norm (timm Attention(qk_norm=True); reference flag --qk-norm, sit.py:114-116): LayerNorm over head_dim (eps, affine

@@ -1167,6 +1167,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
   delta[(b * H + h) * T + t] = acc;
 }
 
+// delta[b, h, t] from the partial dot products the dO-producing GEMM left (reed_gemm epilogue 13): dpart f32 [H, S, B * T]
+__global__ __launch_bounds__(256) void attn_delta_combine_kernel(const float* __restrict__ dpart, float* __restrict__ delta,
+                                                                 long ntok, int T, int H, int S) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;   // h * ntok + (b * T + t)
+  if (i >= ntok * H) return;
+  const int h = (int)(i / ntok);
+  const long tokn = i - h * ntok;
+  float acc = dpart[(long)h * S * ntok + tokn];
+  if (S == 2) acc += dpart[((long)h * S + 1) * ntok + tokn];
+  const long b = tokn / T;
+  const int t = (int)(tokn - b * T);
+  delta[(b * H + h) * T + t] = acc;
+}
+
 template <int HD>
 __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
@@ -1921,11 +1935,10 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
 // one-shot key-stationary kernel of reed_attention_bwd instead (same-box A/B).
 extern "C" int64_t reed_attention_bwd_ws_floats(int B, int T, int H) { return (int64_t)B * T * H; }
 
-extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
-                                     int B, int T, int H, int hd, void* stream) {
-  static const bool other = getenv("REED_ATTN_BWD") != nullptr || (getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1);
-  if (other || !ws) return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
-  REED_CHECK_ARG(qkv && o && d_o && lse && dqkv, "attention_bwd: null pointer");
+// dpart != NULL: delta comes from the partial dot products of reed_gemm's epilogue 13 (o is not read)
+static int attention_bwd_persistent(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
+                                    const float* dpart, int B, int T, int H, int hd, void* stream) {
+  REED_CHECK_ARG(qkv && (o || dpart) && d_o && lse && dqkv && ws, "attention_bwd: null pointer");
   REED_CHECK_ARG(hd == 64 || hd == 72, "attention: head_dim %d unsupported (64 or 72)", hd);
   REED_CHECK_ARG(B > 0 && H > 0 && T > 0 && T <= 256, "attention_bwd: B=%d H=%d T=%d unsupported (training path is T <= 256)", B, H, T);
   const int lds = 4 * TILE_B + 256 + 2048;
@@ -1936,11 +1949,18 @@ extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void*
   const dim3 pgrid(nitems < ncu ? nitems : ncu);
   hipStream_t s = (hipStream_t)stream;
   static const int dbg = getenv("REED_ATTN_KSP_DBG") ? atoi(getenv("REED_ATTN_KSP_DBG")) : 0;   // diagnosis: skip parts of the work
+#define REED_DELTA(HD)                                                                                                    \
+  do {                                                                                                                    \
+    if (dpart)                                                                                                            \
+      REED_KLAUNCH(attn_delta_combine_kernel, dim3(cdiv(nseg, 256)), dim3(256), 0, s, dpart, ws, (long)B * T, T, H, (HD) == 64 ? 1 : 2); \
+    else                                                                                                                  \
+      REED_KLAUNCH(attn_delta_kernel<HD>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, ws, nseg, T, H); \
+  } while (0)
 #define REED_BWD_KSP(HD)                                                                                                  \
   do {                                                                                                                    \
     static int once = set_lds(attn_bwd_ksp_kernel<HD>, lds);                                                              \
     if (once) return once;                                                                                                \
-    REED_KLAUNCH(attn_delta_kernel<HD>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, ws, nseg, T, H); \
+    REED_DELTA(HD);                                                                                                       \
     REED_LAUNCH_CHECK();                                                                                                  \
     REED_KLAUNCH(attn_bwd_ksp_kernel<HD>, pgrid, dim3(512), lds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
                  (bf16*)dqkv, T, H, nitems, dbg);                                                                              \
@@ -1952,7 +1972,7 @@ extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void*
   do {                                                                                                                    \
     static int once = set_lds(attn_bwd_ring_kernel<HD>, rlds);                                                            \
     if (once) return once;                                                                                                \
-    REED_KLAUNCH(attn_delta_kernel<HD>, dim3(cdiv(nseg, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, ws, nseg, T, H); \
+    REED_DELTA(HD);                                                                                                       \
     REED_LAUNCH_CHECK();                                                                                                  \
     REED_KLAUNCH(attn_bwd_ring_kernel<HD>, pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
                  (bf16*)dqkv, H, nitems, dbg);                                                                            \
@@ -1968,4 +1988,18 @@ extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void*
 #undef REED_BWD_KSP
   REED_LAUNCH_CHECK();
   return REED_OK;
+}
+#undef REED_DELTA
+
+extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
+                                     int B, int T, int H, int hd, void* stream) {
+  static const bool other = getenv("REED_ATTN_BWD") != nullptr || (getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1);
+  if (other || !ws) return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
+  return attention_bwd_persistent(qkv, o, d_o, lse, dqkv, ws, nullptr, B, T, H, hd, stream);
+}
+
+extern "C" int reed_attention_bwd_dp(const void* qkv, const void* d_o, const float* lse, const float* dpart, void* dqkv, float* ws,
+                                     int B, int T, int H, int hd, void* stream) {
+  REED_CHECK_ARG(dpart != nullptr, "attention_bwd_dp: the partial dot products of reed_gemm epilogue 13 are required");
+  return attention_bwd_persistent(qkv, nullptr, d_o, lse, dqkv, ws, dpart, B, T, H, hd, stream);
 }

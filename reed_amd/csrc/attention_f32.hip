@@ -287,3 +287,9 @@ extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void*
                                      int T, int H, int hd, void* stream) {
   return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
 }
+
+// the partial-dot-product form belongs to the 16-bit GEMM's epilogue 13 (csrc/gemm_common.hpp): not in this build
+extern "C" int reed_attention_bwd_dp(const void*, const void*, const float*, const float*, void*, float*, int, int, int, int, void*) {
+  reed_set_error("reed_attention_bwd_dp: not built for fp32 operands (use reed_attention_bwd_ws)");
+  return REED_ERR_UNSUPPORTED;
+}

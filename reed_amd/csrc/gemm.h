@@ -19,6 +19,10 @@ enum {
   EPI_RES_BF16 = 10,  // C bf16 = bf16(bf16(acc+bias) + R bf16)
   EPI_LS_RES = 12,    // C f32 = R f32 + gamma f32[n] * float(bf16(acc+bias)): LayerScale + fp32 residual (DINOv2 blocks); `gate`
                       //   points at the fp32 gamma vector; NT only
+  EPI_BF16_DOT = 13,  // C bf16 = bf16(acc [+ bias]) and dpart f32 [N / hd, S, M] (C2) = per row and head of hd = rows_per_gate columns
+                      //   (64: S = 1, 72: S = 2) the partial dot products of the stored row with R bf16 [M, N]: slot s of head h is the
+                      //   part inside the (s + 1)-th 64-column strip the head touches.  NN, 256^2 four-wave kernel only: the attention
+                      //   backward's delta = rowsum(dO * O) formed where dO is produced (reed_attention_bwd_dp adds the slots)
   EPI_GELU_ERF = 11   // ABI id only: exact GELU on the EPI_QGELU instantiation (GemmArgs::act_variant = 1); the ViT towers' Mlp
 };
 

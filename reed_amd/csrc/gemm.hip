@@ -228,6 +228,23 @@ int reed_gemm_forced_tile() { return g_force_tile; }
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {
   REED_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "reed_gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+  // epilogue 13 (store + per-head dot products with R) exists in the four-wave 256^2 kernel only: the kernel is selected as for
+  // the plain store, and where that selection is another kernel the call returns 1002 without launching (the caller then
+  // stores plainly and lets reed_attention_bwd_ws form delta itself)
+  const int want = epi;
+  if (epi == EPI_BF16_DOT) {
+    REED_CHECK_ARG(layout == LAY_NN && a.R && a.C2 && (a.rows_per_gate == 64 || a.rows_per_gate == 72) &&
+                       a.N % a.rows_per_gate == 0 && a.N % 64 == 0 && splits <= 1,
+                   "reed_gemm(epilogue 13): NN, R and C2 given, rows_per_gate = head_dim 64 or 72 dividing N");
+    epi = EPI_BF16;
+  }
+#define REED_ONLY_PLAIN()                                                                             \
+  do {                                                                                                \
+    if (want == EPI_BF16_DOT) {                                                                       \
+      reed_set_error("reed_gemm(epilogue 13): this shape runs on a kernel without it (use epilogue 0)"); \
+      return REED_ERR_UNSUPPORTED;                                                                    \
+    }                                                                                                 \
+  } while (0)
   const bool can144 = reed_gemm144_eligible(layout, epi, a, splits);
   REED_CHECK_ARG(a.N % BN == 0 || can144, "reed_gemm: N=%d must be a multiple of %d (or, NT / NN with a bf16-output epilogue, of 144)", a.N, BN);
   REED_CHECK_ARG(a.ldp % 8 == 0 && a.ldq % 8 == 0, "reed_gemm: leading dims must be multiples of 8 elements");
@@ -258,18 +275,23 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
   if ((g_force_tile == 257 || g_force_tile == 258) && reed_gemm256w_eligible(layout, epi, a, splits))
-    return reed_gemm256w_launch(layout, epi, a, stream);   // 257: one-shot form, 258: persistent form wherever it applies
-  if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits))))
+    return reed_gemm256w_launch(layout, want, a, stream);   // 257: one-shot form, 258: persistent form wherever it applies
+  if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits)))) {
+    REED_ONLY_PLAIN();
     return reed_gemm144_launch(layout, epi, a, stream);
+  }
   if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, epi, a, splits)) &&
       !(layout == LAY_TN && a.dbias)) {
     // the 256^2 tile: four waves of 128x128 (gemm256w.hip) where that kernel is built, else eight of 128x64 (gemm256.hip);
     // REED_GEMM_W4=0 or force_tile 256 keep the 8-wave kernel (A/B timing)
     static const bool w4 = !(getenv("REED_GEMM_W4") && atoi(getenv("REED_GEMM_W4")) == 0);
     if (w4 && g_force_tile != 256 && reed_gemm256w_eligible(layout, epi, a, splits))
-      return reed_gemm256w_launch(layout, epi, a, stream);
+      return reed_gemm256w_launch(layout, want, a, stream);
+    REED_ONLY_PLAIN();
     return reed_gemm256_launch(layout, epi, a, splits, stream);
   }
+  REED_ONLY_PLAIN();
+#undef REED_ONLY_PLAIN
   switch (layout) {
     case LAY_NT: return dispatch_epi<LAY_NT>(epi, a, splits, stream);
     case LAY_NN: return dispatch_epi<LAY_NN>(epi, a, splits, stream);

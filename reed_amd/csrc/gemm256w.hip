@@ -705,6 +705,7 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
   } else {                         // input gradients
     switch (epi) {
       case EPI_BF16: return launch256w<LAY, EPI_BF16>(a, s);
+      case EPI_BF16_DOT: return launch256w<LAY, EPI_BF16_DOT>(a, s);
       case EPI_DGELU: return launch256w<LAY, EPI_DGELU>(a, s);
       case EPI_DSILU: return launch256w<LAY, EPI_DSILU>(a, s);
     }
@@ -720,7 +721,7 @@ bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) 
   // waves per SIMD to hide its own latency; measured 0.93 vs 0.64 ms on the ViT-L fc1 shape)
   const bool epi_ok = layout == LAY_NT ? (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES ||
                                           epi == EPI_RES_BF16 || epi == EPI_LS_RES)
-                                       : (epi == EPI_BF16 || epi == EPI_DGELU || epi == EPI_DSILU);
+                                       : (epi == EPI_BF16 || epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_DSILU);
   return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 && epi_ok;
 }
 

@@ -80,6 +80,7 @@ struct EpiOps {
   static constexpr int value = EPI == EPI_BF16 ? 1 + NI * 2
                                : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU ||
                                   EPI == EPI_QGELU || EPI == EPI_RES_BF16) ? 1 + NI * 4
+                               : EPI == EPI_BF16_DOT ? 1 + NI * 4
                                : EPI == EPI_GATE_RES ? 1 + NI * 12
                                : EPI == EPI_LS_RES ? 3 + NI * 8
                                                      : -1;  // fp32-accumulate epilogues: pointer path, not counted
@@ -163,7 +164,58 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
         for (int e = 0; e < 8; ++e) v[h][e] = q[h][e >> 2][e & 3] + bs[e];
     };
 
-    if constexpr (EPI == EPI_BF16) {
+    if constexpr (EPI == EPI_BF16_DOT) {
+      // the plain store plus, per row and head, the dot product of the stored values with R (same layout): a lane owns 8
+      // columns of one head (hd is a multiple of 8), the 8 lanes of a row cover this wave's 64-column strip, which holds the
+      // tail of head hA and possibly the start of head hA + 1; both sums go out from the row's first lane (fixed order: two
+      // quad butterflies + the upper quad, as DPP adds).  dpart f32 [N / hd, S, M]: a wave-level store is 8 consecutive rows.
+      const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsR = tile_rsrc(a.R, a.ldr, 2);
+      int oc = lane_off(a.ldc, 2);
+      const int orr = lane_off(a.ldr, 2);
+      const int s8 = (int)(8 * a.ldc * 2), r8 = (int)(8 * a.ldr * 2);
+      const int hd = a.rows_per_gate, S = hd == 64 ? 1 : 2;
+      const int hA = nbase / hd;
+      const bool inA = col / hd == hA, two = (nbase + 63) / hd != hA;
+      const int slotA = nbase / 64 - (hA * hd) / 64;
+      float* dpA = (float*)a.C2 + (long)(hA * S + slotA) * a.M;
+      float* dpB = (float*)a.C2 + (long)(hA + 1) * S * a.M;
+      bf16x8 rr[NI][2];
+      auto fetch = [&](int i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rr[i][h] = ld_bf16x8(rsR, orr + (2 * i + h) * r8);
+      };
+      auto sum8 = [](float x) {     // lanes 8 k .. 8 k + 7 -> their sum in lane 8 k
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x104, 0xF, 0xF, true));  // row_shl:4
+        return x;
+      };
+#pragma unroll
+      for (int i = 0; i < PF && i < NI; ++i) fetch(i);
+#pragma unroll
+      for (int i = 0; i < NI; ++i, oc += 2 * s8) {
+        if constexpr (PF == 0) fetch(i);
+        float v[2][8];
+        transpose(i, v);
+        if (PF > 0 && i + PF < NI) fetch(i + PF);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(v[h][e]);
+          st_bf16x8(o, rsC, oc + h * s8);
+          float d = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d = fmaf(bf2f(o[e]), bf2f(rr[i][h][e]), d);
+          const float dA = sum8(inA ? d : 0.f), dB = sum8(inA ? 0.f : d);
+          const long row = (long)m0 + rt + 16 * i + 8 * h;
+          if (rd_c == 0 && cv && row < a.M) {
+            dpA[row] = dA;
+            if (two) dpB[row] = dB;
+          }
+        }
+      }
+    } else if constexpr (EPI == EPI_BF16) {
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2);
       int oc = lane_off(a.ldc, 2);
       const int s8 = (int)(8 * a.ldc * 2);

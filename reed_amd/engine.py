@@ -43,6 +43,7 @@ class Engine:
         self.tap_depth = [model.encoder_depth if (zt == "i" or not split) else model.encoder_depth_text
                           for zt in model.z_types]
         self.reducer = None      # set by reed_amd.parallel.GradReducer
+        self._dot_delta = {}     # token count -> the dO GEMM of this shape has the head-dot epilogue (ops.dgrad_with_head_dots)
         self._ws = None
         self._named = None       # [(name, parameter)] and the first trainable parameter, cached for backward
         self._sentinel = None
@@ -375,6 +376,7 @@ class Engine:
         group_wgrad = ops.wgrad_group_fits([(D, Hm), (Hm, D), (D, D), (3 * D, D)])
         nws = ops.attention_bwd_ws_floats(B, T, H)       # delta = rowsum(dO * O) of the persistent attention backward
         attn_ws = f32(nws) if nws else None
+        dot_delta = self._dot_delta if os.environ.get("REED_ATTN_DP", "1") != "0" and hdt != torch.float32 else {M: False}
         side = None
         if self.wgrad_stream or (self.wgrad_stream is None and M <= self.wgrad_stream_max_tokens):
             if self._side is None:
@@ -508,9 +510,19 @@ class Engine:
             else:
                 self._wgrad(dy1, bk.o, b + "attn.proj.weight", M, D, D, acc, dev, side=side)
             do = bf(M, D)
-            self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
             dqkv = bf(M, 3 * D)
-            ops.attention_bwd(bk.qkv_a, bk.o, do, bk.lse, dqkv, B, T, H, hd, ws=attn_ws)
+            # delta = rowsum(dO * O) of the attention backward where dO is produced: the GEMM's epilogue 13 leaves per-row,
+            # per-head partial dot products with O (12 MB instead of a 302 MB row pass over dO and O at b = 256); where this
+            # shape's GEMM kernel has no such epilogue (False, decided once per token count) the plain store + the row kernel
+            fused = False
+            if dot_delta.get(M, True) and attn_ws is not None and T <= 256:
+                dpart = f32(M * H * (1 if hd == 64 else 2))
+                fused = dot_delta[M] = ops.dgrad_with_head_dots(dy1, self.W(b + "attn.proj.weight"), do, bk.o, dpart, M, D, D, hd)
+            if fused:
+                ops.attention_bwd_dp(bk.qkv_a, do, bk.lse, dpart, dqkv, attn_ws, B, T, H, hd)
+            else:
+                self._dgrad(EPI_BF16, dy1, b + "attn.proj.weight", M, D, D, do)
+                ops.attention_bwd(bk.qkv_a, bk.o, do, bk.lse, dqkv, B, T, H, hd, ws=attn_ws)
             if m.qk_norm:  # back through the per-head LayerNorm of q and k; parameter grads via per-block partials
                 nb = (M * 3 * H + 255) // 256
                 part = f32(nb, 4 * hd)

@@ -15,7 +15,7 @@ from . import _lib
 NT, NN, TN = 0, 1, 2
 TN_TALL, TN_WIDE = 3, 4   # TN on the 256x128 / 128x256 tile of csrc/gemm_tn.hip (weight gradients)
 (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32, EPI_QGELU,
- EPI_RES_BF16, EPI_GELU_ERF, EPI_LS_RES) = range(13)
+ EPI_RES_BF16, EPI_GELU_ERF, EPI_LS_RES, EPI_BF16_DOT) = range(14)
 
 
 def _p(t):
@@ -342,6 +342,23 @@ def attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd, ws=None):
         _call("reed_attention_bwd", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, T, H, hd, _stream())
     else:
         _call("reed_attention_bwd_ws", _p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), _p(ws), B, T, H, hd, _stream())
+
+
+def attention_bwd_dp(qkv, do, lse, dpart, dqkv, ws, B, T, H, hd):
+    """The persistent backward with delta from the partial dot products of gemm epilogue 13 (dpart f32 [H, 1|2, B*T])."""
+    _call("reed_attention_bwd_dp", _p(qkv), _p(do), _p(lse), _p(dpart), _p(dqkv), _p(ws), B, T, H, hd, _stream())
+
+
+def dgrad_with_head_dots(dy, w, dx, o, dpart, M, N, K, hd):
+    """dx bf16 [M, K] = dy [M, N] @ w [N, K] and dpart = per-row, per-head partial dot products of dx with o (epilogue 13).
+    False (nothing launched) where this shape's GEMM kernel has no such epilogue: store plainly instead."""
+    L = _lib.load(_PRECISION)
+    rc = L.reed_gemm(NN, EPI_BF16_DOT, _p(dy), N, _p(w), K, M, K, N, _p(dx), K, _p(dpart), 0, _p(o), K, None, None, 0, hd, None, 0, 1,
+                     0, _stream())
+    if rc == 1002:
+        return False
+    _lib.check(rc, "reed_gemm", L)
+    return True
 
 
 def attention_bwd_ws_floats(B, T, H):

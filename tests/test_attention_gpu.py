@@ -109,3 +109,55 @@ def test_attention_deterministic_and_forms_agree(dev):
     a, b = outs[0][2].float(), outs[2][2].float()
     assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
     assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.99999
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("b,H,hd,force", [(64, 16, 72, 258), (64, 6, 64, 0), (100, 16, 72, 0), (33, 12, 64, 257), (256, 16, 72, 0)])
+def test_delta_from_the_dgrad_epilogue(dev, prec, b, H, hd, force):
+    """reed_gemm epilogue 13 + reed_attention_bwd_dp (what the engine runs where the dO GEMM is on the four-wave 256^2 kernel):
+    dO = dY W stored exactly as epilogue 0 stores it, the partial dot products dO . O per row and head summing to the row kernel's
+    delta (fp32 rounding of another summation order), every slot written exactly once (NaN-filled before), and the attention
+    backward through them equal to the workspace form to bf16 resolution; twice -> identical bits.  hd 72: heads straddle the
+    64-column strips (two slots); hd 64: one strip per head; b = 100 / 33: a ragged last row tile, N = 768 a ragged column tile;
+    force 257 / 258: the one-shot / persistent form of the kernel where the heuristics would take another one; b = 256 is the
+    bench's shape."""
+    from reed_amd import ops
+    T, D = 256, H * hd
+    M = b * T
+    hdt = ops.half_dtype(prec)
+    g = torch.Generator().manual_seed(b + hd)
+    dy = (torch.randn(M, D, generator=g) * 0.5).to(hdt).to(dev)
+    w = (torch.randn(D, D, generator=g) / D ** 0.5).to(hdt).to(dev)
+    qkv = torch.randn(b, T, 3, H, hd, generator=g).to(hdt).to(dev)
+    prev = ops.use(prec)
+    ops.gemm_force_tile(force)
+    try:
+        o = torch.zeros(b, T, D, dtype=hdt, device=dev)
+        lse = torch.zeros(b, H, T, device=dev)
+        ops.attention_fwd(qkv, o, lse, b, T, H, hd)
+        do0 = torch.empty(M, D, dtype=hdt, device=dev)
+        ops.gemm(ops.NN, ops.EPI_BF16, dy, w, M, D, D, do0, D, D, D)
+        S = 1 if hd == 64 else 2
+        runs = []
+        for _ in range(2):
+            do1 = torch.full((M, D), float("nan"), dtype=hdt, device=dev)
+            dpart = torch.full((H, S, M), float("nan"), device=dev)
+            if not ops.dgrad_with_head_dots(dy, w, do1, o, dpart, M, D, D, hd):
+                pytest.skip("this shape's GEMM kernel has no head-dot epilogue")
+            dq = torch.full_like(qkv, float("nan"))
+            ws = torch.full((ops.attention_bwd_ws_floats(b, T, H),), float("nan"), device=dev)
+            ops.attention_bwd_dp(qkv, do1, lse, dpart, dq, ws, b, T, H, hd)
+            torch.cuda.synchronize()
+            runs.append((do1, dpart, dq))
+        do1, dpart, dq = runs[0]
+        assert all(torch.equal(x, y) for x, y in zip(runs[0], runs[1]))
+        assert torch.equal(do1, do0) and torch.isfinite(dpart).all()
+        want = (do0.double() * o.view(M, D).double()).view(M, H, hd).sum(-1)
+        torch.testing.assert_close(dpart.sum(1).T.double(), want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+        dq0 = torch.full_like(qkv, float("nan"))
+        ops.attention_bwd(qkv, o, do0, lse, dq0, b, T, H, hd, ws=torch.empty_like(ws))
+        a, r = dq.float(), dq0.float()
+        assert torch.isfinite(a).all() and (a - r).abs().max().item() <= 1e-2 * r.abs().max().item()
+    finally:
+        ops.gemm_force_tile(0)
+        ops.use(prev)

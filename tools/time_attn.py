@@ -35,7 +35,19 @@ for b in [int(a) for a in sys.argv[1:]] or [32, 256]:
     ws = None if os.environ.get("REED_ATTN_BWD") else torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
     tf = timeit(lambda: ops.attention_fwd(qkv, o, lse, b, T, H, hd))
     tb = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd, ws=ws))
+    # the form the engine runs where the dO GEMM is on the four-wave 256^2 kernel: delta from that GEMM's epilogue 13 (the GEMM
+    # with and without it is timed beside)
+    w = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
+    dy = torch.randn(M, D, device=dev).to(torch.bfloat16)
+    dpart = torch.empty(H, 2, M, device=dev)
+    line2 = ""
+    if ws is not None and ops.dgrad_with_head_dots(dy, w, do, o, dpart, M, D, D, hd):
+        tdp = timeit(lambda: ops.attention_bwd_dp(qkv, do, lse, dpart, dqkv, ws, b, T, H, hd))
+        tg1 = timeit(lambda: ops.dgrad_with_head_dots(dy, w, do, o, dpart, M, D, D, hd))
+        tg0 = timeit(lambda: ops.gemm(ops.NN, ops.EPI_BF16, dy, w, M, D, D, do, D, D, D))
+        line2 = (f" | bwd with delta from the dO GEMM {tdp*1e6:8.1f} us + {max(0.0, tg1 - tg0)*1e6:5.1f} us in that GEMM "
+                 f"({tg0*1e6:.1f} -> {tg1*1e6:.1f} us)")
     ff, fb = 4.0 * T * T * hd * b * H, 10.0 * T * T * hd * b * H
     bytes_f, bytes_b = M * D * 2 * 4, M * D * 2 * 8
     print(f"b={b:4d} fwd {tf*1e6:8.1f} us {ff/tf/1e12:7.1f} TFLOP/s {bytes_f/tf/1e12:5.2f} TB/s | "
-          f"bwd {tb*1e6:8.1f} us {fb/tb/1e12:7.1f} TFLOP/s {bytes_b/tb/1e12:5.2f} TB/s")
+          f"bwd {tb*1e6:8.1f} us {fb/tb/1e12:7.1f} TFLOP/s {bytes_b/tb/1e12:5.2f} TB/s" + line2)
