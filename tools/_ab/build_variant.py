@@ -18,7 +18,7 @@ srcs = B._sources()
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 with ThreadPoolExecutor(8) as ex:
-    res = list(ex.map(B._compile, [(s, False) for s in srcs]))
+    res = list(ex.map(B._compile, [(s, "", []) for s in srcs]))
 cmd = [B.HIPCC, "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", B.LIB] + [o for o, _ in res] + \
       ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-Bsymbolic"]
 subprocess.run(cmd, check=True)
