@@ -5,16 +5,23 @@
 //   C[M,N] (+)= sum_k P(m,k) * Q(n,k)        same three operand layouts and the same epilogue ids as csrc/gemm.hip
 //
 // Matrix instruction: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate; exact fp32 products, 64 cycles per SIMD = 1/16 of
-// the bf16 rate, MI355X_MICROARCH.md "Matrix cores").  At that rate the loop is MFMA-bound by a wide margin, so the kernel is
-// the plain form: tile 128x128x16, four waves of 64x64 (2x2 MFMA tiles, 64 accumulator registers), operands staged
-// global -> registers -> LDS k-major ([16][128+32] floats per operand: a fragment read is 2 rows x 32 consecutive floats,
-// the 32-float pad puts the two rows on disjoint bank halves), double buffered, one barrier per K step; every bound
+// the bf16 rate, MI355X_MICROARCH.md "Matrix cores").  The matrix pipe is slow enough that the loop can stay the plain form:
+// tile 128x128x16, four waves of 64x64 (2x2 MFMA tiles, 64 accumulator registers), two workgroups per CU, operands staged
+// global -> registers -> LDS k-major ([16][128+32] floats per operand: a fragment read is 2 rows x 32 consecutive floats, the
+// 32-float pad puts the two rows on disjoint bank halves), double buffered, one barrier per K step, XCD-contiguous tile map.
+// Measured (tools/_ab/time_gemm_f32.py): 81-112 TFLOP/s at M = 8192, 112-127 at M = 65536 (71-81 % of the 157 TFLOP/s fp32
+// MFMA peak).  (The geometry is a template on the wave grid: a 256x256 tile of SIXTEEN waves, one workgroup of 1024 threads
+// per CU, was built for its 64 flop per operand byte and measured 59-120 TFLOP/s — level at M = 65536, 20-40 % slower at
+// M = 8192 — so only the 2 x 2 grid is instantiated.)  Every bound
 // (ragged M, N, K; split-K ranges) is a guard on the staging loads and on the stores, so there are no shape restrictions
 // beyond 4-element alignment.  In this build `bf16` IS float (common.hpp): C, C2, R, bias and the gate are fp32 arrays and
 // every rounding point of the mixed-precision epilogues is the identity — one kernel per layout, the epilogue a run-time
 // switch.  This file is not part of the 16-bit builds (reed_amd/build.py).
 #include <stdlib.h>
 #include <string.h>
+
+#include <type_traits>
+#include <utility>
 
 #include "../../include/reed_hip.h"
 #include "gemm.h"
@@ -23,44 +30,73 @@
 #error "gemm_f32.hip belongs to the fp32-operand build (-DREED_FP32) only"
 #endif
 
+int reed_num_cus();
+
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 160;     // LDT: floats per k-row of an LDS tile (128 + 32 pad)
-constexpr int TILE_FLOATS = BK * LDT;
+constexpr int BK = 16;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-struct Stage {       // one K step of one operand in registers: two float4 per thread
-  f32x4 v[2];
+// Tile geometry for a W x W grid of 64x64 waves: BT rows / columns, NT threads, LDT floats per k-row of an LDS tile (BT + 32
+// pad), PP 16-byte pieces per thread, operand and K step.
+template <int W>
+struct Geo {
+  static constexpr int BT = 64 * W, NT = 64 * W * W, LDT = BT + 32, TILE_FLOATS = BK * LDT, PP = BT * 4 / NT;
 };
 
-// k-contiguous operand X[rows][K] (ld floats per row): tile rows r0.. x k [k0, k0+16).  Thread t: row t>>1, k-half (t&1)*8.
-__device__ __forceinline__ void load_row(Stage& s, const float* X, long ld, int r0, int rows, int k0, int kend, int t) {
-  const int r = r0 + (t >> 1), kq = k0 + (t & 1) * 8;
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int PP>
+struct Stage {       // one K step of one operand in registers: PP float4 per thread
+  f32x4 v[PP];
+};
+
+// k-contiguous operand X[rows][K] (ld floats per row): tile rows r0.. x k [k0, k0+16).  Piece p = t + i NT: row p>>2, k (p&3)*4.
+template <int W>
+__device__ __forceinline__ void load_row(Stage<Geo<W>::PP>& s, const float* X, long ld, int r0, int rows, int k0, int kend, int t) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int k = kq + 4 * i;
+  for (int i = 0; i < Geo<W>::PP; ++i) {
+    const int p = t + i * Geo<W>::NT;
+    const int r = r0 + (p >> 2), k = k0 + (p & 3) * 4;
     s.v[i] = (r < rows && k < kend) ? *(const f32x4*)(X + (long)r * ld + k) : f32x4{0.f, 0.f, 0.f, 0.f};   // K % 4 == 0
   }
 }
-__device__ __forceinline__ void store_row(const Stage& s, float* tile, int t) {
-  const int r = t >> 1, kq = (t & 1) * 8;
+template <int W>
+__device__ __forceinline__ void store_row(const Stage<Geo<W>::PP>& s, float* tile, int t) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < Geo<W>::PP; ++i) {
+    const int p = t + i * Geo<W>::NT;
+    const int r = p >> 2, kq = (p & 3) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tile[(kq + 4 * i + e) * LDT + r] = s.v[i][e];
+    for (int e = 0; e < 4; ++e) tile[(kq + e) * Geo<W>::LDT + r] = s.v[i][e];
+  }
 }
-// k-strided operand X[K][cols]: tile k [k0, k0+16) x cols c0..  Thread t: k-row (t>>5) + 8 i, columns (t&31)*4.
-__device__ __forceinline__ void load_tr(Stage& s, const float* X, long ld, int c0, int cols, int k0, int kend, int t) {
-  const int c = c0 + (t & 31) * 4;
+// k-strided operand X[K][cols]: tile k [k0, k0+16) x cols c0..  Piece p = t + i NT: k-row p / (BT/4), columns (p % (BT/4))*4.
+template <int W>
+__device__ __forceinline__ void load_tr(Stage<Geo<W>::PP>& s, const float* X, long ld, int c0, int cols, int k0, int kend, int t) {
+  constexpr int Q = Geo<W>::BT / 4;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int k = k0 + (t >> 5) + 8 * i;
+  for (int i = 0; i < Geo<W>::PP; ++i) {
+    const int p = t + i * Geo<W>::NT;
+    const int k = k0 + p / Q, c = c0 + (p % Q) * 4;
     s.v[i] = (k < kend && c < cols) ? *(const f32x4*)(X + (long)k * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};     // cols % 4 == 0
   }
 }
-__device__ __forceinline__ void store_tr(const Stage& s, float* tile, int t) {
+template <int W>
+__device__ __forceinline__ void store_tr(const Stage<Geo<W>::PP>& s, float* tile, int t) {
+  constexpr int Q = Geo<W>::BT / 4;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) *(f32x4*)(tile + ((t >> 5) + 8 * i) * LDT + (t & 31) * 4) = s.v[i];
+  for (int i = 0; i < Geo<W>::PP; ++i) {
+    const int p = t + i * Geo<W>::NT;
+    *(f32x4*)(tile + (p / Q) * Geo<W>::LDT + (p % Q) * 4) = s.v[i];
+  }
 }
 
 __device__ __forceinline__ float act_fwd(int epi, int variant, float x) {
@@ -69,32 +105,48 @@ __device__ __forceinline__ float act_fwd(int epi, int variant, float x) {
   return variant ? gelu_erf_f(x) : x * sigmoid_f(1.702f * x);   // EPI_QGELU
 }
 
-template <int LAY>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int epi) {
-  __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];   // [buffer][P | Q]
+template <int LAY, int W>
+__global__ __launch_bounds__(64 * W * W, W == 2 ? 2 : 1) void gemm_f32_kernel(GemmArgs a, int epi) {
+  constexpr int BM = Geo<W>::BT, BN = Geo<W>::BT, LDT = Geo<W>::LDT, TILE_FLOATS = Geo<W>::TILE_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float smem_f32[];        // [buffer][P | Q][TILE_FLOATS]
+  float (*smem)[2][TILE_FLOATS] = (float (*)[2][TILE_FLOATS])smem_f32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = (a.N + BN - 1) / BN;
-  const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+  const int wm = wave / W, wn = wave % W;
+  // block -> tile: XCD-contiguous runs (consecutive workgroup ids alternate over the 8 XCDs), grouped along M: the tiles an
+  // XCD works on at a time share operand panels in its L2
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int group = bid / per_group, first_m = group * GM;
+  const int gs = min(ntm - first_m, GM);
+  const int tm = first_m + (bid % per_group) % gs;
+  const int tn = (bid % per_group) / gs;
   const int z = blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = z * a.ksplit_len;
   const int kend = min(a.K, kbeg + a.ksplit_len);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
-  auto load = [&](int t, Stage& sp, Stage& sq) {
+  typedef Stage<Geo<W>::PP> stage_t;
+  auto load = [&](int t, stage_t& sp, stage_t& sq) {
     const int k0 = kbeg + t * BK;
-    if constexpr (LAY == LAY_TN) load_tr(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
-    else load_row(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
-    if constexpr (LAY == LAY_NT) load_row(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
-    else load_tr(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
+    if constexpr (LAY == LAY_TN) load_tr<W>(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
+    else load_row<W>(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
+    if constexpr (LAY == LAY_NT) load_row<W>(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
+    else load_tr<W>(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
   };
-  auto store = [&](int buf, const Stage& sp, const Stage& sq) {
-    if constexpr (LAY == LAY_TN) store_tr(sp, smem[buf][0], tid);
-    else store_row(sp, smem[buf][0], tid);
-    if constexpr (LAY == LAY_NT) store_row(sq, smem[buf][1], tid);
-    else store_tr(sq, smem[buf][1], tid);
+  auto store = [&](int buf, const stage_t& sp, const stage_t& sq) {
+    if constexpr (LAY == LAY_TN) store_tr<W>(sp, smem[buf][0], tid);
+    else store_row<W>(sp, smem[buf][0], tid);
+    if constexpr (LAY == LAY_NT) store_row<W>(sq, smem[buf][1], tid);
+    else store_tr<W>(sq, smem[buf][1], tid);
   };
 
   f32x16 acc[2][2];
@@ -109,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int epi) {
   const bool do_dbias = (LAY == LAY_TN) && a.dbias != nullptr && tn == 0;
   float bsum = 0.f;
 
-  Stage sp, sq;
+  stage_t sp, sq;
   if (nt > 0) {
     load(0, sp, sq);
     store(0, sp, sq);
@@ -148,42 +200,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int epi) {
   const float* Rf = (const float*)a.R;
   float* C = (float*)a.C;
   float* C2 = (float*)a.C2;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (n >= a.N) continue;
-      const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-        if (m >= a.M) continue;
-        const float v = acc[i][j][r] + bv;
-        switch (epi) {
-          case EPI_BF16: C[(long)m * a.ldc + n] = v; break;
-          case EPI_GELU: case EPI_SILU: case EPI_QGELU:
-            if (C) C[(long)m * a.ldc + n] = v;
-            C2[(long)m * a.ldc2 + n] = act_fwd(epi, a.act_variant, v);
-            break;
-          case EPI_GATE_RES: {
-            if (C2) C2[(long)m * a.ldc2 + n] = v;
-            const float g = a.gate[(long)(m / a.rows_per_gate) * a.ldgate + n];
-            C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + g * v;
-          } break;
-          case EPI_LS_RES: C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + a.gate[n] * v; break;
-          case EPI_DGELU: C[(long)m * a.ldc + n] = v * gelu_tanh_grad_f(Rf[(long)m * a.ldr + n]); break;
-          case EPI_DSILU: C[(long)m * a.ldc + n] = v * silu_grad_f(Rf[(long)m * a.ldr + n]); break;
-          case EPI_RES_BF16: C[(long)m * a.ldc + n] = v + Rf[(long)m * a.ldr + n]; break;
-          case EPI_F32: {
-            float* cp = C + (long)z * a.slab_stride + (long)m * a.ldc + n;
-            *cp = a.accumulate ? *cp + v : v;
-          } break;
-          case EPI_ADDF32_RB: C[(long)m * a.ldc + n] += v; break;
-          case EPI_ATOMIC_F32: atomicAdd(C + (long)m * a.ldc + n, v); break;
-        }
-      }
+  // (compile-time indices into the accumulators: with run-time ones — a loop the compiler does not fully unroll around the
+  //  epilogue switch — the 64 accumulator registers become a scratch array that is written back after EVERY K step: 16 KiB per
+  //  wave and step, four times the operand traffic; that was the first version of this kernel at 35-50 TFLOP/s)
+  auto elem = [&](auto I, auto J, auto Rr) {
+    constexpr int i = decltype(I)::value, j = decltype(J)::value, r = decltype(Rr)::value;
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    const int m = m0 + wm * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+    if (n >= a.N || m >= a.M) return;
+    const float v = acc[i][j][r] + (bias ? bias[n] : 0.f);
+    switch (epi) {
+      case EPI_BF16: C[(long)m * a.ldc + n] = v; break;
+      case EPI_GELU: case EPI_SILU: case EPI_QGELU:
+        if (C) C[(long)m * a.ldc + n] = v;
+        C2[(long)m * a.ldc2 + n] = act_fwd(epi, a.act_variant, v);
+        break;
+      case EPI_GATE_RES: {
+        if (C2) C2[(long)m * a.ldc2 + n] = v;
+        const float g = a.gate[(long)(m / a.rows_per_gate) * a.ldgate + n];
+        C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + g * v;
+      } break;
+      case EPI_LS_RES: C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + a.gate[n] * v; break;
+      case EPI_DGELU: C[(long)m * a.ldc + n] = v * gelu_tanh_grad_f(Rf[(long)m * a.ldr + n]); break;
+      case EPI_DSILU: C[(long)m * a.ldc + n] = v * silu_grad_f(Rf[(long)m * a.ldr + n]); break;
+      case EPI_RES_BF16: C[(long)m * a.ldc + n] = v + Rf[(long)m * a.ldr + n]; break;
+      case EPI_F32: {
+        float* cp = C + (long)z * a.slab_stride + (long)m * a.ldc + n;
+        *cp = a.accumulate ? *cp + v : v;
+      } break;
+      case EPI_ADDF32_RB: C[(long)m * a.ldc + n] += v; break;
+      case EPI_ATOMIC_F32: atomicAdd(C + (long)m * a.ldc + n, v); break;
     }
+  };
+  static_for<2>([&](auto I) { static_for<2>([&](auto J) { static_for<16>([&](auto Rr) { elem(I, J, Rr); }); }); });
   if (do_dbias && tid < BM) {
     const int m = m0 + tid;
     if (m < a.M) {
@@ -194,12 +243,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a, int epi) {
   }
 }
 
-template <int LAY>
-int launch(const GemmArgs& a, int epi, int splits, hipStream_t stream) {
-  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), splits, 1);
-  REED_KLAUNCH((gemm_f32_kernel<LAY>), grid, dim3(256), 0, stream, a, epi);
+template <int LAY, int W>
+int launch_w(const GemmArgs& a, int epi, int splits, hipStream_t stream) {
+  constexpr int lds = 2 * 2 * Geo<W>::TILE_FLOATS * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<LAY, W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { reed_set_error("gemm_f32: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, Geo<W>::BT) * cdiv(a.N, Geo<W>::BT), splits, 1);
+  REED_KLAUNCH((gemm_f32_kernel<LAY, W>), grid, dim3(Geo<W>::NT), lds, stream, a, epi);
   REED_LAUNCH_CHECK();
   return REED_OK;
+}
+
+template <int LAY>
+int launch(const GemmArgs& a, int epi, int splits, hipStream_t stream) {
+  return launch_w<LAY, 2>(a, epi, splits, stream);
 }
 
 }  // namespace
