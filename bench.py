@@ -40,11 +40,12 @@ def parse(argv=None):
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--model", type=str, default="SiT-XL/2")
     ap.add_argument("--z-dim", type=int, default=1024)
-    ap.add_argument("--mixed-precision", choices=["bf16", "fp16"], default="bf16",
+    ap.add_argument("--mixed-precision", choices=["bf16", "fp16", "fp32"], default="bf16",
                     help="operand type of the step (BASELINE's configuration is bf16; fp16 = the reference CLI's default, IEEE-half "
                          "operands with dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the C4 (text + image alignment) and C5 (sampler) legs the N = 1 run appends")
     ap.add_argument("--no-vae-leg", action="store_true", help="skip the SD-VAE decode leg (SURVEY.md N4) the N = 1 run appends")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the b = 32 per-GPU leg (the 8-GPU shape) the N = 1 run appends")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("REED_BENCH_LAUNCH_TIMEOUT", "2400")),
@@ -301,6 +302,67 @@ def c3_leg(step, dev, z_dim, b=32, steps=10, warmup=3):
             "note": "one GPU, no gradient all-reduce: the compute side of the 8-GPU run (b = 256 / 8 per GPU)"}
 
 
+def c4_leg(dev, b=32, steps=8, warmup=3):
+    """BASELINE configs[3] (C4) on this one GPU at its 8-GPU per-GPU shape: SiT-XL/2 with TWO alignment projectors — CLIP-ViT-L
+    image tokens (1024-d, tapped at block 8) and a pooled text embedding (768-d, tapped at block 10) — the REED loss with
+    coefficients 1.0 / 0.5 (image/train.py `--enc-type clip-vit-L --text-embeds-dir ... --repa-coeff 1.0 0.5
+    --encoder-depth-text 10`), local batch 32, no communication."""
+    import copy
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.optim import FusedAdamWEMA
+    from reed_amd.trainer import TrainStep
+    model = SiT_models["SiT-XL/2"](z_dims=[1024, 768], z_types=["i", "t"], encoder_depth=8, encoder_depth_text=10).to(dev).train()
+    random_fill(model, 4321)
+    ema = copy.deepcopy(model).requires_grad_(False).eval()
+    opt = FusedAdamWEMA(model, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
+    lf = SILoss(enc_names=["clip-vit-L", "text_embeds_open_clip"], loss_weights={"clip-vit-L": 1.0, "text_embeds_open_clip": 0.5})
+    step = TrainStep(model, lf, opt, None, proj_coeff=1.0, diffusion_warm_up_steps=0)
+    g = torch.Generator(device=dev).manual_seed(777)
+    mean = torch.randn(b, 4, 32, 32, device=dev, generator=g) * 5.49
+    moments = torch.cat([mean, torch.full_like(mean, 0.5)], dim=1)
+    labels = torch.randint(0, 1000, (b,), device=dev, generator=g)
+    zs = [torch.randn(b, 256, 1024, device=dev, generator=g), torch.randn(b, 768, device=dev, generator=g)]
+    for _ in range(warmup):
+        step(None, labels, zs, moments=moments)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step(None, labels, zs, moments=moments)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    opt.flush()
+    return {"local_batch": b, "steps": steps, "images_per_sec_per_gpu": round(b * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 3),
+            "final_loss": round(float(res["loss"]), 5), "text_proj_loss": round(float(torch.as_tensor(res["text_proj_loss"]).detach()), 5),
+            "note": "C4: image + text alignment (two projectors), one GPU at the per-GPU batch of the 8-GPU run, no all-reduce"}
+
+
+def c5_leg(dev, n=32, heun_steps=4):
+    """BASELINE configs[4] (C5): generate.py's sampling loop on this GPU — SiT-XL/2, Heun ODE sampler with classifier-free
+    guidance over the whole interval (every evaluation at batch 2n; image/samplers.py:46-104), fp16 operands (what
+    generate.py uses under the reference's default --tf32).  A short run (2 heun_steps - 1 evaluations) scaled to the 250-step
+    recipe's 499 evaluations: the cost of an evaluation does not depend on the step index (tools/bench_generate.py)."""
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.samplers import euler_sampler
+    model = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8, use_cfg=True).to(dev).eval()
+    random_fill(model, 1234)
+    model.precision = "fp16"
+    g = torch.Generator(device=dev).manual_seed(55)
+    z = torch.randn(n, 4, 32, 32, device=dev, generator=g)
+    y = torch.randint(0, 1000, (n,), device=dev, generator=g)
+    euler_sampler(model, z, y, num_steps=2, heun=True, cfg_scale=1.5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = euler_sampler(model, z, y, num_steps=heun_steps, heun=True, cfg_scale=1.5, guidance_low=0.0, guidance_high=1.0)
+    torch.cuda.synchronize()
+    per_eval = (time.perf_counter() - t0) / (2 * heun_steps - 1)
+    flop_eval = 237.23e9 * 2 * n
+    return {"n_per_gpu": n, "operands": "fp16", "ms_per_evaluation": round(per_eval * 1e3, 2),
+            "images_per_sec_per_gpu_250_heun_cfg": round(n / (499 * per_eval), 3),
+            "mfma_frac": round(flop_eval / per_eval / PEAK_BF16, 4), "finite": bool(torch.isfinite(out).all()),
+            "note": f"C5: {2 * heun_steps - 1} evaluations at batch {2 * n} timed, scaled to 499; ranks sample independent images, N GPUs give N times this"}
+
+
 def n4_vae_leg(dev, batch=8, reps=3):
     """SURVEY.md §8f N4 beside the headline: the SD-VAE decoder of generate.py / the previews (published sd-vae-ft configuration,
     random weights, 32x32 latents -> 256x256 images) on the HIP kernels, fp16 operands = what generate.py uses under the
@@ -489,7 +551,7 @@ def main():
         out = {
             "metric": "SiT-XL/2 ImageNet-256 train images/sec", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.mixed_precision == "bf16" else "f16",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.mixed_precision],
             "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)" +
                     (" — REHEARSAL: ranks share the visible GPUs, collectives over gloo; not a measurement" if REHEARSE else ""),
             "config": {"workload": f"C{'2' if world == 1 else '3'}: {args.model} + {args.z_dim}-d alignment projector (REED loss), "
@@ -543,6 +605,12 @@ def main():
                 out["c3_per_gpu_leg"] = c3_leg(step, dev, args.z_dim)
             except Exception as e:   # a reported leg, never a reason to lose the headline line
                 out["c3_per_gpu_leg"] = {"error": repr(e)}
+        if world == 1 and not args.no_config_legs and args.model == "SiT-XL/2":
+            for key, fn in (("c4_per_gpu_leg", c4_leg), ("c5_sampler_leg", c5_leg)):
+                try:
+                    out[key] = fn(dev)
+                except Exception as e:
+                    out[key] = {"error": repr(e)}
         if world == 1 and not args.no_vae_leg:
             try:
                 out["n4_vae_decode"] = n4_vae_leg(dev)
