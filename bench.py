@@ -484,7 +484,7 @@ def main():
     for _ in range(n_warm):
         res = step(None, labels, zs, moments=moments)
     barrier()
-    if rank == 0 and not args.no_kernel_table:
+    if rank == 0:
         ops.wgrad_group_probe = probe   # event pairs on the launch stream around every launch of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -563,10 +563,11 @@ def main():
             "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
             "data_parallel": dp,
         }
-        if not args.no_kernel_table:
-            # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region
-            rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm)
-            n_l = sum(len(v) for v in dom.values())
+        # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region (with or without the
+        # isolated kernel table, which only supplies the stand-in when the grouped launch did not run)
+        n_l = sum(len(v) for v in dom.values())
+        rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm) if not args.no_kernel_table else None
+        if n_l or rows is not None:
             if n_l:
                 tot_ms = sum(sum(v) for v in dom.values())
                 tot_fl = sum(fl * len(v) for fl, v in dom.items())
@@ -594,6 +595,7 @@ def main():
                               "path (the grouped launch was not used in this run), event-timed in ISOLATION after the timed region",
                     "launches_timed": 0, "avg_ms_per_launch": r["ms"],
                     "flop_per_launch": round(r["tflops"] * r["ms"] * 1e9)}
+        if rows is not None:
             tot = sum(r["ms"] for r in rows)
             agg = sum(r["tflops"] * r["ms"] for r in rows) / tot
             # the GEMM family launched in ISOLATION after the timed region (12 shapes of one block, time-weighted): an upper
