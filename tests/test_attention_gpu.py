@@ -112,17 +112,18 @@ def test_attention_deterministic_and_forms_agree(dev):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("b,H,hd,force", [(64, 16, 72, 258), (64, 6, 64, 0), (100, 16, 72, 0), (33, 12, 64, 257), (256, 16, 72, 0)])
-def test_delta_from_the_dgrad_epilogue(dev, prec, b, H, hd, force):
+@pytest.mark.parametrize("b,H,hd,force,T", [(64, 16, 72, 258, 256), (64, 6, 64, 0, 256), (100, 16, 72, 0, 256), (33, 12, 64, 257, 256),
+                                            (256, 16, 72, 0, 256), (128, 16, 72, 258, 128), (50, 12, 64, 257, 64)])
+def test_delta_from_the_dgrad_epilogue(dev, prec, b, H, hd, force, T):
     """reed_gemm epilogue 13 + reed_attention_bwd_dp (what the engine runs where the dO GEMM is on the four-wave 256^2 kernel):
     dO = dY W stored exactly as epilogue 0 stores it, the partial dot products dO . O per row and head summing to the row kernel's
     delta (fp32 rounding of another summation order), every slot written exactly once (NaN-filled before), and the attention
     backward through them equal to the workspace form to bf16 resolution; twice -> identical bits.  hd 72: heads straddle the
     64-column strips (two slots); hd 64: one strip per head; b = 100 / 33: a ragged last row tile, N = 768 a ragged column tile;
     force 257 / 258: the one-shot / persistent form of the kernel where the heuristics would take another one; b = 256 is the
-    bench's shape."""
+    bench's shape; T = 128 / 64: the tile form of the persistent kernel behind the same entry."""
     from reed_amd import ops
-    T, D = 256, H * hd
+    D = H * hd
     M = b * T
     hdt = ops.half_dtype(prec)
     g = torch.Generator().manual_seed(b + hd)
