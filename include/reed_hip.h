@@ -327,11 +327,12 @@ int reed_groupnorm_stats(const float* x, int B, int64_t hw, int C, int G, float 
  * attention's Linear layers.  C, kcols, ldo multiples of 4; fewer than 2^31 output positions. */
 int reed_conv_rows(const float* x, const float* table, int B, int Hi, int Wi, int C, int silu, int upsample, int taps,
                    int64_t row0, int64_t nrows, int kcols, void* out, int64_t ldo, void* stream);
-/* 3x3 convolution, padding 1, as an implicit GEMM on the 16-bit matrix cores (csrc/conv.hip; the fp32-operand build returns 1002:
- * use reed_conv_rows with taps = 9 + reed_gemm there): out f32 [B*Ho*Wo, ldc] (+)= conv(a) + bias, a (operand type) NHWC
+/* 3x3 convolution, padding 1, as an implicit GEMM (no im2col matrix: the kernel's row operand is gathered from the activation,
+ * zero outside the image; 16-bit builds: csrc/conv.hip on v_mfma_f32_16x16x32, LDS-DMA gather; fp32 build: csrc/gemm_f32.hip's
+ * kernel with the window gather in its staging loads): out f32 [B*Ho*Wo, ldc] (+)= conv(a) + bias, a (operand type) NHWC
  * [B, Hi, Wi, C] read through nearest x2 upsampling when `upsample` (Ho = Hi << upsample), w (operand type) [N, 9 C] in
  * (ky, kx, ci) order, bias f32 [N] or NULL; accumulate != 0 adds onto what `out` holds (the residual connection, in place).
- * C % 64 == 0, N % 128 == 0, B*Hi*Wi*C*2 bytes < 2 GiB. */
+ * 16-bit builds: C % 64 == 0, N % 128 == 0, B*Hi*Wi*C*2 bytes < 2 GiB; fp32 build: C % 4 == 0, N % 4 == 0. */
 int reed_conv3x3(const void* a, const void* w, const float* bias, float* out, int64_t ldc, int B, int Hi, int Wi, int C, int N,
                  int upsample, int accumulate, void* stream);
 /* p (operand type) [rows, ldp] = softmax over the first `cols` columns of scale * s f32 [rows, lds] */

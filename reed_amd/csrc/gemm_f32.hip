@@ -105,8 +105,15 @@ __device__ __forceinline__ float act_fwd(int epi, int variant, float x) {
   return variant ? gelu_erf_f(x) : x * sigmoid_f(1.702f * x);   // EPI_QGELU
 }
 
+// C > 0 (NT only): P is not a matrix but the 3x3 window gather of an NHWC activation a.P f32 [B, Hi, Wi, C] — row m = output pixel
+// (b, y, x) of the [B, Hi << up, Wi << up] grid, column k = tap * C + c = a(b, (y + tap / 3 - 1) >> up, (x + tap % 3 - 1) >> up, c),
+// zero outside the grid: the convolutions of the SD-VAE decoder (reed_conv3x3) without an im2col matrix.  C == 0: a plain GEMM.
+struct ConvGeo {
+  int C, Hi, Wi, up;
+};
+
 template <int LAY, int W>
-__global__ __launch_bounds__(64 * W * W, W == 2 ? 2 : 1) void gemm_f32_kernel(GemmArgs a, int epi) {
+__global__ __launch_bounds__(64 * W * W, W == 2 ? 2 : 1) void gemm_f32_kernel(GemmArgs a, int epi, ConvGeo cg) {
   constexpr int BM = Geo<W>::BT, BN = Geo<W>::BT, LDT = Geo<W>::LDT, TILE_FLOATS = Geo<W>::TILE_FLOATS;
   extern __shared__ __attribute__((aligned(16))) float smem_f32[];        // [buffer][P | Q][TILE_FLOATS]
   float (*smem)[2][TILE_FLOATS] = (float (*)[2][TILE_FLOATS])smem_f32;
@@ -135,10 +142,34 @@ __global__ __launch_bounds__(64 * W * W, W == 2 ? 2 : 1) void gemm_f32_kernel(Ge
   const int nt = (kend - kbeg + BK - 1) / BK;
 
   typedef Stage<Geo<W>::PP> stage_t;
+  // window gather: the output pixel of each of this thread's row pieces, decomposed once
+  int cy[Geo<W>::PP], cx[Geo<W>::PP], cb[Geo<W>::PP];
+  if (LAY == LAY_NT && cg.C > 0) {
+    const int Ho = cg.Hi << cg.up, Wo = cg.Wi << cg.up;
+#pragma unroll
+    for (int i = 0; i < Geo<W>::PP; ++i) {
+      const int m = m0 + ((tid + i * Geo<W>::NT) >> 2);
+      const int b = m / (Ho * Wo), rem = m - b * (Ho * Wo);
+      cy[i] = m < a.M ? rem / Wo : -4;          // a row beyond M: every tap lands outside
+      cx[i] = rem - (rem / Wo) * Wo;
+      cb[i] = b * cg.Hi * cg.Wi;
+    }
+  }
   auto load = [&](int t, stage_t& sp, stage_t& sq) {
     const int k0 = kbeg + t * BK;
     if constexpr (LAY == LAY_TN) load_tr<W>(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
-    else load_row<W>(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
+    else if (LAY == LAY_NT && cg.C > 0) {
+      const int Ho = cg.Hi << cg.up, Wo = cg.Wi << cg.up;
+#pragma unroll
+      for (int i = 0; i < Geo<W>::PP; ++i) {
+        const int k = k0 + ((tid + i * Geo<W>::NT) & 3) * 4;
+        const int tap = k / cg.C, c = k - tap * cg.C;
+        const int yy = cy[i] + tap / 3 - 1, xx = cx[i] + (tap - (tap / 3) * 3) - 1;
+        const bool in = k < kend && (unsigned)yy < (unsigned)Ho && (unsigned)xx < (unsigned)Wo;
+        sp.v[i] = in ? *(const f32x4*)(a.P + ((long)(cb[i] + (yy >> cg.up) * cg.Wi + (xx >> cg.up)) * cg.C + c))
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else load_row<W>(sp, a.P, a.ldp, m0, a.M, k0, kend, tid);
     if constexpr (LAY == LAY_NT) load_row<W>(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
     else load_tr<W>(sq, a.Q, a.ldq, n0, a.N, k0, kend, tid);
   };
@@ -244,7 +275,7 @@ __global__ __launch_bounds__(64 * W * W, W == 2 ? 2 : 1) void gemm_f32_kernel(Ge
 }
 
 template <int LAY, int W>
-int launch_w(const GemmArgs& a, int epi, int splits, hipStream_t stream) {
+int launch_w(const GemmArgs& a, int epi, int splits, hipStream_t stream, ConvGeo cg = ConvGeo{0, 0, 0, 0}) {
   constexpr int lds = 2 * 2 * Geo<W>::TILE_FLOATS * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -253,7 +284,7 @@ int launch_w(const GemmArgs& a, int epi, int splits, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, Geo<W>::BT) * cdiv(a.N, Geo<W>::BT), splits, 1);
-  REED_KLAUNCH((gemm_f32_kernel<LAY, W>), grid, dim3(Geo<W>::NT), lds, stream, a, epi);
+  REED_KLAUNCH((gemm_f32_kernel<LAY, W>), grid, dim3(Geo<W>::NT), lds, stream, a, epi, cg);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }
@@ -289,10 +320,33 @@ int reed_gemm_tn_group_launch(int, const GemmArgs*, hipStream_t) {
   return REED_ERR_UNSUPPORTED;
 }
 
-// The implicit-GEMM convolution is a 16-bit MFMA kernel (conv.hip); fp32 operands take reed_conv_rows (taps = 9) + reed_gemm.
-extern "C" int reed_conv3x3(const void*, const void*, const float*, float*, int64_t, int, int, int, int, int, int, int, void*) {
-  reed_set_error("reed_conv3x3: not built for fp32 operands (reed_conv_rows with taps = 9 + reed_gemm instead)");
-  return REED_ERR_UNSUPPORTED;
+// 3x3 convolution, padding 1, optional nearest x2 upsampling of the input, as an implicit GEMM on the fp32 MFMA kernel above (the
+// 16-bit builds have their own: conv.hip): out f32 [B*Ho*Wo, ldc] (+)= conv(a f32 NHWC [B, Hi, Wi, C]; w f32 [N, 9 C]) + bias.
+extern "C" int reed_conv3x3(const void* act, const void* w, const float* bias, float* out, int64_t ldc, int B, int Hi, int Wi, int C,
+                            int N, int upsample, int accumulate, void* stream) {
+  REED_CHECK_ARG(act && w && out && B > 0 && Hi > 0 && Wi > 0 && C > 0 && N > 0, "reed_conv3x3: empty problem");
+  REED_CHECK_ARG(upsample == 0 || upsample == 1, "reed_conv3x3: upsample must be 0 or 1 (nearest x2)");
+  REED_CHECK_ARG(C % 4 == 0 && N % 4 == 0 && ldc >= N, "reed_conv3x3(fp32): C=%d and N=%d must be multiples of 4, ldc >= N", C, N);
+  const long M = (long)B * (Hi << upsample) * (Wi << upsample);
+  REED_CHECK_ARG(M < (1l << 31) - 256 && (long)B * Hi * Wi < (1l << 31), "reed_conv3x3: too many positions for one call");
+  REED_CHECK_ARG(((uintptr_t)act % 16) == 0 && ((uintptr_t)w % 16) == 0 && (!bias || (uintptr_t)bias % 16 == 0),
+                 "reed_conv3x3: operands must be 16-byte aligned");
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = (const float*)act;
+  a.Q = (const float*)w;
+  a.ldp = 9 * C;
+  a.ldq = 9 * C;
+  a.M = (int)M;
+  a.N = N;
+  a.K = 9 * C;
+  a.C = out;
+  a.ldc = ldc;
+  a.bias = bias;
+  a.accumulate = accumulate;
+  a.rows_per_gate = 1;
+  a.ksplit_len = a.K;
+  return launch_w<LAY_NT, 2>(a, EPI_F32, 1, (hipStream_t)stream, ConvGeo{C, Hi, Wi, upsample});
 }
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream) {

@@ -215,8 +215,9 @@ class _HipDecode:
         assert out.shape == (B, Ho, Wo, npad) and out.is_contiguous()
         tb = self._table(x, norm) if norm is not None else None
         es = ops.half_dtype(prec).itemsize
-        if prec != "fp32" and taps == 9 and C % 64 == 0:
-            # 16-bit builds: the activation once in the operand type (norm + SiLU + rounding, 6 B / element), then the implicit GEMM
+        if taps == 9 and C % (4 if prec == "fp32" else 64) == 0:
+            # the activation once in the operand type (norm + SiLU + rounding: 6 B / element, 8 with fp32 operands), then the
+            # implicit GEMM (csrc/conv.hip; fp32 operands: csrc/gemm_f32.hip with the window gather in its staging loads)
             per = Hi * Wi * C * es
             bc = max(1, min(B, 0x7FFF0000 // per))
             act = self._workspace(bc * per, x.device)
