@@ -45,7 +45,7 @@ def parse(argv=None):
                          "operands with dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
-    ap.add_argument("--no-config-legs", action="store_true", help="skip the C4 (text + image alignment) and C5 (sampler) legs the N = 1 run appends")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the C4 (text + image alignment), C5 (sampler) and N2 (frozen encoder) legs the N = 1 run appends")
     ap.add_argument("--no-vae-leg", action="store_true", help="skip the SD-VAE decode leg (SURVEY.md N4) the N = 1 run appends")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the b = 32 per-GPU leg (the 8-GPU shape) the N = 1 run appends")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("REED_BENCH_LAUNCH_TIMEOUT", "2400")),
@@ -363,6 +363,41 @@ def c5_leg(dev, n=32, heun_steps=4):
             "note": f"C5: {2 * heun_steps - 1} evaluations at batch {2 * n} timed, scaled to 499; ranks sample independent images, N GPUs give N times this"}
 
 
+def n2_encoder_leg(dev, batch=64, reps=3):
+    """SURVEY.md §8f N2 beside the headline: the frozen target encoder the reference runs on the raw images every step
+    (image/train.py:351-357) — the CLIP ViT-L/14 tower of the C4 configuration, raw uint8 256x256 images -> preprocess_raw_image
+    -> 257 tokens x 24 blocks -> patch-token features, random weights, bf16 operands, at the per-GPU batch of a 4-GPU run."""
+    from reed_amd.encoders import CLIP_CONFIGS, ClipVisionEncoder
+    cfg = CLIP_CONFIGS["L"]
+    enc = ClipVisionEncoder(**cfg)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.ndim >= 2:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * (3.0 / p[0].numel()) ** 0.5)
+            elif "ln_" in n and n.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.05)
+    enc = enc.to(dev).eval()
+    raw = torch.randint(0, 256, (batch, 3, 256, 256), dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        out = enc.encode_raw(raw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = enc.encode_raw(raw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    W, L, T = cfg["width"], cfg["layers"], (cfg["image"] // cfg["patch"]) ** 2 + 1
+    flop = 2.0 * (L * (T * 12 * W * W + 2 * T * T * W) + (T - 1) * 3 * cfg["patch"] ** 2 * W)
+    return {"images_per_sec": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 2), "batch": batch, "operands": "bf16",
+            "gflop_per_image": round(flop / 1e9, 1), "mfma_frac": round(flop * batch / dt / PEAK_BF16, 4),
+            "finite": bool(torch.isfinite(out.float()).all()),
+            "note": "CLIP ViT-L/14 image tower (reed_amd/encoders.py) incl. the preprocessing pass; runs beside the train step when "
+                    "features are not precomputed"}
+
+
 def n4_vae_leg(dev, batch=8, reps=3):
     """SURVEY.md §8f N4 beside the headline: the SD-VAE decoder of generate.py / the previews (published sd-vae-ft configuration,
     random weights, 32x32 latents -> 256x256 images) on the HIP kernels, fp16 operands = what generate.py uses under the
@@ -608,7 +643,7 @@ def main():
             except Exception as e:   # a reported leg, never a reason to lose the headline line
                 out["c3_per_gpu_leg"] = {"error": repr(e)}
         if world == 1 and not args.no_config_legs and args.model == "SiT-XL/2":
-            for key, fn in (("c4_per_gpu_leg", c4_leg), ("c5_sampler_leg", c5_leg)):
+            for key, fn in (("c4_per_gpu_leg", c4_leg), ("c5_sampler_leg", c5_leg), ("n2_encoder_leg", n2_encoder_leg)):
                 try:
                     out[key] = fn(dev)
                 except Exception as e:
