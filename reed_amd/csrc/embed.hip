@@ -68,6 +68,56 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
   }
 }
 
+// The same with the roles turned: a thread keeps the weight rows of ITS four adjacent columns d = 4 tid .. 4 tid + 3 in registers
+// (K = 16 at patch 2: 64 floats) and walks PT tokens whose K inputs sit in LDS — 4 broadcast reads of 16 bytes, 64 FMAs, one
+// 16-byte load of the positional row and ONE 16-byte store per token, where the kernel above re-reads every input of its 8 tokens
+// from LDS for every column (128 ds_read_b32 per column) and stores 4 bytes per lane.  Same accumulation order over k:
+// bit-identical tokens.  320 threads (288 of them active for D = 1152).
+constexpr int PT = 64, PK = 16, PNT = 320;
+__global__ __launch_bounds__(PNT) void patch_embed_fwd16_kernel(const float* __restrict__ x, const bf16* __restrict__ w,
+                                                                const bf16* __restrict__ bias,
+                                                                const float* __restrict__ pos, float* __restrict__ tok,
+                                                                int B, int C, int HW, int P, int D) {
+  __shared__ __attribute__((aligned(16))) float xs[PT * PK];
+  const int G = HW / P, T = G * G;
+  const long bt0 = (long)blockIdx.x * PT, BT = (long)B * T;
+  for (int i = threadIdx.x; i < PT * PK; i += PNT) {
+    long bt = bt0 + i / PK;
+    xs[i] = bt < BT ? bfround(x[patch_src((int)(bt / T), (int)(bt % T), i % PK, C, HW, P, 0)]) : 0.f;
+  }
+  const int d0 = 4 * threadIdx.x;
+  const bool act = d0 < D;                       // D % 4 == 0
+  float wr[4][PK], bv[4];
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16x8 w0 = *(const bf16x8*)(w + (long)(d0 + e) * PK), w1 = *(const bf16x8*)(w + (long)(d0 + e) * PK + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { wr[e][j] = bf2f(w0[j]); wr[e][8 + j] = bf2f(w1[j]); }
+      bv[e] = bias ? bf2f(bias[d0 + e]) : 0.f;
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  for (int s_ = 0; s_ < PT; ++s_) {
+    const long bt = bt0 + s_;
+    if (bt >= BT) break;
+    f32x4 xv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xv[q] = *(const f32x4*)(xs + s_ * PK + 4 * q);
+    const f32x4 pv = *(const f32x4*)(pos + (bt % T) * (long)D + d0);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < PK; ++k) acc += wr[e][k] * xv[k >> 2][k & 3];
+      o[e] = bfround(acc + bv[e]) + pv[e];
+    }
+    *(f32x4*)(tok + bt * D + d0) = o;
+  }
+}
+
 // ---- small-K weight gradient (final layer: KS = 2*C*p*p = 32, patch embed: KS = C*p*p = 16 at patch 2), stage 1 ----
 // out[d][k] = sum_m wide[m][d] * small[m][k] over a token slice; ws[slice] holds the partial out (layout 0: d*KS+k,
 // 1: k*Dw+d), then the partial colsum(wide)[Dw], then the partial colsum(small)[KS].
@@ -277,6 +327,97 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict_
   }
 }
 
+// The same with the weight staged in LDS once per block of FR rows (a wave walks FR / 4 of them): the wave-per-row kernel above
+// re-reads the [NO, D] weight (36 KiB for XL/2) from L1 / L2 for EVERY row — 2.4 GB at b = 256, 0.67 ms for a pass whose HBM
+// traffic is 0.3 GB.  Same per-lane accumulation order and the same wave reduction: bit-identical outputs.
+constexpr int FR = 64;
+__global__ __launch_bounds__(256) void final_fwd_lds_kernel(const float* __restrict__ x, const bf16* __restrict__ shift,
+                                                            const bf16* __restrict__ scale, long ldmod,
+                                                            const bf16* __restrict__ w, const bf16* __restrict__ bias,
+                                                            float* __restrict__ out, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int B, int T, int D, int C, int P,
+                                                            float eps) {
+  extern __shared__ __attribute__((aligned(16))) char wl_raw[];
+  bf16* wl = (bf16*)wl_raw;                       // [NO][D]
+  const int NO = P * P * C, M = B * T;
+  for (int i = threadIdx.x * 8; i < NO * D; i += 256 * 8) *(bf16x8*)(wl + i) = *(const bf16x8*)(w + i);   // NO * D % 8 == 0
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
+  const int HW = (int)(sqrtf((float)T) + 0.5f) * P;
+  // two rows per wave and pass, every stage issued for both before either is consumed (a wave's row is a chain of dependent
+  // wave reductions; the second row fills its gaps); the arithmetic of a row is unchanged
+  for (int rr = 2 * wave; rr < FR; rr += 8) {
+    const int row0 = blockIdx.x * FR + rr;
+    if (row0 >= M) break;
+    const bool two = row0 + 1 < M;
+    f32x4 v[2][MAXV];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float* xr = x + (long)(row0 + (u && two ? 1 : 0)) * D;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        int idx = lane + 64 * k;
+        if (idx < nv) { v[u][k] = *(const f32x4*)(xr + idx * 4); s[u] += v[u][k][0] + v[u][k][1] + v[u][k][2] + v[u][k][3]; }
+      }
+    }
+    float mu[2], r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) mu[u] = wave_sum(s[u]) / D;
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        int idx = lane + 64 * k;
+        if (idx < nv) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { float d = v[u][k][j] - mu[u]; q[u] += d * d; }
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) r[u] = rsqrtf(wave_sum(q[u]) / D + eps);
+    int bb_[2], tt_[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = row0 + (u && two ? 1 : 0);
+      if (lane == 0 && mean && (u == 0 || two)) { mean[row] = mu[u]; rstd[row] = r[u]; }
+      bb_[u] = row / T;
+      tt_[u] = row - bb_[u] * T;
+      const bf16* sc = scale + (long)bb_[u] * ldmod;
+      const bf16* sh = shift + (long)bb_[u] * ldmod;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        int idx = lane + 64 * k;
+        if (idx < nv) {
+          f32x4 a = ld_bf4(sc + idx * 4), bb = ld_bf4(sh + idx * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[u][k][j] = bfround((v[u][k][j] - mu[u]) * r[u] * bfround(1.f + a[j]) + bb[j]);
+        }
+      }
+    }
+    for (int j = 0; j < NO; ++j) {
+      float acc[2] = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        int idx = lane + 64 * k;
+        if (idx < nv) {
+          f32x4 wv = ld_bf4(wl + j * D + idx * 4);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[u] += v[u][k][0] * wv[0] + v[u][k][1] * wv[1] + v[u][k][2] * wv[2] + v[u][k][3] * wv[3];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] = wave_sum(acc[u]);
+      if (lane == 0) {
+        const float bj = bias ? bf2f(bias[j]) : 0.f;
+        out[patch_src(bb_[0], tt_[0], j, C, HW, P, 1)] = bfround(acc[0] + bj);
+        if (two) out[patch_src(bb_[1], tt_[1], j, C, HW, P, 1)] = bfround(acc[1] + bj);
+      }
+    }
+  }
+}
+
 // ---- final layer backward, row part: h (bf16), dlin (bf16), dh (bf16) ----
 __global__ __launch_bounds__(256) void final_bwd_rows_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                              const float* __restrict__ mean,
@@ -329,7 +470,66 @@ __global__ __launch_bounds__(256) void final_bwd_rows_kernel(const float* __rest
   }
 }
 
+// The same with the weight in LDS per block of FR rows (see final_fwd_lds_kernel): bit-identical outputs.
+__global__ __launch_bounds__(256) void final_bwd_rows_lds_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const bf16* __restrict__ shift, const bf16* __restrict__ scale,
+                                                                 long ldmod, const bf16* __restrict__ w, bf16* __restrict__ hbuf,
+                                                                 bf16* __restrict__ dlin, bf16* __restrict__ dh, int B, int T,
+                                                                 int D, int C, int P) {
+  extern __shared__ __attribute__((aligned(16))) char lraw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nv = D >> 2;
+  const int M = B * T, NO = P * P * C, HW = (int)(sqrtf((float)T) + 0.5f) * P;
+  bf16* wl = (bf16*)lraw;                                   // [NO][D]
+  float* my = (float*)(lraw + (long)NO * D * sizeof(bf16)) + wave * NO;   // this wave's NO output gradients of its current row
+  for (int i = threadIdx.x * 8; i < NO * D; i += 256 * 8) *(bf16x8*)(wl + i) = *(const bf16x8*)(w + i);
+  __syncthreads();
+  for (int rr = wave; rr < FR; rr += 4) {
+    const int row = blockIdx.x * FR + rr;
+    if (row >= M) break;
+    const int b = row / T, t = row - b * T;
+    for (int j = lane; j < NO; j += 64) {
+      float g = bfround(dout[patch_src(b, t, j, C, HW, P, 1)]);
+      my[j] = g;
+      dlin[(long)row * NO + j] = f2bf(g);
+    }
+    __builtin_amdgcn_wave_barrier();           // `my` is this wave's own: LDS executes a wave's accesses in order
+    const float mu = mean[row], r = rstd[row];
+    const bf16* sc = scale + (long)b * ldmod;
+    const bf16* sh = shift + (long)b * ldmod;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      int idx = lane + 64 * k;
+      if (idx < nv) {
+        f32x4 xv = *(const f32x4*)(x + (long)row * D + idx * 4);
+        f32x4 a = ld_bf4(sc + idx * 4), bb = ld_bf4(sh + idx * 4);
+        bf16x4 hv, gv;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int j = 0; j < NO; ++j) {
+          f32x4 wv = ld_bf4(wl + j * D + idx * 4);
+          float g = my[j];
+          acc[0] += g * wv[0]; acc[1] += g * wv[1]; acc[2] += g * wv[2]; acc[3] += g * wv[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hv[j] = f2bf((xv[j] - mu) * r * bfround(1.f + a[j]) + bb[j]);
+          gv[j] = f2bf(acc[j]);
+        }
+        *(bf16x4*)(hbuf + (long)row * D + idx * 4) = hv;
+        *(bf16x4*)(dh + (long)row * D + idx * 4) = gv;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
+
+// REED_EMBED_OLD=1: the first forms of the patch-embed / final-layer forward (tests compare the two bit for bit; A/B timing)
+static bool embed_old_forms() {
+  const char* e = getenv("REED_EMBED_OLD");
+  return e && atoi(e) == 1;
+}
 
 extern "C" int reed_patchify_bf16(const float* x, void* out, int B, int C, int HW, int P, int order, void* stream) {
   REED_CHECK_ARG(HW % P == 0, "patchify: HW=%d not divisible by P=%d", HW, P);
@@ -344,6 +544,13 @@ extern "C" int reed_patch_embed_fwd(const float* x, const void* w, const void* b
   REED_CHECK_ARG(x && w && pos && tokens, "patch_embed_fwd: null pointer");
   REED_CHECK_ARG(HW % P == 0 && (C * P * P) % 8 == 0, "patch_embed: HW=%d P=%d C=%d unsupported", HW, P, C);
   const int T = (HW / P) * (HW / P), K = C * P * P;
+  if (K == PK && D % 4 == 0 && D <= 4 * PNT && ((uintptr_t)w % 16) == 0 && ((uintptr_t)pos % 16) == 0 &&
+      ((uintptr_t)tokens % 16) == 0 && !embed_old_forms()) {   // patch 2 on 4 channels (every SiT-*/2 preset)
+    REED_KLAUNCH(patch_embed_fwd16_kernel, dim3(cdiv((long)B * T, PT)), dim3(PNT), 0, (hipStream_t)stream, x, (const bf16*)w,
+                 (const bf16*)bias, pos, tokens, B, C, HW, P, D);
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
   REED_KLAUNCH(patch_embed_fwd_kernel, dim3(cdiv((long)B * T, 8)), dim3(256), 8 * K * sizeof(float),
                      (hipStream_t)stream, x, (const bf16*)w, (const bf16*)bias, pos, tokens, B, C, HW, P, D);
   REED_LAUNCH_CHECK();
@@ -411,6 +618,14 @@ extern "C" int reed_final_layer_fwd(const float* x, const void* shift, const voi
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
   int G = (int)(sqrtf((float)T) + 0.5f);
   REED_CHECK_ARG(G * G == T, "final_layer: T=%d is not a square grid", T);
+  const long wbytes = (long)P * P * C * D * sizeof(bf16);
+  if (wbytes <= 64 * 1024 && (P * P * C * D) % 8 == 0 && ((uintptr_t)w % 16) == 0 && !embed_old_forms()) {   // the weight fits a block's LDS
+    REED_KLAUNCH(final_fwd_lds_kernel, dim3(cdiv((long)B * T, FR)), dim3(256), (size_t)wbytes, (hipStream_t)stream, x,
+                 (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w, (const bf16*)bias, out, mean, rstd, B, T, D, C, P,
+                 eps);
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
   REED_KLAUNCH(final_fwd_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, x,
                      (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w, (const bf16*)bias, out, mean,
                      rstd, B, T, D, C, P, eps);
@@ -425,6 +640,14 @@ extern "C" int reed_final_layer_bwd_rows(const float* dout, const float* x, cons
   REED_CHECK_ARG(dout && x && mean && rstd && shift && scale && w && hbuf && dlin && dh, "final_layer_bwd_rows: null pointer");
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
   const int NO = P * P * C;
+  const long wb = (long)NO * D * sizeof(bf16);
+  if (wb + 4 * NO * (long)sizeof(float) <= 64 * 1024 && (NO * D) % 8 == 0 && ((uintptr_t)w % 16) == 0 && !embed_old_forms()) {
+    REED_KLAUNCH(final_bwd_rows_lds_kernel, dim3(cdiv((long)B * T, FR)), dim3(256), (size_t)(wb + 4 * NO * sizeof(float)),
+                 (hipStream_t)stream, dout, x, mean, rstd, (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w,
+                 (bf16*)hbuf, (bf16*)dlin, (bf16*)dh, B, T, D, C, P);
+    REED_LAUNCH_CHECK();
+    return REED_OK;
+  }
   REED_KLAUNCH(final_bwd_rows_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 4 * NO * sizeof(float),
                      (hipStream_t)stream, dout, x, mean, rstd, (const bf16*)shift, (const bf16*)scale, (long)ldmod,
                      (const bf16*)w, (bf16*)hbuf, (bf16*)dlin, (bf16*)dh, B, T, D, C, P);

@@ -516,3 +516,40 @@ def test_fp16_library_gemm_and_attention(dev):
     assert torch.equal(outs[256][0], outs[257][0]) and torch.equal(outs[256][1], outs[257][1])
     assert torch.equal(outs[258][0], outs[257][0]) and torch.equal(outs[258][1], outs[257][1])   # persistent form
     torch.testing.assert_close(outs[144][0].float(), outs[257][0].float(), atol=4e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("B,D", [(40, 1152), (3, 384), (7, 1024)])
+def test_embed_and_final_layer_second_forms_bit_identical(dev, monkeypatch, B, D):
+    """The patch-embed forward with the weight rows in registers (16-byte stores) and the final-layer forward / backward rows with
+    the weight staged in LDS per 64 rows (csrc/embed.hip) against the first forms (REED_EMBED_OLD=1): the same per-lane accumulation
+    order and the same wave reductions, so every output is bit-identical; B * 256 rows not a multiple of 64 (40, 3, 7 images)."""
+    from reed_amd import ops
+    C, HW, P, T = 4, 32, 2, 256
+    g = torch.Generator().manual_seed(B + D)
+    x = torch.randn(B, C, HW, HW, generator=g).to(dev)
+    w = (torch.randn(D, 16, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    bias = torch.randn(D, generator=g).to(torch.bfloat16).to(dev)
+    pos = torch.randn(T, D, generator=g).to(dev)
+    xt = torch.randn(B * T, D, generator=g).to(dev)
+    mod = torch.randn(B, 2 * D, generator=g).to(torch.bfloat16).to(dev)
+    wf = (torch.randn(16, D, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    bf = torch.randn(16, generator=g).to(torch.bfloat16).to(dev)
+    dout = torch.randn(B, C, HW, HW, generator=g).to(dev)
+
+    def run():
+        tok = torch.full((B * T, D), float("nan"), device=dev)
+        out = torch.full((B, C, HW, HW), float("nan"), device=dev)
+        mean, rstd = torch.empty(B * T, device=dev), torch.empty(B * T, device=dev)
+        hbuf = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device=dev)
+        dh, dlin = torch.full_like(hbuf, float("nan")), torch.full((B * T, 16), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.patch_embed_fwd(x, w, bias, pos, tok, B, C, HW, P, D)
+        ops.final_layer_fwd(xt, mod.data_ptr(), mod.data_ptr() + 2 * D, 2 * D, wf, bf, out, mean, rstd, B, T, D, C, P)
+        ops.final_layer_bwd_rows(dout, xt, mean, rstd, mod.data_ptr(), mod.data_ptr() + 2 * D, 2 * D, wf, hbuf, dlin, dh, B, T, D, C, P)
+        torch.cuda.synchronize()
+        return tok, out, mean, rstd, hbuf, dh, dlin
+
+    new = run()
+    monkeypatch.setenv("REED_EMBED_OLD", "1")
+    old = run()
+    for a, b in zip(new, old):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
