@@ -4,14 +4,14 @@ from reed_amd import ops
 dev = torch.device("cuda:0")
 ops.use("fp32")
 for lay, name in ((ops.NT, "NT"), (ops.NN, "NN"), (ops.TN, "TN")):
-    for M, N, K in ((65536, 4608, 1152), (65536, 1152, 4608), (32768, 3456, 1152)):
+    for M, N, K in ((8192, 4608, 1152), (8192, 1152, 4608), (65536, 4608, 1152), (65536, 1152, 4608), (65536, 128, 1152)):
         P = torch.randn(M if lay != ops.TN else K, K if lay != ops.TN else M, device=dev)
         Q = torch.randn(N if lay == ops.NT else K, K if lay == ops.NT else N, device=dev)
         C = torch.empty(M, N, device=dev)
         ldp = P.shape[1]; ldq = Q.shape[1]
         f = lambda: ops.gemm(lay, ops.EPI_F32, P, Q, M, N, K, C, ldp, ldq, N)
         out = []
-        for force in (128, 256, 0):
+        for force in (0,):
             ops.gemm_force_tile(force)
             f(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
