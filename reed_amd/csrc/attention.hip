@@ -610,6 +610,390 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(const bf16* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4: the T <= 256 forward with every operand at least one phase further ahead (attn_fwd256p_kernel; the engine's form).
+//
+// attn_fwd256_kernel above meets at three barriers per item and can only ask for K(n+1), Q(n+1) once every wave is past
+// S(n), and for V(n+1) once every wave is past PV(n): each tile has less than one item's time to arrive, the waves wait
+// for it at the next barrier, and the per-CU vector-memory path (the kernel's floor: 180 KiB per item at ~10 B/clk) idles
+// whenever a compute phase runs long.  Its instruction stream also carried a third of dead weight (ISA census, hd 72:
+// 84 v_mov_b64 zeroing accumulators, 90 v_perm_b32 re-packing the 16-bit elements of every inline-asm transposed read, 132
+// v_cndmask + 65 v_cmp of the ragged-key masks and ~90 scalar spill moves around the T-dependent branches, 128 v_add of
+// the row sums: ~1200 vector instructions per wave and item for 176 MFMAs).  Here:
+//   * LDS = K x 2 | V | Q: the K tile is double-buffered, K(n+2) is issued when every wave is past softmax(n) and is
+//     first read 1.7 items later;
+//   * Q is per wave: a wave DMAs its own 32 query rows into its own 5 KiB patch and reads them back itself (no barrier
+//     for Q at all); Q(n+1) is issued as soon as Q(n)'s fragments are in registers, a whole item ahead;
+//   * the output staging patch is the wave's own 32 rows of the V tile (dead after the barrier that ends PV), and a
+//     wave's five V pieces are exactly those rows: V(n+1) is issued by each wave right after its own read-back, in FRONT
+//     of its output stores, and is first read after S(n+1) AND softmax(n+1) (the V wait moved behind the softmax);
+//   * two barriers per item (V landed + all past S; all past PV + K(n+1) landed) instead of three;
+//   * T == 256 (FULL) is a separate instantiation without masks or T-dependent branches; the first MFMA of every
+//     accumulator takes C = 0; the transposed reads return 32-bit pairs (no v_perm); for hd 72 the row sums come out of
+//     the PV product itself: column 72 of the V tile (pad of the fifth 16-column output tile) is set to 1.0 by the wave
+//     that owns the rows, so O^T row 72 = sum_k P[q][k] — the sum of the SAME bf16-rounded P the output is built from.
+// Every vector-memory instruction is issued unconditionally (items past the end use an empty buffer descriptor: the
+// range check turns them into zero fills and dropped stores), so every wait is one counted s_waitcnt vmcnt(N) with the
+// same N for every wave and item.  Issue order per wave and item n, [count]:
+//   start: Q(n+1)[5] | after softmax + barrier: K(n+2)[5] | end: V(n+1)[5], O rows + lse [5 + 2]
+//   Q(n) landed  <=> at most K(n+1) 5 + V(n) 5 + stores(n-1) 7 = 17 younger
+//   V(n) landed  <=> at most stores(n-1) 7 + Q(n+1) 5 = 12 younger
+//   K(n+1) landed <=> at most V(n) 5 + stores(n-1) 7 + Q(n+1) 5 + K(n+2) 5 = 22 younger
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 tr16_u(unsigned a) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF));
+  return r;
+}
+template <int RB, int OFF>
+__device__ __forceinline__ bf16x8 frag_trT_u(unsigned lane_base) {
+  const u32x2 lo = tr16_u<OFF>(lane_base), hi = tr16_u<OFF + 16 * RB>(lane_base);
+  const u32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 lds_read128_asm(unsigned a) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a) : "memory");
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(size_t)(const char __attribute__((address_space(3)))*)p;
+}
+template <int RB, int S, int NDT, int... DTS>
+__device__ __forceinline__ void pvu_load(unsigned vb, bf16x8 (&vf)[NDT], std::integer_sequence<int, DTS...>) {
+  ((vf[DTS] = frag_trT_u<RB, S * 32 * RB + DTS * 32>(vb)), ...);
+}
+// one 32-key step of O^T += V^T P^T: the V^T fragments of step S + 1 are read before the MFMAs of step S issue
+template <int RB, int S, int NS, int NDT, int... DTS>
+__device__ __forceinline__ void pvu_step(unsigned vb, const bf16x8 (&pb)[2][8], f32x4 (&ot)[2][NDT], bf16x8 (&cur)[NDT],
+                                         bf16x8 (&nxt)[NDT], std::integer_sequence<int, DTS...> seq) {
+  if constexpr (S < NS) {
+    if constexpr (S + 1 < NS) pvu_load<RB, S + 1, NDT>(vb, nxt, seq);
+    if constexpr (S == 0)
+      ((ot[0][DTS] = MFMA(cur[DTS], pb[0][S], zero4()), ot[1][DTS] = MFMA(cur[DTS], pb[1][S], zero4())), ...);
+    else
+      ((ot[0][DTS] = MFMA(cur[DTS], pb[0][S], ot[0][DTS]), ot[1][DTS] = MFMA(cur[DTS], pb[1][S], ot[1][DTS])), ...);
+    ATTN_LDS_WAIT();
+  }
+}
+template <int RB, int NS, int NDT>
+__device__ __forceinline__ void pvu_all(unsigned vb, const bf16x8 (&pb)[2][8], f32x4 (&ot)[2][NDT]) {
+  constexpr auto seq = std::make_integer_sequence<int, NDT>{};
+  bf16x8 va[NDT], vb2[NDT];
+  pvu_load<RB, 0, NDT>(vb, va, seq);
+  ATTN_LDS_WAIT();
+  pvu_step<RB, 0, NS, NDT>(vb, pb, ot, va, vb2, seq);
+  pvu_step<RB, 1, NS, NDT>(vb, pb, ot, vb2, va, seq);
+  pvu_step<RB, 2, NS, NDT>(vb, pb, ot, va, vb2, seq);
+  pvu_step<RB, 3, NS, NDT>(vb, pb, ot, vb2, va, seq);
+  pvu_step<RB, 4, NS, NDT>(vb, pb, ot, va, vb2, seq);
+  pvu_step<RB, 5, NS, NDT>(vb, pb, ot, vb2, va, seq);
+  pvu_step<RB, 6, NS, NDT>(vb, pb, ot, va, vb2, seq);
+  pvu_step<RB, 7, NS, NDT>(vb, pb, ot, vb2, va, seq);
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128_off(unsigned a) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF));
+  return __builtin_bit_cast(bf16x8, r);
+}
+// S^T = K Q^T one 16-key tile at a time, software pipelined like the PV product: the K row fragments of tile KT + 1 are read
+// (asm: unordered by the compiler, no wait of its own) before the MFMAs of tile KT issue, and waited for behind them.
+// ka = tile + i * RB + 16 g (lane base), kaw = the same with lanes g >= 2 moved back two chunks (the k-step that covers columns
+// 64..95 of a 72- / 80-wide head: columns 80..95 do not exist, those lanes re-read 64..79; their Q slots are zero)
+template <int HD, int RB, int KT>
+__device__ __forceinline__ void sk_load(unsigned ka, unsigned kaw, bf16x8 (&kf)[Cfg<HD>::KS]) {
+  constexpr int KS = Cfg<HD>::KS;
+  kf[0] = lds_read128_off<KT * 16 * RB>(ka);
+  kf[1] = lds_read128_off<KT * 16 * RB + 64>(ka);
+  if constexpr (KS == 3) kf[2] = lds_read128_off<KT * 16 * RB + 128>(HD % 32 != 0 ? kaw : ka);
+}
+template <int HD, int RB, int KT, int NKT>
+__device__ __forceinline__ void sk_step(unsigned ka, unsigned kaw, const bf16x8 (&qf)[2][Cfg<HD>::KS], f32x4 (&st)[2][16],
+                                        bf16x8 (&cur)[Cfg<HD>::KS], bf16x8 (&nxt)[Cfg<HD>::KS]) {
+  constexpr int KS = Cfg<HD>::KS;
+  if constexpr (KT < NKT) {
+    if constexpr (KT + 1 < NKT) sk_load<HD, RB, KT + 1>(ka, kaw, nxt);
+    st[0][KT] = MFMA(cur[0], qf[0][0], zero4());
+    st[1][KT] = MFMA(cur[0], qf[1][0], zero4());
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) {
+      st[0][KT] = MFMA(cur[ks], qf[0][ks], st[0][KT]);
+      st[1][KT] = MFMA(cur[ks], qf[1][ks], st[1][KT]);
+    }
+    ATTN_LDS_WAIT();
+  }
+}
+template <int HD, int RB>
+__device__ __forceinline__ void sk_all(unsigned ka, unsigned kaw, const bf16x8 (&qf)[2][Cfg<HD>::KS], f32x4 (&st)[2][16]) {
+  bf16x8 fa[Cfg<HD>::KS], fb[Cfg<HD>::KS];
+  sk_load<HD, RB, 0>(ka, kaw, fa);
+  ATTN_LDS_WAIT();
+  sk_step<HD, RB, 0, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 1, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 2, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 3, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 4, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 5, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 6, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 7, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 8, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 9, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 10, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 11, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 12, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 13, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 14, 16>(ka, kaw, qf, st, fa, fb);
+  sk_step<HD, RB, 15, 16>(ka, kaw, qf, st, fb, fa);
+}
+// two floats -> one dword of two 16-bit operands (v_cvt_pk_bf16_f32 / v_cvt_pkrtz... of the build's operand type)
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// DBGK: a diagnosis instantiation that takes `dbg` (bit 0: no S products, 1: no exponentials, 2: no PV products, 3: the output
+// stores dropped by the range check, 4: every tile load an empty descriptor); the product instantiations ignore it
+template <int HD, bool FULL, bool DBGK>
+__global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                             float* __restrict__ lse, int T, int H, int nitems, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  constexpr bool ONES = (HD == 72);   // d = 72..79 is the zero pad of the fifth output tile: column 72 carries the row sums
+  if (!DBGK) dbg = 0;
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const long tok = 3l * D;
+  const int tokb = (int)(tok * 2);
+  char* Kb = smem;                                     // two K tiles
+  char* Vt = smem + 2 * TILE_F;
+  char* Vw = Vt + wave * 32 * ROWF;                    // this wave's rows of the V tile = its five DMA pieces = its output patch
+  char* Qw = smem + 3 * TILE_F + wave * 32 * ROWF;     // this wave's 32 query rows
+  const int q0 = wave * 32;
+  const float sc2 = rsqrtf((float)HD) * LOG2E;
+  int voff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) voff[j] = dma_voff<HD, ROWF>((wave * 5 + j) * 64 + lane0, tokb);
+  const long win = (DBGK && (dbg & 16)) ? 0 : tile_window<HD>(T, tokb);
+  // the wave's five pieces (its 32 rows) of a tile whose row 0 is `base`; base == nullptr: an empty descriptor (zero fill)
+  auto issue = [&](char* wave_rows, const bf16* base) {
+    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(base, win);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wave_rows + j * 1024), 16, voff[j], 0, 0, 0);
+  };
+  auto base_of = [&](int item) -> const bf16* {
+    if (item >= nitems) return nullptr;
+    const int b = item / H, h = item - b * H;
+    return qkv + (long)b * T * tok + h * HD;
+  };
+  auto plus = [](const bf16* p, long n) -> const bf16* { return p ? p + n : nullptr; };
+  const int G = gridDim.x;
+  int it = xcd_contiguous(blockIdx.x, G);   // the 16 heads of a sample run on one XCD at about the same time
+  {
+    const bf16* b0 = base_of(it);
+    issue(Qw, b0);
+    issue(Kb + wave * 32 * ROWF, plus(b0, D));
+    issue(Kb + TILE_F + wave * 32 * ROWF, plus(base_of(it + G), D));
+    issue(Vw, plus(b0, 2 * D));
+    const __amdgpu_buffer_rsrc_t none = mk_rsrc(nullptr, 0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, none, DMA_OOB, 0, 0);   // "stores(-1)": the counts below hold from item 0
+    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // Q, K of the first item (younger: K of the second, V, the 7 stores)
+    ATTN_BARRIER();
+  }
+  constexpr int NS = 8;
+  const int nsub = FULL ? 4 : (T + 63) >> 6;
+  int par = 0;
+  for (; it < nitems; it += G, par ^= 1) {
+    const int b = it / H, h = it - b * H;
+    // lane-derived values are re-derived per item from an opaque copy of the lane id (hoisted, they are spilled around the
+    // loop and the reload's compiler-made vmcnt(0) drains the DMA queue)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+    const char* Kt = Kb + par * TILE_F;
+    // ---------------- Q(n): own patch, own wait ----------------
+    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 qf[2][KS];
+    {
+      const unsigned qa = lds_addr(Qw + i * ROWF + 16 * g);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          // columns 64..95 of a 72-wide head: 64..79 exist (72..79 = zero pad); lanes g >= 2 re-read them and are zeroed
+          const bool wrap = HD % 32 != 0 && ks == KS - 1;
+          const unsigned a = qa + qt * 16 * ROWF + ks * 64 - ((wrap && g >= 2) ? 32 : 0);
+          qf[qt][ks] = lds_read128_asm(a);
+        }
+      ATTN_LDS_WAIT();
+      if (HD % 32 != 0 && g >= 2) { qf[0][KS - 1] = zero_frag(); qf[1][KS - 1] = zero_frag(); }
+    }
+    issue(Qw, base_of(it + G));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- S^T = K Q^T (K(n) landed: the barrier that ended item n-1) ----------------
+    f32x4 st[2][16];
+    if (DBGK && (dbg & 1)) {
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) st[0][kt] = st[1][kt] = zero4();
+    } else if (FULL) {
+      const unsigned ka = lds_addr(Kt + i * ROWF + 16 * g);
+      sk_all<HD, ROWF>(ka, ka - (g >= 2 ? 32 : 0), qf, st);
+    } else {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        if (sub < nsub) {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int kt = sub * 4 + k4;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              const bf16x8 kf = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Kt, 16 * kt, ks, lane)
+                                                               : frag_rows_f<false>(Kt, 16 * kt, ks, lane);
+              if (ks == 0) {
+                st[0][kt] = MFMA(kf, qf[0][ks], zero4());
+                st[1][kt] = MFMA(kf, qf[1][ks], zero4());
+              } else {
+                st[0][kt] = MFMA(kf, qf[0][ks], st[0][kt]);
+                st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) st[0][sub * 4 + k4] = st[1][sub * 4 + k4] = zero4();
+        }
+      }
+    }
+    // ---------------- softmax over the keys, in registers ----------------
+    if (!FULL) {
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        if (64 * sub + 64 > T) {   // keys past T: a ragged or absent sub-block (wave-uniform)
+          int gg = g;
+          asm volatile("" : "+v"(gg));   // per-item value: keeps the 64 lane masks from being hoisted out of the item loop
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (64 * sub + 16 * k4 + 4 * gg + r >= T) st[qt][sub * 4 + k4][r] = -INFINITY;
+        }
+      }
+    }
+    float mrow[2], lrow[2];
+    bf16x8 pb[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mneg = mx * sc2;   // the scale is positive: max of the scaled scores
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_fmaf(st[qt][kt][r], sc2, -mneg);
+          if (!(DBGK && (dbg & 2))) p = __builtin_amdgcn_exp2f(p);
+          st[qt][kt][r] = p;
+          if (!ONES) sum += p;
+        }
+        if (kt & 1) pb[qt][kt >> 1] = pack2(st[qt][kt - 1], st[qt][kt]);
+      }
+      if (!ONES) {
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+      }
+      mrow[qt] = mneg;
+      lrow[qt] = sum;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- V(n) landed; every wave is past S(n): K(n+2) may overwrite K(n) ----------------
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (ONES && lane < 32) *(bf16*)(Vw + lane * ROWF + HD * 2) = (bf16)1.0f;   // own rows, behind own pieces: the ones column
+    ATTN_BARRIER();
+    issue(Kb + par * TILE_F + wave * 32 * ROWF, plus(base_of(it + 2 * G), D));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- O^T = V^T P^T ----------------
+    f32x4 ot[2][DT];
+    {
+      const unsigned vb = lds_addr(Vt + (4 * g + (i >> 2)) * ROWF + (i & 3) * 8);
+      if (DBGK && (dbg & 4)) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ot[0][dt] = ot[1][dt] = f32x4{1.f, 1.f, 1.f, 1.f};
+      } else if (FULL) {
+        pvu_all<ROWF, NS, DT>(vb, pb, ot);
+      } else {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) ot[qt][dt] = zero4();
+        pv_all<ROWF, DT>(Vt + (4 * g + (i >> 2)) * ROWF + (i & 3) * 8, (T + 31) >> 5, pb, ot);
+      }
+    }
+    // K(n+1) landed (this wave's pieces); after the barrier: every wave's, and every wave is past its V reads
+    asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    ATTN_BARRIER();
+    // ---------------- output: staged in the wave's own rows of the V tile, whole 144-byte row pieces out ----------------
+    float lsev[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float l = lrow[qt];
+      if (ONES) l = __shfl(ot[qt][DT - 1][0], 32 + i, 64);   // O^T row 72 (lanes g = 2, element 0) = sum_k P[q][k]
+      const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        const u32x2 v = {pk2(ot[qt][dt][0] * inv, ot[qt][dt][1] * inv), pk2(ot[qt][dt][2] * inv, ot[qt][dt][3] * inv)};
+        if (16 * dt + 16 <= HD || d < HD) *(u32x2*)(Vw + (16 * qt + i) * ROWF + d * 2) = v;   // (only hd 72's fifth tile is partial)
+      }
+      lsev[qt] = mrow[qt] * LN2 + __logf(l);
+    }
+    {
+      // exactly 5 + 2 buffer stores per wave and item (counted by the waits above); rows >= T and the lanes past the
+      // 32 x NCH chunks fall outside the descriptors and are dropped by the range check
+      const bool drop = DBGK && (dbg & 8);
+      const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(drop ? nullptr : o + (long)b * T * D + h * HD, tile_window<HD>(T, D * 2));
+      const __amdgpu_buffer_rsrc_t rsL = mk_rsrc((lse && !drop) ? lse + ((long)b * H + h) * T : nullptr, (long)T * 4);
+      constexpr int NQ = 32 * NCH;
+      u32x4 piece[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int qi = min(lane + 64 * k, NQ - 1);
+        const int rr = qi / NCH, c = qi - rr * NCH;
+        piece[k] = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vw + rr * ROWF + c * 16)));
+      }
+      ATTN_LDS_WAIT();
+      issue(Vw, plus(base_of(it + G), 2 * D));   // V(n+1) into the rows just read back, in front of the stores
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int qi = lane + 64 * k;
+        const int rr = qi / NCH, c = qi - rr * NCH;
+        __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsO, qi < NQ ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
+                                              g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills of the items past the end: LDS stays allocated until they land
+}
+
+// ------------------------------------------------------------------------------------------
 // Backward, T <= 256: one workgroup per (batch, head), Q, K, V, dO resident (4 x 36 KiB), every operand read from HBM once.
 // Three other forms were built in round 2, passed every test and lost on the same box (attention;
 // profiles/r2_pmc_attention.txt): (a) four 80-KiB workgroups per item (dQ / dK,dV roles x halves, two per CU): 2.7 GB of
@@ -1854,6 +2238,26 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
     int ncu = num_cus();
     ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
     const dim3 grid(nitems < ncu ? nitems : ncu);
+    // REED_ATTN_FWD=r2 keeps round 2's three-barrier kernel (same-box A/B); REED_ATTN_FWD_DBG=<bits> runs the diagnosis
+    // instantiation of the round-4 kernel (hd 72, T = 256 only: parts of the work switched off, results meaningless)
+    static const bool r2 = getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 'r';
+    static const int fdbg = getenv("REED_ATTN_FWD_DBG") ? atoi(getenv("REED_ATTN_FWD_DBG")) : 0;
+    if (!r2) {
+#define LAUNCH_FWD256P(HD, FULL, DBGK)                                                                                 \
+    do {                                                                                                               \
+      static int once = set_lds(attn_fwd256p_kernel<HD, FULL, DBGK>, lds);                                             \
+      if (once) return once;                                                                                           \
+      REED_KLAUNCH((attn_fwd256p_kernel<HD, FULL, DBGK>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,  \
+                   (bf16*)o, lse, T, H, nitems, fdbg);                                                                 \
+    } while (0)
+      if (fdbg && hd == 72 && T == 256) LAUNCH_FWD256P(72, true, true);
+      else if (hd == 64) { if (T == 256) LAUNCH_FWD256P(64, true, false); else LAUNCH_FWD256P(64, false, false); }
+      else if (hd == 72) { if (T == 256) LAUNCH_FWD256P(72, true, false); else LAUNCH_FWD256P(72, false, false); }
+      else { if (T == 256) LAUNCH_FWD256P(80, true, false); else LAUNCH_FWD256P(80, false, false); }
+#undef LAUNCH_FWD256P
+      REED_LAUNCH_CHECK();
+      return REED_OK;
+    }
 #define LAUNCH_FWD256(HD)                                                                                              \
     do {                                                                                                               \
       static int once = set_lds(attn_fwd256_kernel<HD>, lds);                                                          \
