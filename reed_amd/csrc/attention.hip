@@ -800,8 +800,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     issue(Kb + TILE_F + wave * 32 * ROWF, plus(base_of(it + G), D));
     issue(Vw, plus(b0, 2 * D));
     const __amdgpu_buffer_rsrc_t none = mk_rsrc(nullptr, 0);
+    // "stores(-1)": seven dropped stores, so that the counts below hold from item 0 (distinct, non-adjacent offsets and
+    // values: identical ones are merged into one instruction — the ISA must show seven, tools/r4/check_isa.py)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, none, DMA_OOB, 0, 0);   // "stores(-1)": the counts below hold from item 0
+    for (int k = 0; k < 7; ++k) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(k + lane0), none, DMA_OOB - 256 * k, 0, 0);
     asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // Q, K of the first item (younger: K of the second, V, the 7 stores)
     ATTN_BARRIER();
   }

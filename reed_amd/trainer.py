@@ -89,10 +89,18 @@ class TrainStep:
         self.tune_error = None
         self._tune = []
         self._tune_algo = False
-        mode = os.environ.get("REED_COMM_CUS", "off")
-        self._tune_shard = (os.environ.get("REED_OPT_SHARD") == "auto" and reducer is not None and reducer.active()
-                            and hasattr(optimizer, "set_sharded") and getattr(optimizer, "overlap", False))
+        self._tune_shard = False
         self.shard_tuning = None
+        self.plan_tuning(os.environ.get("REED_COMM_CUS", "off"), os.environ.get("REED_OPT_SHARD"), os.environ.get("REED_COMM_ALGO"))
+
+    def plan_tuning(self, mode="auto", shard="auto", algo=None):
+        """Schedule the run-time measurements described in __init__ for the next optimiser steps (what the constructor does from
+        the environment).  bench.py calls it AFTER it has timed the plain plan — reserve 0, all-reduce buckets, replicated
+        optimiser pass — so that a measurement that fails on first contact with the real interconnect cannot lose that number."""
+        reducer, optimizer = self.reducer, self.opt
+        mode = mode or "off"
+        self._tune_shard = (shard == "auto" and reducer is not None and reducer.active()
+                            and hasattr(optimizer, "set_sharded") and getattr(optimizer, "overlap", False))
         if reducer is not None and reducer.active() and (mode != "off" or self._tune_shard):
             if mode not in ("off", "auto"):
                 self.cu_reserve = int(mode)
@@ -103,14 +111,16 @@ class TrainStep:
                 nt = max(1, int(os.environ.get("REED_COMM_TUNE_STEPS", "3")))
                 self._tune = [(c, k) for c in cands for k in range(nt + 1)]   # k = 0: settling step, k >= 1: timed
                 self._tune_times = {}
-                self._tune_algo = os.environ.get("REED_COMM_ALGO") == "auto" and hasattr(reducer, "algo")
+                self._tune_algo = algo == "auto" and hasattr(reducer, "algo")
                 if self._tune_algo:
                     self._tune += [("rsag", k) for k in range(nt + 1)]
                 if self._tune_shard:
                     self._tune += [("shard", k) for k in range(nt + 1)]
 
     def __call__(self, x, labels, zs, moments=None, **inject):
-        """x: latents [b,4,32,32] (or pass moments=[b,8,32,32] to run sample_posterior). Returns device scalars."""
+        """x: latents [b,4,32,32] (or pass moments=[b,8,32,32] to run sample_posterior). Returns device scalars.
+        res["grad_norm"] is a VIEW of one of the optimiser's two alternating norm buffers: read (or clone) it before the step
+        after next — a caller that keeps device scalars over a logging window must clone it."""
         rd, rs, sd, wu, dd, mx = self.sched
         w_repa = repa_weight_decay(rd, self.global_step, rs)
         w_diff = diffusion_loss_decay(dd, self.global_step, sd, wu, mx)
