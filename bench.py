@@ -86,30 +86,49 @@ def self_launch(args, argv):
         return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this image
+    # rank 0 leaves the record of its FIRST timed region (the plain plan) here the moment it has it: if the ranks then have to
+    # be abandoned (a tuner that hangs on first contact with RCCL and takes the in-process watchdog with it), this parent —
+    # which never touched the GPU — ends the group and still prints that record
+    plain_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"reed_bench_plain.{os.getpid()}.json")
+    env["REED_BENCH_PLAIN_FILE"] = plain_file
     cmd = launcher_argv(args, argv, _free_port())
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)
+    timed_out = False
     try:
         out, _ = p.communicate(timeout=args.launch_timeout)
     except subprocess.TimeoutExpired:
+        timed_out = True
         try:
             os.killpg(p.pid, signal.SIGKILL)     # exactly the process group this function started
         except ProcessLookupError:
             pass
         out, _ = p.communicate()
         print(f"bench.py: ranks still running after {args.launch_timeout:.0f} s - ended", file=sys.stderr, flush=True)
-        return 3
     line = None
     for ln in out.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         else:
             print(ln, file=sys.stderr)
+    rc = 3 if timed_out else p.returncode
+    if line is None and os.path.exists(plain_file):
+        try:
+            with open(plain_file) as f:
+                rec = json.load(f)
+            rec.setdefault("plans", {})["tuned"] = {"error": "ranks abandoned by the launcher" + (" (timeout)" if timed_out else f" (exit code {p.returncode})")}
+            line, rc = json.dumps(rec), 0
+        except Exception as e:
+            print(f"bench.py: could not read the plain-plan record: {e!r}", file=sys.stderr, flush=True)
+    try:
+        os.unlink(plain_file)
+    except OSError:
+        pass
     if line is not None:
         print(line, flush=True)
-    if p.returncode == 0 and line is None:
+    if rc == 0 and line is None:
         print("bench.py: the ranks exited without a result line", file=sys.stderr, flush=True)
         return 4
-    return p.returncode
+    return rc
 
 
 def random_fill(model, seed):
@@ -337,11 +356,11 @@ def c4_leg(dev, b=32, steps=8, warmup=3):
             "note": "C4: image + text alignment (two projectors), one GPU at the per-GPU batch of the 8-GPU run, no all-reduce"}
 
 
-def c5_leg(dev, n=32, heun_steps=4):
-    """BASELINE configs[4] (C5): generate.py's sampling loop on this GPU — SiT-XL/2, Heun ODE sampler with classifier-free
-    guidance over the whole interval (every evaluation at batch 2n; image/samplers.py:46-104), fp16 operands (what
-    generate.py uses under the reference's default --tf32).  A short run (2 heun_steps - 1 evaluations) scaled to the 250-step
-    recipe's 499 evaluations: the cost of an evaluation does not depend on the step index (tools/bench_generate.py)."""
+def c5_leg(dev, n=32, num_steps=250):
+    """BASELINE configs[4] (C5): generate.py's sampling loop on this GPU at its REAL length — SiT-XL/2, the 250-step Heun ODE
+    sampler with classifier-free guidance over the whole interval (2 * 250 - 1 = 499 model evaluations, every one at batch 2n;
+    image/samplers.py:46-104), fp16 operands (what generate.py uses under the reference's default --tf32).  One full run is
+    timed (about 9 s), nothing is scaled."""
     from reed_amd.models.sit import SiT_models
     from reed_amd.samplers import euler_sampler
     model = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8, use_cfg=True).to(dev).eval()
@@ -353,14 +372,18 @@ def c5_leg(dev, n=32, heun_steps=4):
     euler_sampler(model, z, y, num_steps=2, heun=True, cfg_scale=1.5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = euler_sampler(model, z, y, num_steps=heun_steps, heun=True, cfg_scale=1.5, guidance_low=0.0, guidance_high=1.0)
+    out = euler_sampler(model, z, y, num_steps=num_steps, heun=True, cfg_scale=1.5, guidance_low=0.0, guidance_high=1.0)
     torch.cuda.synchronize()
-    per_eval = (time.perf_counter() - t0) / (2 * heun_steps - 1)
+    dt = time.perf_counter() - t0
+    n_eval = 2 * num_steps - 1
+    per_eval = dt / n_eval
     flop_eval = 237.23e9 * 2 * n
-    return {"n_per_gpu": n, "operands": "fp16", "ms_per_evaluation": round(per_eval * 1e3, 2),
-            "images_per_sec_per_gpu_250_heun_cfg": round(n / (499 * per_eval), 3),
+    return {"n_per_gpu": n, "operands": "fp16", "num_steps": num_steps, "evaluations": n_eval, "seconds": round(dt, 3),
+            "seconds_per_image": round(dt / n, 4), "ms_per_evaluation": round(per_eval * 1e3, 2),
+            "images_per_sec_per_gpu_250_heun_cfg": round(n / dt, 3),
             "mfma_frac": round(flop_eval / per_eval / PEAK_BF16, 4), "finite": bool(torch.isfinite(out).all()),
-            "note": f"C5: {2 * heun_steps - 1} evaluations at batch {2 * n} timed, scaled to 499; ranks sample independent images, N GPUs give N times this"}
+            "note": f"C5: the whole {num_steps}-step Heun + CFG run ({n_eval} evaluations at batch {2 * n}) timed once; ranks sample "
+                    "independent images, N GPUs give N times this"}
 
 
 def n2_encoder_leg(dev, batch=64, reps=3):
@@ -477,12 +500,14 @@ def main():
         reducer = GradReducer(model, rank, world)
         reducer.broadcast_params(0)
     loss_fn = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
-    # the run-time measurement of the CU reserve is opt-in in the library (REED_COMM_CUS=auto); the bench asks for it on a
-    # data-parallel run unless the caller fixed it.  The bucket form stays "allreduce" unless REED_COMM_ALGO says otherwise.
-    if reducer is not None:
-        os.environ.setdefault("REED_COMM_CUS", "auto")
-        if world > 1:
-            os.environ.setdefault("REED_OPT_SHARD", "auto")   # measured against the replicated pass, kept only if faster
+    # Data-parallel runs time the PLAIN plan first — torch's RCCL binding, all-reduce buckets, no CU reserve, replicated
+    # optimiser pass, nothing measured at run time — and only then, as a second timed region inside a watchdog, the TUNED plan
+    # (run-time measurement of the CU reserve and of the sharded optimiser pass: TrainStep.plan_tuning).  The tuners have never
+    # run over RCCL with more than one rank: a failure or a hang there must not cost the number.  `value` is the better of the
+    # two regions, both are reported under "plans".  A caller that fixes REED_COMM_CUS / REED_OPT_SHARD / REED_COMM_ALGO gets
+    # exactly that plan in the first region and no second one.
+    user_fixed = any(k in os.environ for k in ("REED_COMM_CUS", "REED_OPT_SHARD", "REED_COMM_ALGO"))
+    want_tuned = reducer is not None and not user_fixed and os.environ.get("REED_BENCH_TUNED", "1") != "0"
     step = TrainStep(model, loss_fn, opt, reducer, proj_coeff=0.5, diffusion_warm_up_steps=0)
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -507,36 +532,132 @@ def main():
             return 2.0 * tokens * sum(n * k for n, k in shapes)
         return None
 
-    # W untimed warm-up steps — more when the data-parallel step still measures its CU reserve (trainer.py): that
-    # measurement (two steps per candidate) stays out of the timed region
     # REED_MAIN_PRIO=1 (experiment): run the steps on a high-priority stream (the device has two levels; the optimiser's and the
     # weight-gradient side streams stay at the default level)
     if os.environ.get("REED_MAIN_PRIO", "0") == "1":
         hp = torch.cuda.Stream(device=dev, priority=-1)
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)
-    n_warm = max(args.warmup, step.tune_steps_left() + 1 if step.tune_steps_left() else 0)
-    for _ in range(n_warm):
-        res = step(None, labels, zs, moments=moments)
-    barrier()
-    if rank == 0:
-        ops.wgrad_group_probe = probe   # event pairs on the launch stream around every launch of the dominant kernel
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(None, labels, zs, moments=moments)
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.wgrad_group_probe = None
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+
+    def timed_region(n_warm):
+        """n_warm untimed steps, then EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over ranks."""
+        res = None
+        for _ in range(n_warm):
+            res = step(None, labels, zs, moments=moments)
+        barrier()
+        if rank == 0:
+            ops.wgrad_group_probe = probe   # event pairs on the launch stream around every launch of the dominant kernel
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step(None, labels, zs, moments=moments)
+        barrier()
+        dt = time.perf_counter() - t0
+        ops.wgrad_group_probe = None
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dom = {}
+        for key, e0, e1 in ops.gemm_probe_log:
+            dom.setdefault(key, []).append(e0.elapsed_time(e1))
+        ops.gemm_probe_log.clear()
+        return {"dt": float(tmax.item()), "loss": float(res["loss"]), "dom": dom}
+
+    def plan_record(reg, what):
+        return {"plan": what, "images_per_sec": round(args.global_batch * args.steps / reg["dt"], 2),
+                "ms_per_step": round(reg["dt"] / args.steps * 1e3, 3), "final_loss": round(reg["loss"], 5)}
+
+    def plan_of_step():
+        return (f"{getattr(reducer, 'binding', None)} binding, {getattr(reducer, 'algo', None)} buckets, CU reserve {step.cu_reserve}, "
+                f"{'sharded' if getattr(opt, '_shard', False) else 'replicated'} optimiser pass") if reducer is not None else "single GPU"
+
+    # W untimed warm-up steps — more when the caller asked for a run-time measurement through the environment (trainer.py): that
+    # measurement (one settling + three timed steps per candidate) stays out of the timed region
+    plain = timed_region(max(args.warmup, step.tune_steps_left() + 1 if step.tune_steps_left() else 0))
+    plans = {"plain": plan_record(plain, plan_of_step())}
+    chosen = plain
+
+    def base_record(reg):
+        ips = args.global_batch * args.steps / reg["dt"]
+        return {
+            "metric": "SiT-XL/2 ImageNet-256 train images/sec", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(reg["dt"] / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.mixed_precision],
+            "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)" +
+                    (" — REHEARSAL: ranks share the visible GPUs, collectives over gloo; not a measurement" if REHEARSE else ""),
+            "config": {"workload": f"C{'2' if world == 1 else '3'}: {args.model} + {args.z_dim}-d alignment projector (REED loss), "
+                                   f"global batch {args.global_batch} (b={b}/GPU), full train step "
+                                   "(fwd+bwd+clip+AdamW+EMA), bf16 MFMA / fp32 master",
+                       "global_batch": args.global_batch, "local_batch": b, "parallelism": f"dp{world}"},
+            "final_loss": round(reg["loss"], 5),
+            # the whole step against the MFMA roofline: images/s/GPU x 724.97 GFLOP / 2.5 PFLOP/s (the headline efficiency)
+            "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
+        }
+
+    # ---- the watchdog: from here to the end of the process.  If it fires before rank 0 has printed its line, rank 0 prints the
+    # plain-plan record; every rank then leaves with os._exit(0) (no exec, no teardown of a communicator that may be wedged)
+    import threading
+    wd_lock = threading.Lock()
+    wd_state = {"printed": False, "phase": "tuned plan"}
+
+    def emit(rec):
+        """rank 0: the ONE JSON line on the real stdout."""
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(json.dumps(rec), flush=True)
+        os.dup2(2, 1)
+
+    def wd_fire():
+        with wd_lock:
+            if rank == 0 and not wd_state["printed"]:
+                rec = base_record(plain)
+                rec["plans"] = dict(plans, tuned=plans.get("tuned") or {"error": f"timeout in: {wd_state['phase']}"})
+                rec["plan_in_value"] = "plain"
+                emit(rec)
+                wd_state["printed"] = True
+            print(f"[bench.py] rank {rank}: watchdog fired in: {wd_state['phase']} - leaving", file=sys.stderr, flush=True)
+            os._exit(0)
+
+    watchdog = None
     if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    loss_val = float(res["loss"])
+        if rank == 0 and os.environ.get("REED_BENCH_PLAIN_FILE"):
+            try:
+                rec = base_record(plain)
+                rec["plans"], rec["plan_in_value"] = dict(plans), "plain"
+                with open(os.environ["REED_BENCH_PLAIN_FILE"], "w") as f:
+                    json.dump(rec, f)
+            except OSError:
+                pass
+        watchdog = threading.Timer(float(os.environ.get("REED_BENCH_TUNED_TIMEOUT", "300")), wd_fire)
+        watchdog.daemon = True
+        watchdog.start()
+    if want_tuned:
+        try:
+            fail = os.environ.get("REED_TEST_TUNER_FAIL", "")   # tests: a tuner that hangs / raises on first contact
+            step.plan_tuning("auto", "auto" if world > 1 else None, None)
+            if fail == "hang":
+                while True:
+                    time.sleep(1.0)
+            if fail == "raise":
+                raise RuntimeError("REED_TEST_TUNER_FAIL=raise")
+            tuned = timed_region(step.tune_steps_left() + 1)
+            plans["tuned"] = plan_record(tuned, plan_of_step())
+            if tuned["dt"] < plain["dt"]:
+                chosen = tuned
+        except Exception as e:   # the plain record stands; the ranks may no longer agree on anything: leave without collectives
+            plans["tuned"] = {"error": repr(e)}
+            if rank == 0:
+                with wd_lock:
+                    rec = base_record(plain)
+                    rec["plans"], rec["plan_in_value"] = plans, "plain"
+                    emit(rec)
+                    wd_state["printed"] = True
+            print(f"[bench.py] rank {rank}: tuned plan failed ({e!r}) - leaving with the plain record", file=sys.stderr, flush=True)
+            os._exit(0)
+    wd_state["phase"] = "diagnosis / teardown"
+    dt = chosen["dt"]
+    loss_val = chosen["loss"]
+    dom = chosen["dom"]
     model.engine().check_errors()
-    dom = {}
-    for key, e0, e1 in ops.gemm_probe_log:
-        dom.setdefault(key, []).append(e0.elapsed_time(e1))
-    ops.gemm_probe_log.clear()
 
     # ---- data-parallel diagnosis (after the timed region): bucket plan, bytes, and with a reducer two extra steps with an
     # event pair around every bucket reduction (comm stream) and around reducer.sync() (compute stream: what the step waits)
@@ -581,23 +702,11 @@ def main():
             dp["error"] = repr(e)
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        ips = args.global_batch * args.steps / dt
-        out = {
-            "metric": "SiT-XL/2 ImageNet-256 train images/sec", "value": round(ips, 2), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.mixed_precision],
-            "data": "synthetic (random ImageNet-256 latents / DINOv2-L-shaped features; random-init weights)" +
-                    (" — REHEARSAL: ranks share the visible GPUs, collectives over gloo; not a measurement" if REHEARSE else ""),
-            "config": {"workload": f"C{'2' if world == 1 else '3'}: {args.model} + {args.z_dim}-d alignment projector (REED loss), "
-                                   f"global batch {args.global_batch} (b={b}/GPU), full train step "
-                                   "(fwd+bwd+clip+AdamW+EMA), bf16 MFMA / fp32 master",
-                       "global_batch": args.global_batch, "local_batch": b, "parallelism": f"dp{world}"},
-            "final_loss": round(loss_val, 5),
-            # the whole step against the MFMA roofline: images/s/GPU x 724.97 GFLOP / 2.5 PFLOP/s (the headline efficiency)
-            "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
-            "data_parallel": dp,
-        }
+        out = base_record(chosen)
+        out["data_parallel"] = dp
+        if reducer is not None:
+            out["plans"] = plans
+            out["plan_in_value"] = "tuned" if chosen is not plain else "plain"
         # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region (with or without the
         # isolated kernel table, which only supplies the stand-in when the grouped launch did not run)
         n_l = sum(len(v) for v in dom.values())
@@ -659,10 +768,9 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}
-        sys.stdout.flush()
-        os.dup2(stdout_fd, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+        with wd_lock:
+            emit(out)
+            wd_state["printed"] = True
     if use_dist:   # rank 0 is still timing the kernel table: nobody tears a communicator down under it
         torch.cuda.synchronize()
         dist.barrier()
@@ -670,6 +778,8 @@ def main():
         reducer.close()
     if use_dist:
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

@@ -762,6 +762,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
   constexpr bool ONES = (HD == 72);   // d = 72..79 is the zero pad of the fifth output tile: column 72 carries the row sums
   if (!DBGK) dbg = 0;
+  // dbg bit 5 (DBGK only): shader-clock time per phase, summed over the wave's items in registers and written over the start
+  // of `lse` when the wave is done ([workgroup][wave][10] x u64; tools/r4/fwd_stamps.py) — no memory instruction inside the loop
+  unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define ATTN_STAMP(k)                                               \
+  do {                                                              \
+    if (DBGK && (dbg & 32)) {                                       \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+      tacc[k] += t_ - tprev;                                        \
+      tprev = t_;                                                   \
+    }                                                               \
+  } while (0)
   const int tid = threadIdx.x;
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -818,9 +829,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     asm volatile("" : "+v"(lane));
     const int i = lane & 15, g = lane >> 4;
     const char* Kt = Kb + par * TILE_F;
+    if (DBGK && (dbg & 32)) tprev = __builtin_amdgcn_s_memtime();
     // ---------------- Q(n): own patch, own wait ----------------
     asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(0);
     bf16x8 qf[2][KS];
     {
       const unsigned qa = lds_addr(Qw + i * ROWF + 16 * g);
@@ -838,6 +851,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     }
     issue(Qw, base_of(it + G));
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(1);
     // ---------------- S^T = K Q^T (K(n) landed: the barrier that ended item n-1) ----------------
     f32x4 st[2][16];
     if (DBGK && (dbg & 1)) {
@@ -873,6 +887,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
         }
       }
     }
+    ATTN_STAMP(2);
     // ---------------- softmax over the keys, in registers ----------------
     if (!FULL) {
 #pragma unroll
@@ -922,11 +937,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       lrow[qt] = sum;
       __builtin_amdgcn_sched_barrier(0);
     }
+    ATTN_STAMP(3);
     // ---------------- V(n) landed; every wave is past S(n): K(n+2) may overwrite K(n) ----------------
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(4);
     if (ONES && lane < 32) *(bf16*)(Vw + lane * ROWF + HD * 2) = (bf16)1.0f;   // own rows, behind own pieces: the ones column
     ATTN_BARRIER();
+    ATTN_STAMP(5);
     issue(Kb + par * TILE_F + wave * 32 * ROWF, plus(base_of(it + 2 * G), D));
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- O^T = V^T P^T ----------------
@@ -946,9 +964,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
         pv_all<ROWF, DT>(Vt + (4 * g + (i >> 2)) * ROWF + (i & 3) * 8, (T + 31) >> 5, pb, ot);
       }
     }
+    ATTN_STAMP(6);
     // K(n+1) landed (this wave's pieces); after the barrier: every wave's, and every wave is past its V reads
     asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(7);
     ATTN_BARRIER();
+    ATTN_STAMP(8);
     // ---------------- output: staged in the wave's own rows of the V tile, whole 144-byte row pieces out ----------------
     float lsev[2];
 #pragma unroll
@@ -991,8 +1013,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
                                               g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
     }
+    ATTN_STAMP(9);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills of the items past the end: LDS stays allocated until they land
+  if (DBGK && (dbg & 32) && lse && lane0 == 0) {
+    unsigned long long* dst = (unsigned long long*)lse + ((long)blockIdx.x * 8 + wave) * 10;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) dst[k] = tacc[k];
+  }
+#undef ATTN_STAMP
 }
 
 // ------------------------------------------------------------------------------------------

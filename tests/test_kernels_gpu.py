@@ -518,13 +518,16 @@ def test_fp16_library_gemm_and_attention(dev):
     torch.testing.assert_close(outs[144][0].float(), outs[257][0].float(), atol=4e-3, rtol=2e-3)
 
 
-@pytest.mark.parametrize("B,D", [(40, 1152), (3, 384), (7, 1024)])
-def test_embed_and_final_layer_second_forms_bit_identical(dev, monkeypatch, B, D):
+@pytest.mark.parametrize("B,D,HW", [(40, 1152, 32), (3, 384, 32), (7, 1024, 32), (3, 384, 8), (5, 1152, 16), (1, 384, 8)])
+def test_embed_and_final_layer_second_forms_bit_identical(dev, monkeypatch, B, D, HW):
     """The patch-embed forward with the weight rows in registers (16-byte stores) and the final-layer forward / backward rows with
     the weight staged in LDS per 64 rows (csrc/embed.hip) against the first forms (REED_EMBED_OLD=1): the same per-lane accumulation
-    order and the same wave reductions, so every output is bit-identical; B * 256 rows not a multiple of 64 (40, 3, 7 images)."""
+    order and the same wave reductions, so every output is bit-identical.  HW = 32: B * 256 rows, always whole 64-row groups;
+    HW = 8 / 16 (T = 16 / 64 tokens per image) with odd B: 48, 320 and 16 rows — the kernels' tail guards (a last group with fewer
+    than 64 rows, the second half of a row pair missing)."""
     from reed_amd import ops
-    C, HW, P, T = 4, 32, 2, 256
+    C, P = 4, 2
+    T = (HW // P) ** 2
     g = torch.Generator().manual_seed(B + D)
     x = torch.randn(B, C, HW, HW, generator=g).to(dev)
     w = (torch.randn(D, 16, generator=g) * 0.2).to(torch.bfloat16).to(dev)
