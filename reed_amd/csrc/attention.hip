@@ -1911,6 +1911,87 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
   }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform n that is only known per wave class (the instruction takes an immediate)
+__device__ __forceinline__ void vmcnt_wait(int n) {
+  switch (n) {
+#define REED_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    REED_VMC(1) REED_VMC(2) REED_VMC(3) REED_VMC(4) REED_VMC(5) REED_VMC(6) REED_VMC(7) REED_VMC(8) REED_VMC(9) REED_VMC(10)
+    REED_VMC(11) REED_VMC(12) REED_VMC(13) REED_VMC(14) REED_VMC(15) REED_VMC(16) REED_VMC(17) REED_VMC(18) REED_VMC(19) REED_VMC(20)
+#undef REED_VMC
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// Phase B of the ring kernel, round 4: dQ^T = K^T dS^T for one 16-query tile and this wave's column tiles (even waves: the first
+// DTA 16-column tiles, odd waves: the rest), software pipelined like the forward's PV product — the transposed fragments of
+// key step ks + 1 (inline asm, 32-bit pairs, compile-time offsets from ONE lane base per tile) are read before the MFMAs of step
+// ks issue and waited for behind them; the loop of round 3 read, waited and multiplied in turn (8 exposed LDS round trips).
+// dQ then leaves in 16-byte lanes: v_permlane16_swap exchanges the odd 16-lane rows of tile k with the even rows of tile k + 1,
+// after which lane row g holds 8 consecutive columns (16 (g & 1) + 8 (g >> 1) of the tile pair) of its query — one dwordx4
+// store covers 64 contiguous bytes of each of 16 query rows, where the MFMA layout gave two stores of 32-byte pieces.
+template <int HD, bool ODD>
+struct RingB {
+  static constexpr int DT = Cfg<HD>::DT, DTA = (DT + 1) / 2;
+  static constexpr int NK = ODD ? DT - DTA : DTA;      // column tiles of this wave class (hd 72: 3 | 2, hd 64: 2 | 2)
+  static constexpr int D0 = ODD ? DTA : 0;
+  static constexpr int NST = (NK + 1) / 2;             // store instructions per chunk: pairs as dwordx4, a last odd tile as dwordx2
+  template <int KS>
+  static __device__ __forceinline__ void load(unsigned sb, unsigned kb, bf16x8& dsf, bf16x8 (&ktf)[NK]) {
+    dsf = frag_trT_u<ROWB, KS * 32 * ROWB>(sb);
+    ktf[0] = frag_trT_u<ROWB, KS * 32 * ROWB>(kb);
+    if constexpr (NK > 1) ktf[1] = frag_trT_u<ROWB, KS * 32 * ROWB + 32>(kb);
+    if constexpr (NK > 2) ktf[2] = frag_trT_u<ROWB, KS * 32 * ROWB + 64>(kb);
+  }
+  template <int KS>
+  static __device__ __forceinline__ void step(unsigned sb, unsigned kb, f32x4 (&dq)[NK], bf16x8& dsc, bf16x8 (&kc)[NK], bf16x8& dsn,
+                                              bf16x8 (&kn)[NK]) {
+    if constexpr (KS + 1 < 8) load<KS + 1>(sb, kb, dsn, kn);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) dq[k] = (KS == 0) ? MFMA(kc[k], dsc, zero4()) : MFMA(kc[k], dsc, dq[k]);
+    ATTN_LDS_WAIT();
+  }
+  // St / Kt: the dS^T and K tiles (144-byte rows); qrow0: dqkv row of the tile's first query (q part); returns after the stores
+  static __device__ __forceinline__ void run(const char* St, const char* Kt, int qtile, int lane, float scale, bf16* qrow0, long tok,
+                                             bool skip) {
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned sb = lds_addr(St + (4 * g + (i >> 2)) * ROWB + (16 * qtile + 4 * (i & 3)) * 2);
+    const unsigned kb = lds_addr(Kt + (4 * g + (i >> 2)) * ROWB + (16 * D0 + 4 * (i & 3)) * 2);
+    f32x4 dq[NK];
+    if (skip) {   // diagnosis: no products
+#pragma unroll
+      for (int k = 0; k < NK; ++k) dq[k] = zero4();
+    } else {
+      bf16x8 da, db, ka[NK], kb2[NK];
+      load<0>(sb, kb, da, ka);
+      ATTN_LDS_WAIT();
+      step<0>(sb, kb, dq, da, ka, db, kb2);
+      step<1>(sb, kb, dq, db, kb2, da, ka);
+      step<2>(sb, kb, dq, da, ka, db, kb2);
+      step<3>(sb, kb, dq, db, kb2, da, ka);
+      step<4>(sb, kb, dq, da, ka, db, kb2);
+      step<5>(sb, kb, dq, db, kb2, da, ka);
+      step<6>(sb, kb, dq, da, ka, db, kb2);
+      step<7>(sb, kb, dq, db, kb2, da, ka);
+    }
+    u32x2 v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = u32x2{pk2(dq[k][0] * scale, dq[k][1] * scale), pk2(dq[k][2] * scale, dq[k][3] * scale)};
+    bf16* row = qrow0 + (long)i * tok;
+#pragma unroll
+    for (int k = 0; k + 1 < NK; k += 2) {
+      const auto r0 = __builtin_amdgcn_permlane16_swap(v[k][0], v[k + 1][0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(v[k][1], v[k + 1][1], false, false);
+      const int d = 16 * (D0 + k) + 16 * (g & 1) + 8 * (g >> 1);
+      const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+      if (16 * (D0 + k) + 32 <= HD || d < HD) *(u32x4*)(row + d) = w;   // (hd 72: columns 72..79 of the last pair do not exist)
+    }
+    if constexpr (NK & 1) {
+      const int d = 16 * (D0 + NK - 1) + 4 * g;
+      if (16 * (D0 + NK) <= HD || d < HD) *(u32x2*)(row + d) = v[NK - 1];
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------
 // The persistent key-stationary backward for T = 256 with the operand traffic SPREAD over the item (the form the engine runs).
 // attn_bwd_ksp_kernel above still asks for half of an item's bytes at its very end — the wave's own K / V rows (72 KiB per
@@ -1927,14 +2008,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
 // Every wait of the item is a counted s_waitcnt vmcnt(N) (loads, stores and LDS-DMA retire in issue order).  A chunk of Q + dO is
 // 20 pieces of 1 KiB (64 rows of 160 bytes, twice) and a K tile 36: waves 0..3 issue 3 of a chunk and 5 of a K tile, waves 4..7
 // issue 2 and 4, so N depends on the wave's half.  Per item and wave, in issue order:
-//   c=0: X0[3|2] K(n+1)[5|4] dQ[3] | c=1: X1[3|2] dQ[3] | c=2: X2[3|2] dQ[3] | c=3: X3[3|2] own[8] dQ[3] | dK, dV rows[2 NI]
-//   (X0, X1 = chunks 2, 3 of this item; X2, X3 = chunks 0, 1 of the next).  Chunk 2 is needed when chunk 1 ends: X0 landed <=>
-//   at most K + X + 6 younger operations outstanding (14 / 12); chunk 3 when chunk 2 ends: X1 <=> X + 6 (9 / 8); the
-//   item-end wait (the own rows landed: at most 3 + 2 NI younger, the same for every wave) covers X2, X3 and K(n+1).
+//   c=0: X0[3|2] K(n+1)[5|4] dQ[NQ] | c=1: X1[3|2] dQ[NQ] | c=2: X2[3|2] dQ[NQ] | c=3: X3[3|2] own[8] dQ[NQ] | dK, dV rows[2 NI]
+//   (X0, X1 = chunks 2, 3 of this item; X2, X3 = chunks 0, 1 of the next; NQ = the wave's dQ store instructions per chunk, RingB::NST:
+//   hd 72 even waves 2, odd 1; hd 64: 1).  Chunk 2 is needed when chunk 1 ends: X0 landed <=> at most K + X + 2 NQ younger
+//   operations outstanding; chunk 3 when chunk 2 ends: X1 <=> X + 2 NQ; the item-end wait (the own rows landed: at most
+//   NQ + 2 NI younger) covers X2, X3 and K(n+1).  (Round 3 hard-coded the hd-72 counts 14 / 12, 9 / 8 and 3 + 2 NI for both
+//   head sizes: with hd 64's two dQ stores per chunk its waits allowed two operations too many — fixed with the counts computed.)
 // The ring slots use 160-byte rows (ROWF: conflict-free ds_read_b128 and transposing reads; with 144-byte rows 7 of the 8 rows
 // a ds_read_b128 lane group takes at g = 1 share banks with its g = 0 rows), the K and dS^T tiles keep 144 (LDS budget).
 // LDS: Q ring 20 | dO ring 20 | K x 2 72 | dS^T 36 | lse, delta x 2 4 = 152 KiB.
-template <int HD>
+template <int HD, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16* __restrict__ dqkv, int H, int nitems, int dbg) {
@@ -1957,6 +2040,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
   const int r0 = wave * 32;
+  // STAMPS (diagnosis instantiation, dbg bit 2): shader-clock time per phase summed over the wave's items in registers, written over
+  // the start of dqkv when the wave is done ([workgroup][wave][8] x u64; tools/r4/bwd_stamps.py); no memory instruction in the loops
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define RING_STAMP(k)                                               \
+  do {                                                              \
+    if (STAMPS && (dbg & 4)) {                                      \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+      tacc[k] += t_ - tprev;                                        \
+      tprev = t_;                                                   \
+    }                                                               \
+  } while (0)
 
   // chunk `c` (64 rows) of the Q and dO tiles of an item -> ring slot c & 1: 10 + 10 pieces of 1 KiB (16-byte lanes; a 12-byte
   // lane — buffer_load_dwordx3 ... lds — would give every wave the same piece count, but the hardware puts each lane's 12 bytes
@@ -2048,7 +2142,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
     const char* Kt = Kb + par * TILE_B;
     const float* lse2 = ld2 + par * 512;
     const float* dlt = lse2 + 256;
+    if (STAMPS && (dbg & 4)) tprev = __builtin_amdgcn_s_memtime();
     ATTN_BARRIER();    // item boundary: K, lse / delta of this item are in LDS (every wave waited for its pieces and wrote its rows)
+    RING_STAMP(0);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -2130,7 +2226,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
             }
         }
       }
+      RING_STAMP(1);
       ATTN_BARRIER();   // dS^T of the chunk complete; the ring slot is released
+      RING_STAMP(2);
       if (ch < 2 || has_next) {
         int ln = lane0;
         asm volatile("" : "+v"(ln));   // fresh copy: piece offsets and row addresses are computed here, not kept in registers
@@ -2142,47 +2240,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       }
       // ---------------- phase B: dQ^T = K^T dS^T for the chunk's 64 queries ----------------
       {
-        const int qtile = wave >> 1;
-        const int dt0 = (wave & 1) ? DTA : 0;
-        f32x4 dq[DTA];
-#pragma unroll
-        for (int k = 0; k < DTA; ++k) dq[k] = zero4();
-#pragma unroll 1
-        for (int ks = 0; ks < ((dbg & 2) ? 0 : 8); ++ks) {   // dbg bit 1: skip phase B's products
-          const bf16x8 dsf = frag_trT_a<ROWB>(St, 32 * ks, 16 * qtile, lane);
-          bf16x8 ktf[DTA];
-#pragma unroll
-          for (int k = 0; k < DTA; ++k) ktf[k] = frag_trT_a<ROWB>(Kt, 32 * ks, 16 * min(dt0 + k, DT - 1), lane);
-          ATTN_LDS_WAIT();
-#pragma unroll
-          for (int k = 0; k < DTA; ++k)
-            if (dt0 + k < DT) dq[k] = MFMA(ktf[k], dsf, dq[k]);
-        }
-        const int q = ch * 64 + 16 * qtile + i;
-#pragma unroll
-        for (int k = 0; k < DTA; ++k) {
-          const int kk = (dt0 + k < DT) ? k : DT - 1 - dt0;
-          const int d = 16 * (dt0 + kk) + 4 * g;
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[kk][r] * scale);
-          if (d < HD) *(bf16x4*)(dbase + (long)q * tok + d) = v;
-        }
+        bf16* qrow0 = dbase + (long)(ch * 64 + 16 * (wave >> 1)) * tok;
+        if (wave & 1) RingB<HD, true>::run(St, Kt, wave >> 1, lane, scale, qrow0, tok, (dbg & 2) != 0);   // dbg bit 1: no products
+        else RingB<HD, false>::run(St, Kt, wave >> 1, lane, scale, qrow0, tok, (dbg & 2) != 0);
       }
       // the next chunk's Q / dO rows (issued one chunk ago) have landed: counted, see the table in the header
       __builtin_amdgcn_sched_barrier(0);
+      RING_STAMP(3);
       if (has_next) {
-        if (ch == 1) {          // chunk 2 (X0) landed; younger: K(n+1) 5 | 4, dQ 3, X1 3 | 2, dQ 3
-          if (wave < 4) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        } else if (ch == 2) {   // chunk 3 (X1) landed; younger: dQ 3, X2 3 | 2, dQ 3
-          if (wave < 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
+        // X = this wave's pieces of a chunk (3 | 2 by half), Kp = of a K tile (5 | 4), NQ = its dQ stores per chunk (by parity)
+        const int X = wave < 4 ? 3 : 2, Kp = wave < 4 ? 5 : 4;
+        const int NQ = (wave & 1) ? RingB<HD, true>::NST : RingB<HD, false>::NST;
+        if (ch == 1) vmcnt_wait(Kp + X + 2 * NQ);      // chunk 2 (X0) landed; younger: K(n+1), dQ, X1, dQ
+        else if (ch == 2) vmcnt_wait(X + 2 * NQ);      // chunk 3 (X1) landed; younger: dQ, X2, dQ
       } else if (ch == 1 || ch == 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the last item: nothing is issued behind it
       }
+      RING_STAMP(4);
       ATTN_BARRIER();   // dS^T is free for the next chunk; the next chunk's ring slot is complete
+      RING_STAMP(5);
     }
     // ---------------- dK, then dV, of the wave's keys through its own rows of the dS^T tile ----------------
     int le = lane0;
@@ -2219,17 +2295,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
     };
     stage_store(dk, scale, dbase + D);
     stage_store(dv, 1.f, dbase + 2 * D);
+    RING_STAMP(6);
     if (has_next) {
       // the wave's own rows of the next item have landed (and with them everything older: X3, K(n+1)); younger and still in
       // flight: the last chunk's dQ stores and the dK / dV row stores
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NI == 5) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      vmcnt_wait(((wave & 1) ? RingB<HD, true>::NST : RingB<HD, false>::NST) + 2 * NI);
       __builtin_amdgcn_sched_barrier(0);
       own_rows_finish(le, ld2 + (par ^ 1) * 512);
       base = nbase; gbase = ngbase; lbase = nlbase; dlbase = ndlbase; dbase = ndbase;
     }
+    RING_STAMP(7);
   }
+  if (STAMPS && (dbg & 4) && lane0 == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* dst = (unsigned long long*)dqkv + ((long)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = tacc[k];
+  }
+#undef RING_STAMP
 }
 
 int attn_fwd_oneshot() {   // REED_ATTN_FWD=oneshot: the round-1 forward also for T <= 256 (A/B)
@@ -2412,7 +2496,14 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
     REED_KLAUNCH(attn_bwd_ring_kernel<HD>, pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
                  (bf16*)dqkv, H, nitems, dbg);                                                                            \
   } while (0)
-    if (hd == 64) REED_BWD_RING(64);
+    if (hd == 72 && (dbg & 4)) {   // the stamped instantiation (diagnosis)
+      static int once = set_lds(attn_bwd_ring_kernel<72, true>, rlds);
+      if (once) return once;
+      REED_DELTA(72);
+      REED_LAUNCH_CHECK();
+      REED_KLAUNCH((attn_bwd_ring_kernel<72, true>), pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws,
+                   (bf16*)dqkv, H, nitems, dbg);
+    } else if (hd == 64) REED_BWD_RING(64);
     else REED_BWD_RING(72);
 #undef REED_BWD_RING
     REED_LAUNCH_CHECK();

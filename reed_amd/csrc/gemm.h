@@ -47,7 +47,6 @@ struct GemmArgs {
   long slab_stride;
   int act_variant;   // EPI_QGELU: 0 = QuickGELU (CLIP), 1 = GELU(erf) (timm / I-JEPA Mlp, nn.GELU)
   int tile_gm;   // gemm256: tile rows per XCD-local group of the workgroup -> tile map (set by launch256)
-  int stagger_ticks;   // gemm256wp: every other workgroup of an XCD starts this many 100 MHz ticks late (set by launch256wp)
 };
 
 int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t stream);

@@ -502,13 +502,9 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
   const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, runlen = q + (xcd < r ? 1 : 0);
   int p = s;
   if (p >= runlen) return;
-  // Phase stagger (experiment, REED_GEMM_STAGGER_US): every workgroup walks tiles of equal cost, so all 256 CUs run their K loops
-  // together and then their epilogues together — HBM idles under the K loops and saturates under the epilogues.  Starting the
-  // odd workgroups of each XCD half a tile late keeps half the chip in each phase.
-  if (a.stagger_ticks > 0 && (s & 1)) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-  }
+  // (Measured and dropped in round 4: starting every other workgroup of an XCD 6 / 12 / 18 us late, so that half the chip is in
+  // its K loops while the other half is in its epilogues — every shape of the block slower by about the delay itself, none
+  // faster: fwd proj 0.241 -> 0.246, fc1 0.678 -> 0.694, dgrad fc2 0.709 -> 0.727 ms at 12 us; gpurun_out/r4a/stagger.txt)
   int tm, tn;
   w_tile_of(run0 + p, ntm, ntn, a.tile_gm, tm, tn);
   bool first = true;
@@ -670,17 +666,6 @@ int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
   }
   GemmArgs b = a;
   b.tile_gm = GM;
-  {
-    // REED_GEMM_STAGGER_US=<us>[:<epi mask>]: late start of every other workgroup (bit e of the mask = epilogue id e; default all)
-    static int st_us = -1, st_mask = -1;
-    if (st_us < 0) {
-      const char* e = getenv("REED_GEMM_STAGGER_US");
-      st_us = e ? atoi(e) : 0;
-      const char* c = e ? strchr(e, ':') : nullptr;
-      st_mask = c ? atoi(c + 1) : 0x7FFFFFFF;
-    }
-    b.stagger_ticks = (st_us > 0 && ((st_mask >> EPI) & 1)) ? st_us * 100 : 0;
-  }
   REED_KLAUNCH((gemm256wp_kernel<LAY, EPI>), dim3(8 * wpx), dim3(256), LDS_W, stream, b);
   REED_LAUNCH_CHECK();
   *used = true;
