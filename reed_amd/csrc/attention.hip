@@ -18,6 +18,7 @@
 // 32 key rows (dK, dV); Q, K, V, dO stay resident in LDS (147 KiB) for both.
 #include <stdlib.h>
 
+#include <type_traits>
 #include <utility>
 
 #include "../../include/reed_hip.h"
@@ -692,6 +693,59 @@ __device__ __forceinline__ void pvu_all(unsigned vb, const bf16x8 (&pb)[2][8], f
   pvu_step<RB, 7, NS, NDT>(vb, pb, ot, vb2, va, seq);
 }
 
+// PV with the exponentials inside (FULL T = 256): P of 32-key step S + 1 is formed (16 v_exp, 16 v_fma, 8 v_cvt_pk per wave) and the
+// V^T fragments of step S + 1 are read while the matrix pipe works on step S — vector ALU beside MFMA inside one wave, and the
+// fp32 scores die step by step instead of all before the product (the allocator's peak).  SUM: row sums accumulated here (head
+// sizes without a spare V column).
+template <bool SUM>
+__device__ __forceinline__ void px_make(const f32x4 (&st)[2][16], int s, const float (&mneg)[2], float sc2, bf16x8 (&pb)[2],
+                                        float (&sum)[2], bool noexp) {
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    f32x4 a, b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = __builtin_fmaf(st[qt][2 * s][r], sc2, -mneg[qt]), y = __builtin_fmaf(st[qt][2 * s + 1][r], sc2, -mneg[qt]);
+      if (!noexp) { x = __builtin_amdgcn_exp2f(x); y = __builtin_amdgcn_exp2f(y); }
+      a[r] = x;
+      b[r] = y;
+      if (SUM) sum[qt] += x + y;
+    }
+    pb[qt] = pack2(a, b);
+  }
+}
+template <int RB, int S, int NDT, bool SUM, int... DTS>
+__device__ __forceinline__ void pvx_step(unsigned vb, const f32x4 (&st)[2][16], const float (&mneg)[2], float sc2, float (&sum)[2],
+                                         bool noexp, f32x4 (&ot)[2][NDT], bf16x8 (&pc)[2], bf16x8 (&pn)[2], bf16x8 (&cur)[NDT],
+                                         bf16x8 (&nxt)[NDT], std::integer_sequence<int, DTS...> seq) {
+  if constexpr (S + 1 < 8) {
+    pvu_load<RB, S + 1, NDT>(vb, nxt, seq);
+    px_make<SUM>(st, S + 1, mneg, sc2, pn, sum, noexp);
+  }
+  if constexpr (S == 0)
+    ((ot[0][DTS] = MFMA(cur[DTS], pc[0], zero4()), ot[1][DTS] = MFMA(cur[DTS], pc[1], zero4())), ...);
+  else
+    ((ot[0][DTS] = MFMA(cur[DTS], pc[0], ot[0][DTS]), ot[1][DTS] = MFMA(cur[DTS], pc[1], ot[1][DTS])), ...);
+  ATTN_LDS_WAIT();
+}
+template <int RB, int NDT, bool SUM>
+__device__ __forceinline__ void pvx_all(unsigned vb, const f32x4 (&st)[2][16], const float (&mneg)[2], float sc2, float (&sum)[2],
+                                        bool noexp, f32x4 (&ot)[2][NDT]) {
+  constexpr auto seq = std::make_integer_sequence<int, NDT>{};
+  bf16x8 va[NDT], vb2[NDT], pa[2], pb2[2];
+  pvu_load<RB, 0, NDT>(vb, va, seq);
+  px_make<SUM>(st, 0, mneg, sc2, pa, sum, noexp);
+  ATTN_LDS_WAIT();
+  pvx_step<RB, 0, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
+  pvx_step<RB, 1, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
+  pvx_step<RB, 2, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
+  pvx_step<RB, 3, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
+  pvx_step<RB, 4, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
+  pvx_step<RB, 5, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
+  pvx_step<RB, 6, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
+  pvx_step<RB, 7, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
+}
+
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read128_off(unsigned a) {
   u32x4 r;
@@ -755,12 +809,13 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 
 // DBGK: a diagnosis instantiation that takes `dbg` (bit 0: no S products, 1: no exponentials, 2: no PV products, 3: the output
 // stores dropped by the range check, 4: every tile load an empty descriptor); the product instantiations ignore it
-template <int HD, bool FULL, bool DBGK>
+template <int HD, bool FULL, bool DBGK, bool STAG>
 __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                              float* __restrict__ lse, int T, int H, int nitems, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
   constexpr bool ONES = (HD == 72);   // d = 72..79 is the zero pad of the fifth output tile: column 72 carries the row sums
+  constexpr bool PVX = FULL && HD != 80;   // exponentials inside the PV product (pvx_all); hd 80's allocation spills with it
   if (!DBGK) dbg = 0;
   // dbg bit 5 (DBGK only): shader-clock time per phase, summed over the wave's items in registers and written over the start
   // of `lse` when the wave is done ([workgroup][wave][10] x u64; tools/r4/fwd_stamps.py) — no memory instruction inside the loop
@@ -776,6 +831,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   const int tid = threadIdx.x;
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // STAG: the second-dispatched half of the workgroup (waves 4..7, the SIMD partners of waves 0..3) runs one phase late:
+  // after the barrier that ends PV(n) it computes S(n+1) FIRST and only then stores item n, while waves 0..3 store first.
+  // Without it all eight waves leave that barrier into the same 17 vector-memory instructions each (V(n+1), the O rows, Q(n+2))
+  // — the CU's memory path takes them one at a time, the waves sit in instruction issue (4.3 k cycles for waves 0..3, 8.1 k
+  // for waves 4..7 of a 21.3 k-cycle item: fwd_stamps.py) and the matrix pipe idles; now one wave of each SIMD multiplies
+  // while its partner is in the queue.  (O is normalised and staged in LDS before S(n+1): only the two log-sum-exp values
+  // stay in registers across it.)
+  const bool late = STAG && wave >= 4;
   const int D = H * HD;
   const long tok = 3l * D;
   const int tokb = (int)(tok * 2);
@@ -803,34 +866,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   };
   auto plus = [](const bf16* p, long n) -> const bf16* { return p ? p + n : nullptr; };
   const int G = gridDim.x;
-  int it = xcd_contiguous(blockIdx.x, G);   // the 16 heads of a sample run on one XCD at about the same time
-  {
-    const bf16* b0 = base_of(it);
-    issue(Qw, b0);
-    issue(Kb + wave * 32 * ROWF, plus(b0, D));
-    issue(Kb + TILE_F + wave * 32 * ROWF, plus(base_of(it + G), D));
+  const int nsub = FULL ? 4 : (T + 63) >> 6;
+  // "stores(-1)" + V of the first item: seven dropped stores, so that the counted waits hold from item 0 (distinct,
+  // non-adjacent offsets and values: identical ones are merged into one instruction — tools/r4/check_isa.py counts them)
+  auto first_v_and_stores = [&](const bf16* b0) {
     issue(Vw, plus(b0, 2 * D));
     const __amdgpu_buffer_rsrc_t none = mk_rsrc(nullptr, 0);
-    // "stores(-1)": seven dropped stores, so that the counts below hold from item 0 (distinct, non-adjacent offsets and
-    // values: identical ones are merged into one instruction — the ISA must show seven, tools/r4/check_isa.py)
 #pragma unroll
     for (int k = 0; k < 7; ++k) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(k + lane0), none, DMA_OOB - 256 * k, 0, 0);
-    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // Q, K of the first item (younger: K of the second, V, the 7 stores)
-    ATTN_BARRIER();
-  }
-  constexpr int NS = 8;
-  const int nsub = FULL ? 4 : (T + 63) >> 6;
-  int par = 0;
-  for (; it < nitems; it += G, par ^= 1) {
-    const int b = it / H, h = it - b * H;
-    // lane-derived values are re-derived per item from an opaque copy of the lane id (hoisted, they are spilled around the
-    // loop and the reload's compiler-made vmcnt(0) drains the DMA queue)
+  };
+  f32x4 st[2][16];   // S^T of the item in hand: for the late half it is computed at the end of the previous iteration
+  // ---- Q(n): own patch, own wait; then S^T(n) = K(n) Q(n)^T from K buffer `kpar` (landed: the barrier that ended item n-1).
+  // with_first: the late half's first call also issues V and the seven stores of the prologue, BEHIND Q(n+1) (its issue order)
+  auto q_and_s = [&](int n, int kpar, bool with_first) {
     int lane = lane0;
-    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(lane));   // per-item copy of the lane id: hoisted lane-derived values are spilled around the loop
     const int i = lane & 15, g = lane >> 4;
-    const char* Kt = Kb + par * TILE_F;
-    if (DBGK && (dbg & 32)) tprev = __builtin_amdgcn_s_memtime();
-    // ---------------- Q(n): own patch, own wait ----------------
+    const char* Kt = Kb + kpar * TILE_F;
     asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(0);
@@ -849,11 +901,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       ATTN_LDS_WAIT();
       if (HD % 32 != 0 && g >= 2) { qf[0][KS - 1] = zero_frag(); qf[1][KS - 1] = zero_frag(); }
     }
-    issue(Qw, base_of(it + G));
+    issue(Qw, base_of(n + G));
+    if (with_first) first_v_and_stores(base_of(n));
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(1);
-    // ---------------- S^T = K Q^T (K(n) landed: the barrier that ended item n-1) ----------------
-    f32x4 st[2][16];
     if (DBGK && (dbg & 1)) {
 #pragma unroll
       for (int kt = 0; kt < 16; ++kt) st[0][kt] = st[1][kt] = zero4();
@@ -888,6 +939,90 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       }
     }
     ATTN_STAMP(2);
+  };
+  // ---- output of item n in two parts.  stage_item: normalise, round and write O into the wave's own rows of the V tile (dead
+  // after the barrier that ends PV) — the accumulators are free afterwards; store_item: whole 144-byte row pieces read back and
+  // stored, V(n+1) into the rows just read back, in FRONT of the stores.  The late half runs S(n+1) between the two.
+  float lsev[2];
+  auto stage_item = [&](const f32x4 (&ot)[2][DT], const float (&mrow)[2], const float (&lrow)[2]) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float l = lrow[qt];
+      if (ONES) l = __shfl(ot[qt][DT - 1][0], 32 + i, 64);   // O^T row 72 (lanes g = 2, element 0) = sum_k P[q][k]
+      const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        const u32x2 v = {pk2(ot[qt][dt][0] * inv, ot[qt][dt][1] * inv), pk2(ot[qt][dt][2] * inv, ot[qt][dt][3] * inv)};
+        if (16 * dt + 16 <= HD || d < HD) *(u32x2*)(Vw + (16 * qt + i) * ROWF + d * 2) = v;   // (only hd 72's fifth tile is partial)
+      }
+      lsev[qt] = mrow[qt] * LN2 + __logf(l);
+    }
+  };
+  auto store_item = [&](int n) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+    const int b = n / H, h = n - b * H;
+    // exactly 5 + 2 buffer stores per wave and item (counted by the waits); rows >= T and the lanes past the 32 x NCH chunks
+    // fall outside the descriptors and are dropped by the range check
+    const bool drop = DBGK && (dbg & 8);
+    const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(drop ? nullptr : o + (long)b * T * D + h * HD, tile_window<HD>(T, D * 2));
+    const __amdgpu_buffer_rsrc_t rsL = mk_rsrc((lse && !drop) ? lse + ((long)b * H + h) * T : nullptr, (long)T * 4);
+    constexpr int NQ = 32 * NCH;
+    u32x4 piece[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int qi = min(lane + 64 * k, NQ - 1);
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      piece[k] = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vw + rr * ROWF + c * 16)));
+    }
+    ATTN_LDS_WAIT();
+    issue(Vw, plus(base_of(n + G), 2 * D));
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int qi = lane + 64 * k;
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsO, qi < NQ ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
+                                            g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
+    ATTN_STAMP(9);
+  };
+
+  int it = xcd_contiguous(blockIdx.x, G);   // the 16 heads of a sample run on one XCD at about the same time
+  {
+    const bf16* b0 = base_of(it);
+    issue(Qw, b0);
+    issue(Kb + wave * 32 * ROWF, plus(b0, D));
+    issue(Kb + TILE_F + wave * 32 * ROWF, plus(base_of(it + G), D));
+    if (late) {
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // Q, K of the first item (younger: K of the second)
+    } else {
+      first_v_and_stores(b0);
+      asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // Q, K of the first item (younger: K of the second, V, the 7 stores)
+    }
+    ATTN_BARRIER();
+  }
+  // Two copies of the item loop, one per half of the workgroup, selected once (a per-iteration branch on `late` made the
+  // register allocator spill: scratch traffic is vector-memory traffic and would break the counted waits).  Early half: S(n) at
+  // the top of the iteration.  Late half: the loop is rotated — S(n) is in hand at the top (st), S(n+1) is formed at the bottom
+  // between the staging and the stores of item n.  Both copies execute the same two barriers per item.
+  auto item_loop = [&](auto late_c) {
+  constexpr bool LATE = decltype(late_c)::value;
+  if (DBGK && (dbg & 32)) tprev = __builtin_amdgcn_s_memtime();
+  if (LATE && it < nitems) q_and_s(it, 0, true);
+  int par = 0;
+  for (; it < nitems; it += G, par ^= 1) {
+    if (!LATE) q_and_s(it, par, false);
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
     // ---------------- softmax over the keys, in registers ----------------
     if (!FULL) {
 #pragma unroll
@@ -918,6 +1053,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mneg = mx * sc2;   // the scale is positive: max of the scaled scores
       float sum = 0.f;
+      mrow[qt] = mneg;
+      lrow[qt] = 0.f;
+      if (PVX) continue;             // the exponentials are formed inside the PV product (pvx_all)
 #pragma unroll
       for (int kt = 0; kt < 16; ++kt) {
 #pragma unroll
@@ -939,7 +1077,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     }
     ATTN_STAMP(3);
     // ---------------- V(n) landed; every wave is past S(n): K(n+2) may overwrite K(n) ----------------
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    // younger than V(n): stores(n-1) 7 [+ Q(n+1) 5 for the early half, whose Q(n+1) is issued after V(n)]
+    if (LATE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(4);
     if (ONES && lane < 32) *(bf16*)(Vw + lane * ROWF + HD * 2) = (bf16)1.0f;   // own rows, behind own pieces: the ones column
@@ -954,8 +1094,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       if (DBGK && (dbg & 4)) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) ot[0][dt] = ot[1][dt] = f32x4{1.f, 1.f, 1.f, 1.f};
+      } else if (FULL && !PVX) {
+        pvu_all<ROWF, 8, DT>(vb, pb, ot);
       } else if (FULL) {
-        pvu_all<ROWF, NS, DT>(vb, pb, ot);
+        pvx_all<ROWF, DT, !ONES>(vb, st, mrow, sc2, lrow, DBGK && (dbg & 2), ot);
+        if (!ONES) {
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            lrow[qt] += __shfl_xor(lrow[qt], 16, 64);
+            lrow[qt] += __shfl_xor(lrow[qt], 32, 64);
+          }
+        }
       } else {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -971,50 +1120,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     ATTN_STAMP(7);
     ATTN_BARRIER();
     ATTN_STAMP(8);
-    // ---------------- output: staged in the wave's own rows of the V tile, whole 144-byte row pieces out ----------------
-    float lsev[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float l = lrow[qt];
-      if (ONES) l = __shfl(ot[qt][DT - 1][0], 32 + i, 64);   // O^T row 72 (lanes g = 2, element 0) = sum_k P[q][k]
-      const float inv = __builtin_amdgcn_rcpf(l);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * g;
-        const u32x2 v = {pk2(ot[qt][dt][0] * inv, ot[qt][dt][1] * inv), pk2(ot[qt][dt][2] * inv, ot[qt][dt][3] * inv)};
-        if (16 * dt + 16 <= HD || d < HD) *(u32x2*)(Vw + (16 * qt + i) * ROWF + d * 2) = v;   // (only hd 72's fifth tile is partial)
-      }
-      lsev[qt] = mrow[qt] * LN2 + __logf(l);
-    }
-    {
-      // exactly 5 + 2 buffer stores per wave and item (counted by the waits above); rows >= T and the lanes past the
-      // 32 x NCH chunks fall outside the descriptors and are dropped by the range check
-      const bool drop = DBGK && (dbg & 8);
-      const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(drop ? nullptr : o + (long)b * T * D + h * HD, tile_window<HD>(T, D * 2));
-      const __amdgpu_buffer_rsrc_t rsL = mk_rsrc((lse && !drop) ? lse + ((long)b * H + h) * T : nullptr, (long)T * 4);
-      constexpr int NQ = 32 * NCH;
-      u32x4 piece[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int qi = min(lane + 64 * k, NQ - 1);
-        const int rr = qi / NCH, c = qi - rr * NCH;
-        piece[k] = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vw + rr * ROWF + c * 16)));
-      }
-      ATTN_LDS_WAIT();
-      issue(Vw, plus(base_of(it + G), 2 * D));   // V(n+1) into the rows just read back, in front of the stores
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int qi = lane + 64 * k;
-        const int rr = qi / NCH, c = qi - rr * NCH;
-        __builtin_amdgcn_raw_buffer_store_b128(piece[k], rsO, qi < NQ ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
-      }
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
-                                              g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
-    }
-    ATTN_STAMP(9);
+    stage_item(ot, mrow, lrow);
+    asm volatile("" : "+v"(lsev[0]), "+v"(lsev[1]));   // materialised here: nothing of the accumulators stays live across S(n+1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (LATE && it + G < nitems) q_and_s(it + G, par ^ 1, false);   // S(n+1) while the partner waves store item n
+    store_item(it);
   }
+  };
+  if (late) item_loop(std::true_type{});
+  else item_loop(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills of the items past the end: LDS stays allocated until they land
   if (DBGK && (dbg & 32) && lse && lane0 == 0) {
     unsigned long long* dst = (unsigned long long*)lse + ((long)blockIdx.x * 8 + wave) * 10;
@@ -2358,17 +2472,21 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
     static const bool r2 = getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 'r';
     static const int fdbg = getenv("REED_ATTN_FWD_DBG") ? atoi(getenv("REED_ATTN_FWD_DBG")) : 0;
     if (!r2) {
-#define LAUNCH_FWD256P(HD, FULL, DBGK)                                                                                 \
+#define LAUNCH_FWD256P(HD, FULL, DBGK, STAG)                                                                           \
     do {                                                                                                               \
-      static int once = set_lds(attn_fwd256p_kernel<HD, FULL, DBGK>, lds);                                             \
+      static int once = set_lds(attn_fwd256p_kernel<HD, FULL, DBGK, STAG>, lds);                                       \
       if (once) return once;                                                                                           \
-      REED_KLAUNCH((attn_fwd256p_kernel<HD, FULL, DBGK>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,  \
-                   (bf16*)o, lse, T, H, nitems, fdbg);                                                                 \
+      REED_KLAUNCH((attn_fwd256p_kernel<HD, FULL, DBGK, STAG>), grid, dim3(512), lds, (hipStream_t)stream,              \
+                   (const bf16*)qkv, (bf16*)o, lse, T, H, nitems, fdbg);                                               \
     } while (0)
-      if (fdbg && hd == 72 && T == 256) LAUNCH_FWD256P(72, true, true);
-      else if (hd == 64) { if (T == 256) LAUNCH_FWD256P(64, true, false); else LAUNCH_FWD256P(64, false, false); }
-      else if (hd == 72) { if (T == 256) LAUNCH_FWD256P(72, true, false); else LAUNCH_FWD256P(72, false, false); }
-      else { if (T == 256) LAUNCH_FWD256P(80, true, false); else LAUNCH_FWD256P(80, false, false); }
+      // REED_ATTN_FWD=nostag: the round-4 kernel without the half-workgroup stagger (A/B)
+      static const bool nostag = getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 'n';
+      if (fdbg && hd == 72 && T == 256) { if (nostag) LAUNCH_FWD256P(72, true, true, false); else LAUNCH_FWD256P(72, true, true, true); }
+      else if (nostag && hd == 72 && T == 256) LAUNCH_FWD256P(72, true, false, false);
+      // the stagger is instantiated where its late-half loop allocates without scratch (hd 72 at T = 256: SiT-XL; tools/r4/check_isa.py)
+      else if (hd == 64) { if (T == 256) LAUNCH_FWD256P(64, true, false, false); else LAUNCH_FWD256P(64, false, false, false); }
+      else if (hd == 72) { if (T == 256) LAUNCH_FWD256P(72, true, false, true); else LAUNCH_FWD256P(72, false, false, false); }
+      else { if (T == 256) LAUNCH_FWD256P(80, true, false, false); else LAUNCH_FWD256P(80, false, false, false); }
 #undef LAUNCH_FWD256P
       REED_LAUNCH_CHECK();
       return REED_OK;

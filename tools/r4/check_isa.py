@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """attn_fwd256p_kernel's waits are counted (s_waitcnt vmcnt(N)): every instantiation must issue exactly 20 LDS-DMA pieces and 7
-stores before its item loop and 15 + 7 per item.  Compiles csrc/attention.hip to ISA and counts (the compiler merges identical
-stores and could one day split or fuse others).  usage: python tools/r4/check_isa.py"""
+stores before its item loop and 15 + 7 per item (the staggered instantiations carry two copies of the loop, one per half of
+the workgroup: 60 / 28 in the text), in the order the waits assume, and must not touch scratch (a spill is a vector-memory
+instruction the counts do not know).  Compiles csrc/attention.hip to ISA and counts (the compiler merges identical stores and
+could one day split or fuse others).  usage: python tools/r4/check_isa.py"""
 import os
 import re
 import subprocess
@@ -22,7 +24,9 @@ for i in range(1, len(parts), 2):
     body = parts[i + 1].split("s_endpgm")[0]
     dma, st = len(re.findall(r"buffer_load_dwordx4[^\n]* lds", body)), len(re.findall(r"buffer_store", body))
     waits = re.findall(r"vmcnt\((\d+)\)", body)
-    ok = dma == 35 and st == 14 and waits == ["17", "17", "12", "22", "0"] and "scratch_" not in body
+    stag = re.search(r"ILi\d+ELb[01]ELb[01]ELb1E", parts[i]) is not None
+    want = (60, 28, ["17", "5", "17", "12", "22", "17", "7", "22", "17", "0"]) if stag else (35, 14, ["17", "17", "12", "22", "0"])
+    ok = (dma, st, waits) == want and "scratch_" not in body
     bad += not ok
     print(("ok  " if ok else "BAD ") + parts[i][:60], "dma", dma, "stores", st, "waits", waits)
 sys.exit(1 if bad else 0)
