@@ -839,6 +839,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   // while its partner is in the queue.  (O is normalised and staged in LDS before S(n+1): only the two log-sum-exp values
   // stay in registers across it.)
   const bool late = STAG && wave >= 4;
+  if (DBGK && (dbg & 64) && wave >= 4) __builtin_amdgcn_s_setprio(1);    // experiment: static priority for the younger half
+  if (DBGK && (dbg & 128) && wave < 4) __builtin_amdgcn_s_setprio(1);    // (control: for the older half)
   const int D = H * HD;
   const long tok = 3l * D;
   const int tokb = (int)(tok * 2);
@@ -2154,6 +2156,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
   const int r0 = wave * 32;
+  if ((dbg & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);    // experiment (REED_ATTN_KSP_DBG bit 3): static priority for waves 4..7
+  if ((dbg & 16) && wave < 4) __builtin_amdgcn_s_setprio(1);    // (bit 4: for waves 0..3)
   // STAMPS (diagnosis instantiation, dbg bit 2): shader-clock time per phase summed over the wave's items in registers, written over
   // the start of dqkv when the wave is done ([workgroup][wave][8] x u64; tools/r4/bwd_stamps.py); no memory instruction in the loops
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -2479,8 +2483,10 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
       REED_KLAUNCH((attn_fwd256p_kernel<HD, FULL, DBGK, STAG>), grid, dim3(512), lds, (hipStream_t)stream,              \
                    (const bf16*)qkv, (bf16*)o, lse, T, H, nitems, fdbg);                                               \
     } while (0)
-      // REED_ATTN_FWD=nostag: the round-4 kernel without the half-workgroup stagger (A/B)
-      static const bool nostag = getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 'n';
+      // REED_ATTN_FWD=stag: the half-workgroup stagger (measured neutral at b = 256: 180.1 / 182.9 against 185.9 / 175.8 us on
+      // one box, 20.5 k against 21.4 k cycles per item — the vector-memory issue queue is what the waves wait in either way;
+      // kept for A/B, off by default)
+      static const bool nostag = !(getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 's');
       if (fdbg && hd == 72 && T == 256) { if (nostag) LAUNCH_FWD256P(72, true, true, false); else LAUNCH_FWD256P(72, true, true, true); }
       else if (nostag && hd == 72 && T == 256) LAUNCH_FWD256P(72, true, false, false);
       // the stagger is instantiated where its late-half loop allocates without scratch (hd 72 at T = 256: SiT-XL; tools/r4/check_isa.py)
