@@ -30,6 +30,8 @@ bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits);
 int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm256w.hip: 4 waves x 128x128
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
+bool reed_gemm128c_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm128c.hip: 128x256 tiles, two workgroups per CU
+int reed_gemm128c_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 
 namespace {
 using namespace gemm_detail;
@@ -274,6 +276,15 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
+  // the two-workgroups-per-CU kernel (gemm128c.hip): force_tile 129 wherever it is built; REED_GEMM128C=<mask> (bit e = epilogue
+  // id e) selects it for those epilogues on problems of at least 16384 rows
+  {
+    static int cmask = -1;
+    if (cmask < 0) { const char* e = getenv("REED_GEMM128C"); cmask = e ? atoi(e) : 0; }
+    if ((g_force_tile == 129 || (g_force_tile == 0 && ((cmask >> epi) & 1) && a.M >= 16384 && want != EPI_BF16_DOT)) &&
+        reed_gemm128c_eligible(layout, epi, a, splits) && want != EPI_BF16_DOT)
+      return reed_gemm128c_launch(layout, epi, a, stream);
+  }
   if ((g_force_tile == 257 || g_force_tile == 258) && reed_gemm256w_eligible(layout, epi, a, splits))
     return reed_gemm256w_launch(layout, want, a, stream);   // 257: one-shot form, 258: persistent form wherever it applies
   if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits)))) {
