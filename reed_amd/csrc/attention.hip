@@ -2027,6 +2027,102 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
   }
 }
 
+// Phase A of the ring kernel (round 4).  ring_a_load<HD, QO>: the Q and dO row fragments of the 16-query tile that starts at row QO
+// of the ring slot (lane (i, g): row QO + i, columns ks * 32 + 8 g .. + 7; the k-step that covers columns 64..95 of a 72-wide head
+// reads 64..79 again in lanes g >= 2 — qbw / gbw — whose partner slots in kf / vf are zero).
+template <int HD, int QO>
+__device__ __forceinline__ void ring_a_load(unsigned qb, unsigned qbw, unsigned gb, unsigned gbw, bf16x8 (&qa)[Cfg<HD>::KS],
+                                            bf16x8 (&ga)[Cfg<HD>::KS]) {
+  constexpr int KS = Cfg<HD>::KS;
+  qa[0] = lds_read128_off<QO * ROWF>(qb);
+  ga[0] = lds_read128_off<QO * ROWF>(gb);
+  qa[1] = lds_read128_off<QO * ROWF + 64>(qb);
+  ga[1] = lds_read128_off<QO * ROWF + 64>(gb);
+  if constexpr (KS == 3) {
+    qa[2] = lds_read128_off<QO * ROWF + 128>(HD % 32 != 0 ? qbw : qb);
+    ga[2] = lds_read128_off<QO * ROWF + 128>(HD % 32 != 0 ? gbw : gb);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void ring_a_sdp(const bf16x8 (&qa)[Cfg<HD>::KS], const bf16x8 (&ga)[Cfg<HD>::KS],
+                                           const bf16x8 (&kf)[2][Cfg<HD>::KS], const bf16x8 (&vf)[2][Cfg<HD>::KS], f32x4 (&st)[2],
+                                           f32x4 (&dp)[2]) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    st[ct] = MFMA(qa[0], kf[ct][0], zero4());
+    dp[ct] = MFMA(ga[0], vf[ct][0], zero4());
+  }
+#pragma unroll
+  for (int ks = 1; ks < Cfg<HD>::KS; ++ks)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      st[ct] = MFMA(qa[ks], kf[ct][ks], st[ct]);
+      dp[ct] = MFMA(ga[ks], vf[ct][ks], dp[ct]);
+    }
+}
+// one 32-query half (QH = 0 / 1) of a chunk: on entry qa[0] / ga[0] hold its first tile's fragments (read and waited for)
+template <int HD, int QH>
+__device__ __forceinline__ void ring_a_half(unsigned qb, unsigned qbw, unsigned gb, unsigned gbw, bf16x8 (&qa)[2][Cfg<HD>::KS],
+                                            bf16x8 (&ga)[2][Cfg<HD>::KS], const bf16x8 (&kf)[2][Cfg<HD>::KS],
+                                            const bf16x8 (&vf)[2][Cfg<HD>::KS], f32x4 (&dk)[2][Cfg<HD>::DT], f32x4 (&dv)[2][Cfg<HD>::DT],
+                                            char* St, const char* Qs, const char* Gs, const float* lse2, const float* dlt, float sc2,
+                                            int q0c, int r0, int lane) {
+  constexpr int DT = Cfg<HD>::DT;
+  const int i = lane & 15, g = lane >> 4;
+  const int ql = QH * 32, qq0 = q0c + ql;
+  f32x4 st[2][2], dp[2][2];
+  ring_a_load<HD, QH * 32 + 16>(qb, qbw, gb, gbw, qa[1], ga[1]);   // the second tile's fragments fly under the first tile's MFMAs
+  ring_a_sdp<HD>(qa[0], ga[0], kf, vf, st[0], dp[0]);
+  ATTN_LDS_WAIT();
+  f32x4 lq4[2], dl4[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
+    dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
+  }
+  ring_a_sdp<HD>(qa[1], ga[1], kf, vf, st[1], dp[1]);
+  bf16x8 pb[2], dsb[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    f32x4 p0, p1, s0, s1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
+      p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
+      s0[r] = p0[r] * (dp[0][ct][r] - dl4[0][r]);
+      s1[r] = p1[r] * (dp[1][ct][r] - dl4[1][r]);
+    }
+    pb[ct] = pack2(p0, p1);
+    dsb[ct] = pack2(s0, s1);
+    char* sp = St + (r0 + 16 * ct + i) * ROWB + (ql + 4 * g) * 2;
+    *(bf16x4*)sp = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
+    *(bf16x4*)(sp + 32) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
+  }
+  // dO^T / Q^T fragments of the half (transposed reads), then — for the first half — the next half's first tile, all in flight
+  // under the MFMAs of the previous group
+#pragma unroll
+  for (int d0 = 0; d0 < DT; d0 += 3) {
+    bf16x8 gtf[3], qtf[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (d0 + k < DT) {
+        gtf[k] = frag_trT_a<ROWF>(Gs, ql, 16 * (d0 + k), lane);
+        qtf[k] = frag_trT_a<ROWF>(Qs, ql, 16 * (d0 + k), lane);
+      }
+    if (QH == 0 && d0 + 3 >= DT) ring_a_load<HD, 32>(qb, qbw, gb, gbw, qa[0], ga[0]);
+    ATTN_LDS_WAIT();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (d0 + k < DT) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          dv[ct][d0 + k] = MFMA(gtf[k], pb[ct], dv[ct][d0 + k]);
+          dk[ct][d0 + k] = MFMA(qtf[k], dsb[ct], dk[ct][d0 + k]);
+        }
+      }
+  }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform n that is only known per wave class (the instruction takes an immediate)
 __device__ __forceinline__ void vmcnt_wait(int n) {
   switch (n) {
@@ -2277,72 +2373,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       const char* Qs = Qr + (ch & 1) * CHB;
       const char* Gs = Gr + (ch & 1) * CHB;
       // ---------------- phase A: this wave's 32 keys x the chunk's 64 queries ----------------
-#pragma unroll 1
-      for (int qh = 0; qh < ((dbg & 1) ? 0 : 2); ++qh) {   // dbg bit 0 (diagnosis only): skip phase A
-        const int ql = qh * 32;                // row inside the ring slot
-        const int qq0 = ch * 64 + ql;          // query index inside the item
-        f32x4 st[2][2], dp[2][2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            // (hd 72, last k-step: columns 64..79 exist in a 160-byte row, 72..79 zero; lanes g >= 2 re-read them — their
-            // partner slots in kf / vf are zero)
-            bf16x8 qa = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Qs, ql + 16 * qt, ks, lane) : frag_rows_f<false>(Qs, ql + 16 * qt, ks, lane);
-            bf16x8 ga = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Gs, ql + 16 * qt, ks, lane) : frag_rows_f<false>(Gs, ql + 16 * qt, ks, lane);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-              st[qt][ct] = MFMA(qa, kf[ct][ks], st[qt][ct]);
-              dp[qt][ct] = MFMA(ga, vf[ct][ks], dp[qt][ct]);
-            }
-          }
-        f32x4 lq4[2], dl4[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
-          dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
-        }
-        bf16x8 pb[2], dsb[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          f32x4 p0, p1, s0, s1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
-            p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
-            s0[r] = p0[r] * (dp[0][ct][r] - dl4[0][r]);
-            s1[r] = p1[r] * (dp[1][ct][r] - dl4[1][r]);
-          }
-          pb[ct] = pack2(p0, p1);
-          dsb[ct] = pack2(s0, s1);
-          char* sp = St + (r0 + 16 * ct + i) * ROWB + (ql + 4 * g) * 2;
-          *(bf16x4*)sp = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
-          *(bf16x4*)(sp + 32) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int d0 = 0; d0 < DT; d0 += 3) {
-          bf16x8 gtf[3], qtf[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            if (d0 + k < DT) {
-              gtf[k] = frag_trT_a<ROWF>(Gs, ql, 16 * (d0 + k), lane);
-              qtf[k] = frag_trT_a<ROWF>(Qs, ql, 16 * (d0 + k), lane);
-            }
-          ATTN_LDS_WAIT();
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            if (d0 + k < DT) {
-#pragma unroll
-              for (int ct = 0; ct < 2; ++ct) {
-                dv[ct][d0 + k] = MFMA(gtf[k], pb[ct], dv[ct][d0 + k]);
-                dk[ct][d0 + k] = MFMA(qtf[k], dsb[ct], dk[ct][d0 + k]);
-              }
-            }
-        }
+      // Round 4: the two 32-query halves are unrolled and their LDS reads run ahead of the matrix work — the Q / dO row fragments
+      // of the second 16-query tile are read (inline asm, compile-time offsets from one lane base) while the 12 S / dP MFMAs of
+      // the first issue, and the first tile's fragments of the NEXT half are read before the 20 dV / dK MFMAs of this one.  In round
+      // 3 every group of four fragment reads was waited for right before its four MFMAs (four exposed LDS round trips per half).
+      if (!(dbg & 1)) {   // dbg bit 0 (diagnosis only): skip phase A
+        const unsigned qb = lds_addr(Qs + i * ROWF + 16 * g), gb = lds_addr(Gs + i * ROWF + 16 * g);
+        const unsigned qbw = qb - ((HD % 32 != 0 && g >= 2) ? 32 : 0), gbw = gb - ((HD % 32 != 0 && g >= 2) ? 32 : 0);
+        bf16x8 qa[2][KS], ga[2][KS];   // [set][ks]: set 0 = the 16-query tile in the matrix pipe, set 1 = the one being read
+        ring_a_load<HD, 0>(qb, qbw, gb, gbw, qa[0], ga[0]);
+        ATTN_LDS_WAIT();
+        ring_a_half<HD, 0>(qb, qbw, gb, gbw, qa, ga, kf, vf, dk, dv, St, Qs, Gs, lse2, dlt, sc2, ch * 64, r0, lane);
+        ring_a_half<HD, 1>(qb, qbw, gb, gbw, qa, ga, kf, vf, dk, dv, St, Qs, Gs, lse2, dlt, sc2, ch * 64, r0, lane);
       }
       RING_STAMP(1);
       ATTN_BARRIER();   // dS^T of the chunk complete; the ring slot is released
