@@ -43,7 +43,7 @@ class Engine:
         self.tap_depth = [model.encoder_depth if (zt == "i" or not split) else model.encoder_depth_text
                           for zt in model.z_types]
         self.reducer = None      # set by reed_amd.parallel.GradReducer
-        self._dot_delta = {}     # token count -> the dO GEMM of this shape has the head-dot epilogue (ops.dgrad_with_head_dots)
+        self._dot_delta = {}     # (tokens, operand type, reducing, forced tile) -> the dO GEMM has the head-dot epilogue
         self._ws = None
         self._named = None       # [(name, parameter)] and the first trainable parameter, cached for backward
         self._sentinel = None
@@ -376,7 +376,15 @@ class Engine:
         group_wgrad = ops.wgrad_group_fits([(D, Hm), (Hm, D), (D, D), (3 * D, D)])
         nws = ops.attention_bwd_ws_floats(B, T, H)       # delta = rowsum(dO * O) of the persistent attention backward
         attn_ws = f32(nws) if nws else None
-        dot_delta = self._dot_delta if os.environ.get("REED_ATTN_DP", "1") != "0" and hdt != torch.float32 else {M: False}
+        # the answer of the library ("this shape's dO GEMM has the head-dot epilogue") depends on which kernel the GEMM runs on:
+        # the token count, the operand type, whether gradient buckets are being reduced beside this backward (the library then
+        # keeps off the persistent kernels) and a forced tile — all in the key (a 1002 seen once under one of
+        # them was remembered for the rest of the run under the token count alone).  With REED_ATTN_BWD / REED_ATTN_BWD_W4 set
+        # (the A/B switches of the other backward kernels, honoured by reed_attention_bwd_ws only) the fused path is skipped.
+        dkey = (M, str(hdt), self.reducer is not None and self.reducer.active(), ops.gemm_forced_tile())
+        ab = os.environ.get("REED_ATTN_BWD") is not None or os.environ.get("REED_ATTN_BWD_W4", "0") == "1"
+        dot_delta = (self._dot_delta if os.environ.get("REED_ATTN_DP", "1") != "0" and hdt != torch.float32 and not ab
+                     else {dkey: False})
         side = None
         if self.wgrad_stream or (self.wgrad_stream is None and M <= self.wgrad_stream_max_tokens):
             if self._side is None:
@@ -515,9 +523,9 @@ class Engine:
             # per-head partial dot products with O (12 MB instead of a 302 MB row pass over dO and O at b = 256); where this
             # shape's GEMM kernel has no such epilogue (False, decided once per token count) the plain store + the row kernel
             fused = False
-            if dot_delta.get(M, True) and attn_ws is not None and T <= 256:
+            if dot_delta.get(dkey, True) and attn_ws is not None and T <= 256:
                 dpart = f32(M * H * (1 if hd == 64 else 2))
-                fused = dot_delta[M] = ops.dgrad_with_head_dots(dy1, self.W(b + "attn.proj.weight"), do, bk.o, dpart, M, D, D, hd)
+                fused = dot_delta[dkey] = ops.dgrad_with_head_dots(dy1, self.W(b + "attn.proj.weight"), do, bk.o, dpart, M, D, D, hd)
             if fused:
                 ops.attention_bwd_dp(bk.qkv_a, do, bk.lse, dpart, dqkv, attn_ws, B, T, H, hd)
             else:

@@ -156,10 +156,19 @@ def colsum_bf16(x, ld, ws, out, M, N, accumulate=False):
     _call("reed_colsum_bf16", _p(x), ld, _p(ws), _p(out), M, N, int(accumulate), _stream())
 
 
+_FORCED_TILE = 0
+
+
+def gemm_forced_tile():
+    return _FORCED_TILE
+
+
 def gemm_force_tile(tile):
     """0 = heuristic; 128 / 256 (eight waves) / 257 (four 128x128 waves, one tile per workgroup) / 258 (the same, persistent
-    form wherever it applies) / 144 = force that GEMM kernel where it applies
-    (tests and A/B timing).  Set in both builds of the library."""
+    form wherever it applies) / 144 / 129 (128x256 tiles, two workgroups per CU: csrc/gemm128c.hip) = force that GEMM kernel
+    where it applies (tests and A/B timing).  Set in both builds of the library."""
+    global _FORCED_TILE
+    _FORCED_TILE = int(tile)
     for prec in ("bf16", "fp16"):
         _lib.load(prec).reed_gemm_force_tile(int(tile))
     if "fp32" in _lib.loaded():

@@ -521,11 +521,16 @@ def test_tile_choice_is_bit_invisible_at_small_local_batch(dev):
 def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
     """The tie between the kernel plan the XL/2 goldens pin (B = 8: 128^2 / 256x144 tiles, per-GEMM split-K weight gradients, the
     row-kernel delta of the attention backward) and the plan the timed b = 256 step runs (persistent 256^2 four-wave kernels, the
-    grouped weight gradients without split-K, the ring backward with delta from the dO GEMM's epilogue): ONE step of SiT-XL/2 +
-    1024-d projector at local batch 256 on the heuristic plan, and the same step with every GEMM forced onto the 128^2 kernel,
-    REED_WGRAD_GROUP=0 and REED_ATTN_DP=0.  The forward kernels are bit-identical per GEMM, so the loss must be bit-identical;
-    the gradients differ only by fp32 summation order (split-K slabs, the delta's order): every gradient tensor within 1e-4 of
-    its norm (measured: see the printed maximum), the whole arena within 2e-5."""
+    grouped weight gradients without split-K, the ring backward with delta from the dO GEMM's epilogue), at the bench's own size:
+    ONE step of SiT-XL/2 + 1024-d projector at local batch 256, four ways —
+      bench   the heuristic plan (what bench.py times)
+      A       the same with the row-kernel delta (REED_ATTN_DP=0)
+      B       A with every GEMM forced onto the 128^2 kernel            -> loss AND every gradient bit-identical to A
+      C       B with the per-GEMM split-K weight gradients (REED_WGRAD_GROUP=0) = the plan the goldens pin
+                                                                         -> differs from B by fp32 summation order only (<= 1e-5)
+    and bench vs A differs only where the last fp32 bit of delta (another summation order) flips a bf16 rounding of dS: the loss
+    is bit-identical, every gradient tensor within 3e-3 of its norm (measured 1.5e-3, the label table), the arena within 2e-4
+    (measured 7.9e-5) — the level of the bf16 activations' own rounding noise."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import random_fill
@@ -545,7 +550,9 @@ def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
     m.force_drop_mask = torch.rand(B, device=dev, generator=g) < 0.1
     lf = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
 
-    def step(tile):
+    def step(tile, dp, group):
+        monkeypatch.setenv("REED_ATTN_DP", dp)
+        monkeypatch.setenv("REED_WGRAD_GROUP", group)
         ops.gemm_force_tile(tile)
         try:
             for p in m.parameters():
@@ -560,25 +567,33 @@ def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
         finally:
             ops.gemm_force_tile(0)
 
-    l0, g0 = step(0)
-    monkeypatch.setenv("REED_WGRAD_GROUP", "0")
-    monkeypatch.setenv("REED_ATTN_DP", "0")
-    l1, g1 = step(128)
-    assert np.isfinite(l0) and float(g0.abs().max()) > 0 and bool(torch.isfinite(g1).all())
-    assert l0 == l1, (l0, l1)
     L = m._layout
-    worst, who = 0.0, None
-    for name, (off, shp) in L.seg.items():
-        n = int(np.prod(shp))
-        if off + n > L.n_train:
-            continue
-        a, b = g0[off:off + n].double(), g1[off:off + n].double()
-        rel = float((a - b).norm() / a.norm().clamp_min(1e-30))
-        if rel > worst:
-            worst, who = rel, name
-    whole = float((g0.double() - g1.double()).norm() / g0.double().norm())
-    print(f"b=256 plan tie: loss {l0} == {l1}; worst per-tensor relative gradient difference {worst:.3e} ({who}); whole arena {whole:.3e}")
-    assert worst <= 1e-4 and whole <= 2e-5, (worst, who, whole)
+
+    def worst_rel(g0, g1):
+        worst, who = 0.0, None
+        for name, (off, shp) in L.seg.items():
+            n = int(np.prod(shp))
+            if off + n > L.n_train:
+                continue
+            a, b = g0[off:off + n].double(), g1[off:off + n].double()
+            rel = float((a - b).norm() / a.norm().clamp_min(1e-30))
+            if rel > worst:
+                worst, who = rel, name
+        return worst, who, float((g0.double() - g1.double()).norm() / g0.double().norm())
+
+    lb, gb = step(0, "1", "1")
+    la, ga = step(0, "0", "1")
+    l2, g2 = step(128, "0", "1")
+    l3, g3 = step(128, "0", "0")
+    assert np.isfinite(lb) and float(gb.abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in (ga, g2, g3))
+    assert lb == la == l2 == l3, (lb, la, l2, l3)
+    assert torch.equal(ga, g2)                              # tile choice: bit-invisible at b = 256 too
+    w32, who32, all32 = worst_rel(g2, g3)                   # grouped vs split-K weight gradients
+    wdp, whodp, alldp = worst_rel(ga, gb)                   # delta from the row kernel vs from the dO GEMM's epilogue
+    print(f"b=256 plan tie: loss {lb}; split-K vs grouped: worst tensor {w32:.2e} ({who32}), arena {all32:.2e}; "
+          f"delta source: worst tensor {wdp:.2e} ({whodp}), arena {alldp:.2e}")
+    assert w32 <= 1e-5 and all32 <= 1e-6, (w32, who32, all32)
+    assert wdp <= 3e-3 and alldp <= 2e-4, (wdp, whodp, alldp)
 
 
 def test_c4_xl2_two_encoders_vs_reference_bf16(dev):
