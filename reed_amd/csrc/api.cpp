@@ -48,11 +48,13 @@ extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, c
   a.dbias = dbias;
   a.accumulate = accumulate;
   a.slab_stride = slab_stride;
-  if (epilogue == EPI_GELU_ERF) {   // exact GELU = the QuickGELU instantiation with the other activation
+  if (epilogue == EPI_GELU_ERF) {
     a.act_variant = 1;
-    epilogue = EPI_QGELU;
+#if defined(REED_FP32)
+    epilogue = EPI_QGELU;   // the fp32-operand GEMM switches on the variant at run time (gemm_f32.hip)
+#endif
   }
-  const bool act_epi = epilogue == EPI_GELU || epilogue == EPI_SILU || epilogue == EPI_QGELU;
+  const bool act_epi = epilogue == EPI_GELU || epilogue == EPI_SILU || epilogue == EPI_QGELU || epilogue == EPI_GELU_ERF;
   REED_CHECK_ARG(P && Q && (C || act_epi), "reed_gemm: null operand");
   if (act_epi) REED_CHECK_ARG(C2, "reed_gemm: activation epilogue needs C2");
   if (epilogue == EPI_RES_BF16) REED_CHECK_ARG(R, "reed_gemm: residual epilogue needs R");

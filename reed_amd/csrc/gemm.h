@@ -23,7 +23,8 @@ enum {
                       //   (64: S = 1, 72: S = 2) the partial dot products of the stored row with R bf16 [M, N]: slot s of head h is the
                       //   part inside the (s + 1)-th 64-column strip the head touches.  NN, 256^2 four-wave kernel only: the attention
                       //   backward's delta = rowsum(dO * O) formed where dO is produced (reed_attention_bwd_dp adds the slots)
-  EPI_GELU_ERF = 11   // ABI id only: exact GELU on the EPI_QGELU instantiation (GemmArgs::act_variant = 1); the ViT towers' Mlp
+  EPI_GELU_ERF = 11   // C2 bf16 = GELU(erf)(pre): nn.GELU() of the timm / I-JEPA towers' Mlp (its own instantiation since round 4;
+                      //   the fp32-operand build folds it into EPI_QGELU with GemmArgs::act_variant = 1)
 };
 
 struct GemmArgs {
@@ -45,7 +46,7 @@ struct GemmArgs {
   int accumulate;
   int ksplit_len;
   long slab_stride;
-  int act_variant;   // EPI_QGELU: 0 = QuickGELU (CLIP), 1 = GELU(erf) (timm / I-JEPA Mlp, nn.GELU)
+  int act_variant;   // fp32-operand build only: EPI_QGELU as 0 = QuickGELU (CLIP), 1 = GELU(erf) (timm / I-JEPA Mlp, nn.GELU)
   int tile_gm;   // gemm256: tile rows per XCD-local group of the workgroup -> tile map (set by launch256)
 };
 

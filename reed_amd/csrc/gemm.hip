@@ -213,6 +213,7 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
     case EPI_ADDF32_RB: return launch<LAY, EPI_ADDF32_RB>(a, splits, s);
     case EPI_ATOMIC_F32: return launch<LAY, EPI_ATOMIC_F32>(a, splits, s);
     case EPI_QGELU: return launch<LAY, EPI_QGELU>(a, splits, s);
+    case EPI_GELU_ERF: return launch<LAY, EPI_GELU_ERF>(a, splits, s);
     case EPI_RES_BF16: return launch<LAY, EPI_RES_BF16>(a, splits, s);
     case EPI_LS_RES:
       if constexpr (LAY == LAY_NT) return launch<LAY, EPI_LS_RES>(a, splits, s);

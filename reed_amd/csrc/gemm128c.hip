@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256, 2) void gemm128c_kernel(GemmArgs a) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int GM = a.tile_gm > 0 ? a.tile_gm : 8;
+  const int GM = (a.tile_gm & 0xFF) > 0 ? (a.tile_gm & 0xFF) : 8;
+  const bool dbg_nodma = (a.tile_gm & 0x100) != 0, dbg_nomfma = (a.tile_gm & 0x200) != 0;   // REED_GEMM128C_DBG (diagnosis)
   const int per_group = GM * ntn;
   const int group = bid / per_group, first_m = group * GM;
   const int gs = min(ntm - first_m, GM);
@@ -130,13 +131,13 @@ __global__ __launch_bounds__(256, 2) void gemm128c_kernel(GemmArgs a) {
   stage(0, 0);
   if (nt > 1) stage(1, 1);
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (t + 1 < nt && !dbg_nodma) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();     // stage t landed for every wave; every wave is done reading stage t - 1
     asm volatile("" ::: "memory");
-    if (t + 2 < nt) stage(t + 2, (t + 2) % NSTG);
+    if (t + 2 < nt && !(dbg_nodma && t >= 2)) stage(t + 2, (t + 2) % NSTG);
     const char* sa = smem + (t % NSTG) * STG;
     const char* sb = sa + A_BYTES;
     bf16x8 pf[4], qf[8];
@@ -148,6 +149,10 @@ __global__ __launch_bounds__(256, 2) void gemm128c_kernel(GemmArgs a) {
       else qf[j] = frag_tr(sb + wn * 8192, j * 16, 0, lane);
     }
     if constexpr (LAY != LAY_NT) REED_LDS_WAIT();   // asm transposing reads: the compiler does not count them
+    if (dbg_nomfma) {   // diagnosis: the operand stream alone (the fragments are consumed by one MFMA)
+      acc[0][0][0] = REED_MFMA_16x16x32(qf[0], pf[0], acc[0][0][0]);
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -173,7 +178,9 @@ int launch128c(const GemmArgs& a, hipStream_t stream) {
   GemmArgs b = a;
   static int gm = -1;
   if (gm < 0) { const char* e = getenv("REED_GEMM128C_GM"); gm = e ? atoi(e) : 8; }
-  b.tile_gm = gm;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("REED_GEMM128C_DBG"); dbg = e ? atoi(e) : 0; }   // 1: no DMA after the first stages, 2: no MFMAs
+  b.tile_gm = gm | (dbg << 8);
   const int ntm = cdiv(a.M, CBM), ntn = cdiv(a.N, CBN);
   REED_KLAUNCH((gemm128c_kernel<LAY, EPI>), dim3(ntm * ntn), dim3(256), LDS_C, stream, b);
   REED_LAUNCH_CHECK();

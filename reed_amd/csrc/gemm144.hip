@@ -78,13 +78,14 @@ __device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
       *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
-    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU) {
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF) {
       bf16x4 pre, act;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pre[e] = f2bf(v[e]);
         const float x = bf2f(pre[e]);
-        if constexpr (EPI == EPI_QGELU) act[e] = a.act_variant ? f2bf(gelu_erf_f(x)) : f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+        if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+        else if constexpr (EPI == EPI_GELU_ERF) act[e] = f2bf(gelu_erf_f(x));
         else act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
       }
       if (a.C) *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = pre;
@@ -441,6 +442,7 @@ int dispatch144(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_DGELU: return launch144<LAY, EPI_DGELU>(a, s);
     case EPI_DSILU: return launch144<LAY, EPI_DSILU>(a, s);
     case EPI_QGELU: return launch144<LAY, EPI_QGELU>(a, s);
+    case EPI_GELU_ERF: return launch144<LAY, EPI_GELU_ERF>(a, s);
     case EPI_RES_BF16: return launch144<LAY, EPI_RES_BF16>(a, s);
   }
   reed_set_error("reed_gemm(256x144): epilogue %d has no bf16-output form", epi);
@@ -452,7 +454,7 @@ int dispatch144(int epi, const GemmArgs& a, hipStream_t s) {
 // shapes the 256x144 kernel can take: NT / NN, bf16-output epilogue, N a multiple of 144, no split-K
 bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits) {
   const bool bf16_epi = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES || epi == EPI_DGELU ||
-                        epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_RES_BF16;
+                        epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_GELU_ERF || epi == EPI_RES_BF16;
   return (layout == LAY_NT || layout == LAY_NN) && bf16_epi && splits <= 1 && a.N % BN4 == 0 && a.K % BK4 == 0 &&
          a.K >= BK4;
 }

@@ -704,6 +704,8 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
       case EPI_GATE_RES: return launch256w<LAY, EPI_GATE_RES>(a, s);
       case EPI_RES_BF16: return launch256w<LAY, EPI_RES_BF16>(a, s);
       case EPI_LS_RES: return launch256w<LAY, EPI_LS_RES>(a, s);
+      case EPI_QGELU: return launch256w<LAY, EPI_QGELU>(a, s);
+      case EPI_GELU_ERF: return launch256w<LAY, EPI_GELU_ERF>(a, s);
     }
   } else {                         // input gradients
     switch (epi) {
@@ -722,8 +724,10 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) {
   // (QuickGELU / exact-GELU epilogues stay on the 8-wave kernel: their VALU work — erff, two roundings per element — needs two
   // waves per SIMD to hide its own latency; measured 0.93 vs 0.64 ms on the ViT-L fc1 shape)
+  // round 4: each of the two is now its own instantiation (gemm_common.hpp); REED_QGELU_W4=1 sends them to this kernel (A/B)
+  static const bool qw4 = getenv("REED_QGELU_W4") && atoi(getenv("REED_QGELU_W4")) == 1;
   const bool epi_ok = layout == LAY_NT ? (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES ||
-                                          epi == EPI_RES_BF16 || epi == EPI_LS_RES)
+                                          epi == EPI_RES_BF16 || epi == EPI_LS_RES || (qw4 && (epi == EPI_QGELU || epi == EPI_GELU_ERF)))
                                        : (epi == EPI_BF16 || epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_DSILU);
   return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 && epi_ok;
 }

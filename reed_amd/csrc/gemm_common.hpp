@@ -79,7 +79,7 @@ template <int EPI, int NI>
 struct EpiOps {
   static constexpr int value = EPI == EPI_BF16 ? 1 + NI * 2
                                : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU ||
-                                  EPI == EPI_QGELU || EPI == EPI_RES_BF16) ? 1 + NI * 4
+                                  EPI == EPI_QGELU || EPI == EPI_GELU_ERF || EPI == EPI_RES_BF16) ? 1 + NI * 4
                                : EPI == EPI_BF16_DOT ? 1 + NI * 4
                                : EPI == EPI_GATE_RES ? 1 + NI * 12
                                : EPI == EPI_LS_RES ? 3 + NI * 8
@@ -231,7 +231,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           st_bf16x8(o, rsC, oc + h * s8);
         }
       }
-    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU) {
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF) {
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsC2 = tile_rsrc(a.C2, a.ldc2, 2);
       int oc = lane_off(a.ldc, 2), oc2 = lane_off(a.ldc2, 2);
       const int s8 = (int)(8 * a.ldc * 2), t8 = (int)(8 * a.ldc2 * 2);
@@ -246,8 +246,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           for (int e = 0; e < 8; ++e) {
             pre[e] = f2bf(v[h][e]);
             float x = bf2f(pre[e]);
-            if constexpr (EPI == EPI_QGELU)   // x * sigmoid(1.702 x) with eager-mode bf16 roundings (clip_vit.py:168-170)
-              act[e] = a.act_variant ? f2bf(gelu_erf_f(x)) : f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+            // QuickGELU = x * sigmoid(1.702 x) with eager-mode bf16 roundings (clip_vit.py:168-170); exact GELU (nn.GELU: the timm /
+            // I-JEPA towers) is its OWN instantiation since round 4: as a run-time variant of one epilogue both activations
+            // were compiled into every element (11 k instructions, 288 branches: 0.64 ms for ViT-L's fc1 where the tanh-GELU
+            // form of the same shape takes a quarter of that)
+            if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+            else if constexpr (EPI == EPI_GELU_ERF) act[e] = f2bf(gelu_erf_f(x));
             else
               act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
           }
