@@ -414,8 +414,18 @@ def n2_encoder_leg(dev, batch=64, reps=3):
     dt = (time.perf_counter() - t0) / reps
     W, L, T = cfg["width"], cfg["layers"], (cfg["image"] // cfg["patch"]) ** 2 + 1
     flop = 2.0 * (L * (T * 12 * W * W + 2 * T * T * W) + (T - 1) * 3 * cfg["patch"] ** 2 * W)
+    # the same tower at batch 256 (one-GPU feature extraction): 64 x 257 tokens leave a quarter-full 65th tile row, 256 x 257 a
+    # full one more
+    raw4 = torch.randint(0, 256, (256, 3, 256, 256), dtype=torch.uint8, device=dev)
+    enc.encode_raw(raw4)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    enc.encode_raw(raw4)
+    torch.cuda.synchronize()
+    dt4 = time.perf_counter() - t1
     return {"images_per_sec": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 2), "batch": batch, "operands": "bf16",
             "gflop_per_image": round(flop / 1e9, 1), "mfma_frac": round(flop * batch / dt / PEAK_BF16, 4),
+            "batch256": {"images_per_sec": round(256 / dt4, 1), "mfma_frac": round(flop * 256 / dt4 / PEAK_BF16, 4)},
             "finite": bool(torch.isfinite(out.float()).all()),
             "note": "CLIP ViT-L/14 image tower (reed_amd/encoders.py) incl. the preprocessing pass; runs beside the train step when "
                     "features are not precomputed"}

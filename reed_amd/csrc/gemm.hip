@@ -30,6 +30,7 @@ bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits);
 int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm256w.hip: 4 waves x 128x128
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
+int reed_num_cus();   // gemm256.hip
 bool reed_gemm128c_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm128c.hip: 128x256 tiles, two workgroups per CU
 int reed_gemm128c_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 
@@ -277,6 +278,36 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
                    "reed_gemm: split-K needs the atomic or slab fp32 epilogue");
   }
   if (tn_tile) return reed_gemm_tn_launch(tn_tile, a, splits, stream);
+  // Ragged-M split (round 4).  M = B * 257 tokens of a ViT tower (256 patches + CLS) is 64.25 tile rows at B = 64: the 65th row
+  // tile (64 live rows) costs every GEMM of the tower a whole extra round of the chip — 65 x 16 = 1040 tiles of the fc1 GEMM are
+  // 5 rounds of 256 CUs where 64 x 16 = 1024 are exactly 4 (qkv 4 -> 3, proj and fc2 2 -> 1).  Where dropping the ragged row
+  // tile saves a round, the full rows go out as one launch and the <= 128 tail rows as a second, small one (the same kernels
+  // on offset pointers: bit-identical results; epilogues whose row index carries meaning — the per-sample gate, the head-dot
+  // slots — are left alone).  REED_GEMM_SPLIT_M=0 switches it off (A/B).
+  {
+    static int split_on = -1;
+    if (split_on < 0) { const char* e = getenv("REED_GEMM_SPLIT_M"); split_on = e ? atoi(e) : 1; }
+    const bool epi_rows_free = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_QGELU || epi == EPI_GELU_ERF ||
+                               epi == EPI_RES_BF16 || epi == EPI_LS_RES || epi == EPI_DGELU || epi == EPI_DSILU;
+    const int r = a.M % 256, mfull = a.M - r;
+    if (split_on && g_force_tile == 0 && want != EPI_BF16_DOT && epi_rows_free && splits <= 1 && (layout == LAY_NT || layout == LAY_NN) &&
+        r > 0 && r <= 128 && mfull >= 2048) {
+      const int ncu = reed_num_cus(), ntn = cdiv(a.N, 256), rows = mfull / 256;
+      if (cdiv((long)rows * ntn, ncu) < cdiv((long)(rows + 1) * ntn, ncu)) {
+        const int cb = epi == EPI_LS_RES ? 4 : 2, rb = epi == EPI_LS_RES ? 4 : 2;   // bytes per element of C and R
+        GemmArgs m = a, t = a;
+        m.M = mfull;
+        t.M = r;
+        t.P = a.P + (long)mfull * a.ldp;
+        if (a.C) t.C = (char*)a.C + (long)mfull * a.ldc * cb;
+        if (a.C2) t.C2 = (char*)a.C2 + (long)mfull * a.ldc2 * 2;
+        if (a.R) t.R = (const char*)a.R + (long)mfull * a.ldr * rb;
+        const int rc = reed_gemm_launch(layout, epi, m, splits, stream);
+        if (rc != REED_OK) return rc;
+        return reed_gemm_launch(layout, epi, t, splits, stream);
+      }
+    }
+  }
   // the two-workgroups-per-CU kernel (gemm128c.hip): force_tile 129 wherever it is built; REED_GEMM128C=<mask> (bit e = epilogue
   // id e) selects it for those epilogues on problems of at least 16384 rows
   {

@@ -485,3 +485,48 @@ torch.save([(q[2].cpu(), q[3].cpu()) for q in probs], sys.argv[2])
         os.remove(path)
     for (w0, b0), (w1, b1) in zip(*outs):
         assert torch.isfinite(w0).all() and torch.equal(w0, w1) and torch.equal(b0, b1)
+
+
+@pytest.mark.parametrize("N,K", [(1024, 1024), (4096, 1024), (1024, 4096)])
+def test_ragged_m_split_is_bit_invisible(dev, N, K, force_tile):
+    """M = 64 x 257 (a ViT tower at batch 64): the dispatcher sends the 64 full tile rows and the 64 tail rows out as two
+    launches where the ragged 65th row tile would cost a whole round of the chip (csrc/gemm.hip: ragged-M split) — outputs
+    bit-identical to the one-launch form of a forced tile, for the plain, QuickGELU, GELU(erf), bf16-residual and LayerScale
+    epilogues, and nothing written past row M - 1."""
+    if force_tile != 0:
+        pytest.skip("runs once, forcing the tiles itself")
+    from reed_amd import ops
+    M = 64 * 257
+    g = torch.Generator().manual_seed(N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    r16 = _bf(torch.randn(M, N, generator=g)).to(dev)
+    r32 = torch.randn(M, N, generator=g).to(dev)
+    gamma = torch.randn(N, generator=g).to(dev)
+
+    def run(tile):
+        ops.gemm_force_tile(tile)
+        try:
+            o_plain = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(ops.NT, ops.EPI_BF16, x, w, M, N, K, o_plain, K, K, N, bias=b)
+            o_q = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(ops.NT, ops.EPI_QGELU, x, w, M, N, K, None, K, K, N, C2=o_q, ldc2=N, bias=b)
+            o_e = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(ops.NT, ops.EPI_GELU_ERF, x, w, M, N, K, None, K, K, N, C2=o_e, ldc2=N, bias=b)
+            o_r = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm(ops.NT, ops.EPI_RES_BF16, x, w, M, N, K, o_r, K, K, N, R=r16, ldr=N, bias=b)
+            o_l = torch.full((M + 1, N), float("nan"), device=dev)
+            ops.gemm(ops.NT, ops.EPI_LS_RES, x, w, M, N, K, o_l, K, K, N, R=r32, ldr=N, bias=b, gate=gamma)
+            torch.cuda.synchronize()
+            return o_plain, o_q, o_e, o_r, o_l
+        finally:
+            ops.gemm_force_tile(0)
+
+    split, whole = run(0), run(256)
+    for a, c in zip(split, whole):
+        assert torch.isnan(a[M].float()).all() and torch.isfinite(a[:M].float()).all()
+        assert torch.equal(a[:M], c[:M])
+    ref = _bf(x.float() @ w.float().t() + b.float()).float()
+    torch.testing.assert_close(split[0][:M].float(), ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(split[2][:M].float(), _bf(torch.nn.functional.gelu(ref)).float(), atol=1e-2, rtol=1e-2)
