@@ -295,6 +295,82 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Tail query rows of a sequence that is a few tokens longer than a multiple of 256 (round 4): T = 257 (a ViT tower's 256
+// patches + CLS; 261 with DINOv2's registers).  attn_fwd_kernel gives every 256-query block its own workgroup, and the block that
+// holds ONE query still loads every key and value tile of the head: 2 x the memory traffic and 2 x the workgroups of T = 256
+// (8.6 % of the matrix peak in the CLIP tower).  Those rows (<= 16 per head) are done here on the vector ALUs instead — one
+// wave per (batch, head, row), head_dim 64: scores with the key on the lane (q broadcast through scalar registers), exact
+// softmax across the wave, then O with head_dim on the lane (p broadcast by v_readlane) — and the main kernel runs the full
+// 256-query blocks only.  ~2 k instructions per wave; fp32 probabilities (the main kernel rounds them to 16 bits for the MFMA).
+__global__ __launch_bounds__(256) void attn_fwd_rows_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                            float* __restrict__ lse, int T, int H, int row0, int nrows,
+                                                            int nwaves) {
+  constexpr int HD = 64, KPL = 8;                   // keys per lane: T <= 512
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= nwaves) return;
+  const int lane = threadIdx.x & 63;
+  const int bh = w / nrows, row = row0 + (w - bh * nrows);
+  const int b = bh / H, h = bh - b * H;
+  const long D = (long)H * HD, tok = 3 * D;
+  const bf16* base = qkv + (long)b * T * tok + h * HD;
+  const float scale = rsqrtf((float)HD);
+  // q[d] * scale in 64 scalar registers
+  const float qv = bf2f(base[(long)row * tok + lane]) * scale;
+  float q[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) q[d] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), d));
+  // scores of keys lane, lane + 64, ...
+  float sc[KPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    const int key = lane + 64 * j;
+    sc[j] = -INFINITY;
+    if (64 * j < T) {                               // wave-uniform
+      const bf16* kr = base + D + (long)min(key, T - 1) * tok;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD / 8; ++c) {
+        const bf16x8 kk = *(const bf16x8*)(kr + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(bf2f(kk[e]), q[8 * c + e], acc);
+      }
+      if (key < T) sc[j] = acc;
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    sc[j] = __builtin_amdgcn_exp2f((sc[j] - mx) * LOG2E);   // exp2(-inf) = 0 for the keys past T
+    sum += sc[j];
+  }
+  sum = wave_sum(sum);
+  // O[d = lane] = sum_key p[key] v[key][d]
+  const bf16* vb = base + 2 * D + lane;
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    if (64 * j < T) {
+      const int nk = min(64, T - 64 * j);
+      for (int k0 = 0; k0 < nk; k0 += 8) {
+        float vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = bf2f(vb[(long)min(64 * j + k0 + e, T - 1) * tok]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc[j]), (k0 + e) & 63));
+          acc = fmaf((k0 + e < nk) ? p : 0.f, vv[e], acc);
+        }
+      }
+    }
+  }
+  o[((long)b * T + row) * D + h * HD + lane] = f2bf(acc / sum);
+  if (lse && lane == 0) lse[((long)b * H + h) * T + row] = mx + __logf(sum);
+}
+
+// ------------------------------------------------------------------------------------------
 // LDS-DMA tile staging (buffer_load_dwordx4 ... lds): a [256][RB / 16]-chunk tile image is 256 * RB / 1024 wave
 // instructions of 1 KiB; lane L of instruction I carries chunk c = 64 I + L = (row c / CPR, chunk c % CPR) from its own
 // source address to the lane-linear LDS address tile + 16 c.  Chunks behind the head's columns (the pad of a padded row
@@ -2555,6 +2631,16 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
   }
   const int lds = 2 * TILE_F;
   dim3 grid(B * H, (T + 255) / 256);
+  // a last query block of at most 16 rows (T = 257, 261: the ViT towers) goes to the row kernel; REED_ATTN_TAIL=0: the old form
+  static const bool tail_on = !(getenv("REED_ATTN_TAIL") && atoi(getenv("REED_ATTN_TAIL")) == 0);
+  const int tail = T % 256;
+  if (tail_on && hd == 64 && T > 256 && T <= 512 && tail >= 1 && tail <= 16) {
+    grid.y = T / 256;
+    const int nwaves = B * H * tail;
+    REED_KLAUNCH(attn_fwd_rows_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T, H,
+                 T - tail, tail, nwaves);
+    REED_LAUNCH_CHECK();
+  }
   if (hd == 64) {
     static int once = set_lds(attn_fwd_kernel<64>, lds);
     if (once) return once;

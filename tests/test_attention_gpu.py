@@ -15,10 +15,13 @@ def _ref(qkv, B, T, H, hd):
 
 
 # (24, 256, 16, 72), (37, 256, 16, 64), (70, 100, 6, 72): more (batch, head) items than CUs — the persistent T <= 256
-# forward walks several items per workgroup (LDS-DMA ring, counted waits), some workgroups one item more than others
+# forward walks several items per workgroup (LDS-DMA ring, counted waits), some workgroups one item more than others;
+# 257, 261, 272 (hd 64): the ViT towers' lengths — the last <= 16 query rows go to the row kernel (attn_fwd_rows_kernel),
+# 273: one row too many for it
 @pytest.mark.parametrize("B,T,H,hd", [(2, 256, 16, 72), (3, 256, 6, 64), (2, 64, 4, 72), (1, 16, 2, 64),
                                        (1, 100, 2, 72), (1, 1024, 2, 72), (1, 320, 3, 64), (24, 256, 16, 72),
-                                       (37, 256, 16, 64), (70, 100, 6, 72), (1, 257, 2, 64), (3, 200, 5, 72)])
+                                       (37, 256, 16, 64), (70, 100, 6, 72), (1, 257, 2, 64), (3, 200, 5, 72),
+                                       (3, 261, 4, 64), (20, 257, 16, 64), (2, 272, 3, 64), (2, 273, 3, 64)])
 def test_attention_fwd(dev, B, T, H, hd):
     from reed_amd import ops
     g = torch.Generator().manual_seed(B * T + hd)
