@@ -37,6 +37,10 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(reed_clk_buf), sizeof(unsigned long long) * n);
 }
 #endif
+// row groups of epilogue operand loads (residual stream / pre-activation) kept in flight ahead of the group being written
+#ifndef REED_EPI_PF
+#define REED_EPI_PF 4
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -408,7 +412,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) part[i][j] = acc[i][h * 4 + j];
-    tile_epilogue<EPI, NA, 4>(a, part, m0, mrow, n0 + ncol + h * 64, lane, 0, stage);
+    tile_epilogue<EPI, NA, REED_EPI_PF>(a, part, m0, mrow, n0 + ncol + h * 64, lane, 0, stage);
   }
   if constexpr (LAY == LAY_TN) {
     if (do_dbias && (lane >> 4) == 0) {

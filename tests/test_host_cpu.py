@@ -599,3 +599,16 @@ def test_bench_launcher_argv(monkeypatch):
     import subprocess
     monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: started.append(a) or (_ for _ in ()).throw(AssertionError("started")))
     assert bench.self_launch(args, argv) == 2 and not started
+
+
+def test_counted_waits_of_the_attention_forward_match_the_isa():
+    """attn_fwd256p_kernel waits with s_waitcnt vmcnt(N) for immediates derived from how many vector-memory instructions a wave
+    issues per item: compile csrc/attention.hip to gfx950 ISA (hipcc cross-compiles here) and count them in every instantiation —
+    20 + 7 before the item loop, 15 + 7 per item, the waits in the expected order, no scratch traffic (tools/r4/check_isa.py; the
+    compiler once merged seven identical prologue stores into one, which left the first item's waits six operations short)."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r4", "check_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok  ") >= 9 and "BAD" not in r.stdout, r.stdout
