@@ -1,6 +1,7 @@
 // Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip: 128x128 tile; gemm256.hip: 256x256 tile):
 // buffer descriptors, LDS tile formats (swizzles), fragment reads and the fused epilogues.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "gemm.h"
 
@@ -265,67 +266,91 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
                                    rsY = tile_rsrc(a.C2, a.ldc2, 2);
       const long grows = (a.M + a.rows_per_gate - 1) / a.rows_per_gate;
       const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(a.gate, ((grows - 1) * a.ldgate + a.N) * 2);
-      int oc = lane_off(a.ldc, 4), orr = lane_off(a.ldr, 4), oy = lane_off(a.ldc2, 2);
+      const int orr = lane_off(a.ldr, 4);
       const int s8 = (int)(8 * a.ldc * 4), r8 = (int)(8 * a.ldr * 4), y8 = (int)(8 * a.ldc2 * 2);
       // gate row of a 16-row group: scalar walk when groups cannot straddle gate rows, per-lane division otherwise
       const bool gfast = (a.rows_per_gate & 15) == 0;
-      int grow = (m0 + mw) / a.rows_per_gate;
-      int grem = (m0 + mw) - grow * a.rows_per_gate;
+      const int grow0 = (m0 + mw) / a.rows_per_gate;
+      const int grem0 = (m0 + mw) - grow0 * a.rows_per_gate;
       const int og = cv ? col * 2 : EPI_OOB;
-      bf16x8 g[NI][2];
-      f32x4 xin[NI][2][2];
-      auto fetch = [&](int i) {   // operand loads of row group i (they do not depend on the accumulators)
-        int gso = 0;
-        if (gfast) {
-          gso = grow * (int)a.ldgate * 2;
-          grem += 16;
-          if (grem >= a.rows_per_gate) { grem -= a.rows_per_gate; ++grow; }
-        }
-        const int ro = orr + i * 2 * r8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int gvo = og;
-          if (!gfast) gvo = cv ? (int)(((long)((m0 + rt + 16 * i + 8 * h) / a.rows_per_gate) * a.ldgate + col) * 2) : EPI_OOB;
-#ifdef REED_EPI_DIAG_NOLOAD   // diagnosis build (tools/_ab/build_variant.py): the epilogue without its operand loads
-          g[i][h] = bf16x8{};
-          xin[i][h][0] = xin[i][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          (void)gvo; (void)gso; (void)ro;
+      // Round 4: where every row group of the strip lies in ONE gate row (SiT: rows_per_gate = T = 256 = the tile height, always)
+      // the gate vector is loaded once instead of once per (group, half) — a third of the epilogue's operand loads — and the 8
+      // registers per group that frees carry the residual stream of twice as many groups in flight (PF 4 -> 8: the whole strip).
+#ifdef REED_EPI_NOHOIST   // A/B build: round 3's form
+      const bool ghoist = false;
 #else
-          g[i][h] = ld_bf16x8(rsG, gvo, gso);
-          xin[i][h][0] = ld_f32x4(rsR, ro + h * r8);
-          xin[i][h][1] = ld_f32x4(rsR, ro + h * r8 + 16);
+      const bool ghoist = gfast && grem0 + 16 * NI <= a.rows_per_gate;
 #endif
+      auto body = [&](auto hoist_c, auto pf_c) {
+        constexpr bool HOIST = decltype(hoist_c)::value;
+        constexpr int PFX = decltype(pf_c)::value;
+        int grow = grow0, grem = grem0;
+        int oc = lane_off(a.ldc, 4), oy = lane_off(a.ldc2, 2);
+        bf16x8 gone = bf16x8{};
+        if constexpr (HOIST) gone = ld_bf16x8(rsG, og, grow0 * (int)a.ldgate * 2);
+        bf16x8 g[HOIST ? 1 : NI][2];
+        f32x4 xin[NI][2][2];
+        auto fetch = [&](int i) {   // operand loads of row group i (they do not depend on the accumulators)
+          int gso = 0;
+          if (!HOIST && gfast) {
+            gso = grow * (int)a.ldgate * 2;
+            grem += 16;
+            if (grem >= a.rows_per_gate) { grem -= a.rows_per_gate; ++grow; }
+          }
+          const int ro = orr + i * 2 * r8;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#ifdef REED_EPI_DIAG_NOLOAD   // diagnosis build (tools/_ab/build_variant.py): the epilogue without its operand loads
+            if constexpr (!HOIST) g[i][h] = bf16x8{};
+            xin[i][h][0] = xin[i][h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            (void)gso; (void)ro;
+#else
+            if constexpr (!HOIST) {
+              int gvo = og;
+              if (!gfast) gvo = cv ? (int)(((long)((m0 + rt + 16 * i + 8 * h) / a.rows_per_gate) * a.ldgate + col) * 2) : EPI_OOB;
+              g[i][h] = ld_bf16x8(rsG, gvo, gso);
+            }
+            xin[i][h][0] = ld_f32x4(rsR, ro + h * r8);
+            xin[i][h][1] = ld_f32x4(rsR, ro + h * r8 + 16);
+#endif
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < PFX && i < NI; ++i) fetch(i);
+#pragma unroll
+        for (int i = 0; i < NI; ++i, oc += 2 * s8, oy += 2 * y8) {
+          if constexpr (PFX == 0) fetch(i);
+          float v[2][8];
+          transpose(i, v);
+          if (PFX > 0 && i + PFX < NI) fetch(i + PFX);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            bf16x8 y;
+            f32x4 xo[2];
+            const bf16x8 gv = HOIST ? gone : g[HOIST ? 0 : i][h];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              y[e] = f2bf(v[h][e]);
+              xo[e >> 2][e & 3] = xin[i][h][e >> 2][e & 3] + bfround(bf2f(gv[e]) * bf2f(y[e]));
+            }
+#ifdef REED_EPI_DIAG_NOSTORE   // diagnosis build: the stores dropped by the range check (the values stay live through the offset)
+            const int dro = (xo[0][0] == 12345.678f && bf2f(y[0]) == 3.f) ? 0 : EPI_OOB;
+            st_bf16x8(y, rsY, dro);
+            st_f32x4(xo[0], rsC, dro);
+            st_f32x4(xo[1], rsC, dro);
+#else
+            st_bf16x8(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
+            st_f32x4(xo[0], rsC, oc + h * s8);
+            st_f32x4(xo[1], rsC, oc + h * s8 + 16);
+#endif
+          }
         }
       };
-#pragma unroll
-      for (int i = 0; i < PF && i < NI; ++i) fetch(i);
-#pragma unroll
-      for (int i = 0; i < NI; ++i, oc += 2 * s8, oy += 2 * y8) {
-        if constexpr (PF == 0) fetch(i);
-        float v[2][8];
-        transpose(i, v);
-        if (PF > 0 && i + PF < NI) fetch(i + PF);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          bf16x8 y;
-          f32x4 xo[2];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            y[e] = f2bf(v[h][e]);
-            xo[e >> 2][e & 3] = xin[i][h][e >> 2][e & 3] + bfround(bf2f(g[i][h][e]) * bf2f(y[e]));
-          }
-#ifdef REED_EPI_DIAG_NOSTORE   // diagnosis build: the stores dropped by the range check (the values stay live through the offset)
-          const int dro = (xo[0][0] == 12345.678f && bf2f(y[0]) == 3.f) ? 0 : EPI_OOB;
-          st_bf16x8(y, rsY, dro);
-          st_f32x4(xo[0], rsC, dro);
-          st_f32x4(xo[1], rsC, dro);
-#else
-          st_bf16x8(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
-          st_f32x4(xo[0], rsC, oc + h * s8);
-          st_f32x4(xo[1], rsC, oc + h * s8 + 16);
+#ifndef REED_EPI_PFH_NUM     // depth of the hoisted form = PF * NUM / 2 (A/B builds: 3 -> 6 groups, default 4 -> 8 = the whole strip)
+#define REED_EPI_PFH_NUM 4
 #endif
-        }
-      }
+      if (ghoist) body(std::true_type{}, std::integral_constant<int, PF == 0 ? 0 : (PF * REED_EPI_PFH_NUM / 2 < NI ? PF * REED_EPI_PFH_NUM / 2 : NI)>{});
+      else body(std::false_type{}, std::integral_constant<int, PF>{});
     } else if constexpr (EPI == EPI_LS_RES) {
       // x_out = x_in + gamma * float(bf16(acc+bias)): LayerScale (an fp32 parameter times the bf16 linear output promotes
       // to fp32 under autocast) and the fp32 residual add of a DINOv2 block
