@@ -41,6 +41,17 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_EPI_PF
 #define REED_EPI_PF 4
 #endif
+// 1: the epilogues that have an MFMA-layout form (gemm_common.hpp: tile_epilogue_direct) use it — bit-identical, and SLOWER (plain
+// 4.9 vs 4.4 us per tile, gate + residual 27 vs 22: profiles/r4_epilogue_forms.txt), so 0, the LDS-patch forms, is the product
+// 1: the full drain (vmcnt(0)) at a persistent tile's start and at its K-tile 0; 0: counted waits that leave the previous tile's
+// epilogue stores in flight under K-tile 0 (wait_staged below).  Measured equal (block table 5.728 / 5.715 / 5.724 ms drained,
+// 5.732 / 5.715 / 5.723 counted: profiles/r4_epilogue_forms.txt): the drain is not what a tile's first 0.7 us are.  Default: drain.
+#ifndef REED_PM_DRAIN
+#define REED_PM_DRAIN 1
+#endif
+#ifndef REED_EPI_DIRECT
+#define REED_EPI_DIRECT 0
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -74,13 +85,14 @@ __device__ __forceinline__ bf16x8 wtr2(const char* a0, const char* a1) {
 //   MODE 2  128 x 256: A half-tile 0 (8 tiles) x B half-tile wave>>1, 64-column quarter wave&1 (4 tiles)   32
 //   MODE 3  128 x 128: A half-tile 0 quarter wave>>1 (4) x B half-tile 0 quarter wave&1 (4)                16
 // and the half-tiles that do not exist are not staged.
-// PM = 1: the persistent form (gemm256wp_kernel): the workgroup walks a list of tiles; `first` = this is its first tile (it
-// stages its own first two K-tiles), otherwise they were staged by the previous tile's last two K-tiles; nx_mode >= 0: a
+// PM = 1: the persistent form (gemm256wp_kernel): the workgroup walks a list of tiles; prev_mode < 0 = this is its first tile (it
+// stages its own first two K-tiles), otherwise they were staged by the previous tile (of MODE prev_mode)'s last two K-tiles; nx_mode >= 0: a
 // next tile (nx_tm, nx_tn) of MODE nx_mode (0 / 1) follows, and this tile's last two K-tiles stage ITS first two.
 template <int LAY, int EPI, int MODE, int PM = 0>
 __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, const int tm, const int tn,
-                                              const bool first = true, const int nx_mode = -1, const int nx_tm = 0,
+                                              const int prev_mode = -1, const int nx_mode = -1, const int nx_tm = 0,
                                               const int nx_tn = 0) {
+  const bool first = prev_mode < 0;
   constexpr bool RN = (MODE & 1) != 0, RM = (MODE & 2) != 0;
   constexpr int NA = RN ? 4 : 8;              // 16-row tiles per wave
   constexpr int NB = RM ? 4 : 8;              // 16-column tiles per wave
@@ -288,7 +300,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   } while (0)
 
   // PF: K-tile t+2 exists (literal true in the steady-state loop: no branch around the DMAs)
-#define WKTILE(T, CUR, PF, KIND, KT) WKTILE_(T, CUR, PF, KIND, KT, 0)
+#define WKTILE(T, CUR, PF, KIND, KT) WKTILE_(T, CUR, PF, KIND, KT, 0, 0)
 #ifdef REED_CLK_PHASE   /* diagnostic build: cycles per phase (A, the waits + barrier, B), one stamp = s_memtime + lgkmcnt(0) */
 #define WSTAMP(K)                                                                          \
   do {                                                                                     \
@@ -303,7 +315,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #else
 #define WSTAMP(K)
 #endif
-#define WKTILE_(T, CUR, PF, KIND, KT, Z)                                                    \
+#define WKTILE_(T, CUR, PF, KIND, KT, Z, CW)                                                \
   do {                                                                                     \
     const int t_ = (T);                                                                    \
     asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));     \
@@ -313,7 +325,8 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     WPHASE(0, (CUR), 1, false, 0, 0, 0, Z);                                                \
     WSTAMP(0);                                                                             \
     /* phase B: K-tile t+1 landed, every wave done with K-tile t; MFMAs of (t, ks1); reads of (t+1, ks0); DMAs of t+2 */ \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    if constexpr ((CW) != 0) wait_staged(0);                                               \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
     WLGKM0();                                                                              \
     WBARRIER();                                                                            \
     WSTAMP(1);                                                                             \
@@ -324,10 +337,33 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     WSTAMP(2);                                                                             \
   } while (0)
 
+  // PM: the previous tile staged this tile's K-tiles 0 and 1 beside its last two K-tiles; its epilogue's loads and stores are
+  // YOUNGER than those DMAs and counted in the same vmcnt, which retires in issue order: K-tile 0 has landed once at most
+  // (16 DMAs of K-tile 1 + the epilogue's instructions) are outstanding, K-tile 1 once at most the epilogue's are — capped at the
+  // 63 a counted wait can express.  (REED_PM_DRAIN=0 only; the default drains everything, vmcnt(0), at both points.)  The counts are
+  // lower bounds of what a wave issues in the epilogue (gemm_common.hpp: EpiOps per 64-column strip; fewer allowed = stricter = safe).
+  auto wait_staged = [&](const int extra) {
+    constexpr bool direct = REED_EPI_DIRECT && EpiDirect<EPI>::value;
+    constexpr int s8 = direct ? EpiDirectOps<EPI, 8>::value : EpiOps<EPI, 8>::value;   // previous tile MODE 0: two strips of 8 row groups
+    constexpr int s4 = direct ? EpiDirectOps<EPI, 4>::value : EpiOps<EPI, 4>::value;   // MODE 1: two strips of 4
+    constexpr int e0 = s8 < 0 ? 0 : 2 * s8, e1 = s4 < 0 ? 0 : 2 * s4;
+    constexpr int c0 = e0 > 63 ? 63 : e0, c1 = e1 > 63 ? 63 : e1;
+    constexpr int d0 = e0 + 16 > 63 ? 63 : e0 + 16, d1 = e1 + 16 > 63 ? 63 : e1 + 16;   // dmas_next issues 16 pieces per K-tile
+    if (prev_mode < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (extra) {
+      if (prev_mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d1) : "memory");
+    } else {
+      if (prev_mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c1) : "memory");
+    }
+  };
   if (PM != 0 && !first) {
-    // the previous tile staged K-tiles 0 and 1 beside its last two K-tiles; its epilogue's stores are younger than those
-    // DMAs and counted in the same vmcnt (more than the 63 a counted wait can leave outstanding for the fused epilogues)
+#if REED_PM_DRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    wait_staged(1);
+#endif
     WBARRIER();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
@@ -353,7 +389,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #endif
   int t = 0;
   if constexpr (PM != 0) {   // nt >= 4 (the host checked): K-tile 0's first k-step starts the accumulation
-    WKTILE_(0, 0, true, 0, 0, 1);
+    WKTILE_(0, 0, true, 0, 0, 1, !REED_PM_DRAIN);
     WKTILE(1, 1, true, 0, 0);
     t = 2;
   }
@@ -405,6 +441,12 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #endif
   // epilogue: the wave's piece in 64-column groups through gemm_common.hpp's tile_epilogue (fp32 outputs: its pointer path)
   char* stage = smem + 8 * HTW + wave * EPI_STAGE_BYTES;
+#if REED_EPI_DIRECT
+  if constexpr (EpiDirect<EPI>::value) {
+    tile_epilogue_direct<EPI, NA, NB, 0, REED_EPI_PF>(a, acc, m0, mrow, n0 + ncol);
+    if constexpr (NB == 8) tile_epilogue_direct<EPI, NA, NB, 4, REED_EPI_PF>(a, acc, m0, mrow, n0 + ncol + 64);
+  } else
+#endif
 #pragma unroll
   for (int h = 0; h < NB / 4; ++h) {
     f32x4 part[NA][4];
@@ -509,9 +551,15 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
   // (Measured and dropped in round 4: starting every other workgroup of an XCD 6 / 12 / 18 us late, so that half the chip is in
   // its K loops while the other half is in its epilogues — every shape of the block slower by about the delay itself, none
   // faster: fwd proj 0.241 -> 0.246, fc1 0.678 -> 0.694, dgrad fc2 0.709 -> 0.727 ms at 12 us; gpurun_out/r4a/stagger.txt)
+#ifdef REED_STAGGER_TICKS   // diagnostic build (tools/r4/epi_phase.py): every other workgroup of an XCD starts this many 10 ns ticks late
+  if (s & 1) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < REED_STAGGER_TICKS) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   int tm, tn;
   w_tile_of(run0 + p, ntm, ntn, a.tile_gm, tm, tn);
-  bool first = true;
+  int pmode = -1;   // MODE of the previous tile of this workgroup (-1: none)
   for (;;) {
     const int pn = p + wpx;
     int nmode = -1, tmn = 0, tnn = 0;
@@ -523,8 +571,9 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
     const unsigned long long en0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    if (a.N - tn * WBN <= 128) gemm256w_body<LAY, EPI, 1, 1>(a, smem, tm, tn, first, nmode, tmn, tnn);
-    else gemm256w_body<LAY, EPI, 0, 1>(a, smem, tm, tn, first, nmode, tmn, tnn);
+    const int cmode = (a.N - tn * WBN <= 128) ? 1 : 0;
+    if (cmode) gemm256w_body<LAY, EPI, 1, 1>(a, smem, tm, tn, pmode, nmode, tmn, tnn);
+    else gemm256w_body<LAY, EPI, 0, 1>(a, smem, tm, tn, pmode, nmode, tmn, tnn);
 #ifdef REED_CLK_PROBE
     {
       const unsigned long long en1 = __builtin_amdgcn_s_memrealtime();   // stores issued (not waited for, as the kernel runs)
@@ -541,7 +590,7 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
     p = pn;
     tm = tmn;
     tn = tnn;
-    first = false;
+    pmode = cmode;
   }
 }
 
