@@ -5,6 +5,9 @@
 #include "common.hpp"
 #include "gemm.h"
 
+#ifndef REED_WGRAD_ST_NT
+#define REED_WGRAD_ST_NT 0
+#endif
 namespace gemm_detail {
 
 typedef void __attribute__((address_space(3))) * lds_ptr_t;
@@ -698,7 +701,11 @@ __device__ __forceinline__ void tile_epilogue_ptr(const GemmArgs& a, const f32x4
           f32x4 old = *(const f32x4*)cp;
           o += old;
         }
+#if REED_WGRAD_ST_NT   // weight gradients: 85 MB per block written once, read by the norm / optimiser pass at the end of the step
+        __builtin_nontemporal_store(o, (f32x4*)cp);
+#else
         *(f32x4*)cp = o;
+#endif
       } else if constexpr (EPI == EPI_ADDF32_RB) {
         float* cp = (float*)a.C + rc + n;
         f32x4 old = *(const f32x4*)cp;
