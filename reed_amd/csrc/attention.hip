@@ -24,6 +24,10 @@
 #include "../../include/reed_hip.h"
 #include "common.hpp"
 
+// cache policy (aux bits: 2 = nt) of the LDS-DMA tile loads: Q, K, V, dO are read exactly once per launch.  Build parameter for A/B.
+#ifndef REED_ATTN_LD_AUX
+#define REED_ATTN_LD_AUX 0
+#endif
 namespace {
 
 constexpr int ROWB = 144;            // LDS row stride in bytes (72 bf16): the backward's four resident tiles
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(const bf16* __restr
     const __amdgpu_buffer_rsrc_t rs = mk_rsrc(base, win);
 #pragma unroll
     for (int j = 0; j < 5; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + (wave * 5 + j) * 1024), 16, voff[j], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + (wave * 5 + j) * 1024), 16, voff[j], 0, 0, REED_ATTN_LD_AUX);
   };
   auto base_of = [&](int item) {
     const int b = item / H, h = item - b * H;
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     const __amdgpu_buffer_rsrc_t rs = mk_rsrc(base, win);
 #pragma unroll
     for (int j = 0; j < 5; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wave_rows + j * 1024), 16, voff[j], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wave_rows + j * 1024), 16, voff[j], 0, 0, REED_ATTN_LD_AUX);
   };
   auto base_of = [&](int item) -> const bf16* {
     if (item >= nitems) return nullptr;
@@ -1270,7 +1274,7 @@ __global__ __launch_bounds__(1024 / QT, QT == 4 ? 1 : 2) void attn_bwd_kernel(co
       const bool second = pp >= 36;
       const int I = second ? pp - 36 : pp;
       const int vo = dma_voff<HD, ROWB>(I * 64 + lane, second ? sb1 : sb0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   issue_pair(Kt, base + D, (int)(tok * 2), Vt, base + 2 * D, (int)(tok * 2));
@@ -1543,7 +1547,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ks_kernel(const bf16* __restr
     for (int j = 0; j < 5; ++j) {
       const int I = wave + 8 * j;
       const int vo = dma_voff<HD, ROWB>(I * 64 + lane, sb);
-      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(t + I * 1024), 16, vo, 0, 0, 0);
+      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(t + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   issue_tile(Kt, base + D, (int)(tok * 2));
@@ -1823,7 +1827,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
       const bool second = !whole && pp >= 18;
       const int I = whole ? pp : (second ? pp - 18 : pp) + 18 * half;
       const int vo = dma_voff<HD, ROWB>(I * 64 + ln, second ? sb1 : sb0);
-      if (pp < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, 0);
+      if (pp < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   // the 64 rows of chunk c of the Q and dO tiles (9 + 9 pieces): wave w issues pieces w and w + 8, waves 0 / 1 also 16 / 17
@@ -1835,7 +1839,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ksp_kernel(const bf16* __rest
       const bool second = pp >= 9;
       const int I = 9 * c + (second ? pp - 9 : pp);
       const int vo = dma_voff<HD, ROWB>(I * 64 + ln, second ? db : tokb);
-      if (pp < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? Gt : Qt) + I * 1024), 16, vo, 0, 0, 0);
+      if (pp < 18) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? Gt : Qt) + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {
@@ -2357,7 +2361,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       const int sb = second ? db : tokb;
       const int vo = dma_voff<HD, ROWF>(I * 64 + ln, sb);
       const int v2 = vo == DMA_OOB ? DMA_OOB : vo + c * 64 * sb;
-      if (pp < 20) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? g2 : q) + I * 1024), 16, v2, 0, 0, 0);
+      if (pp < 20) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? g2 : q) + I * 1024), 16, v2, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   // a whole K tile: 36 pieces, waves 0..3 issue 5, waves 4..7 issue 4
@@ -2367,7 +2371,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
     for (int j = 0; j < 5; ++j) {
       const int I = wave + 8 * j;
       const int vo = dma_voff<HD, ROWB>(I * 64 + ln, tokb);   // (not inside the builtin's argument list: clang's host pass then drops the kernel)
-      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, 0);
+      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {

@@ -33,6 +33,8 @@ int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 int reed_num_cus();   // gemm256.hip
 bool reed_gemm128c_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm128c.hip: 128x256 tiles, two workgroups per CU
 int reed_gemm128c_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
+bool reed_gemm_skinny_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm_skinny.hip: 16 x 64 tiles, one wave each
+int reed_gemm_skinny_launch(int epi, GemmArgs a, hipStream_t stream);
 
 namespace {
 using namespace gemm_detail;
@@ -226,7 +228,7 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 / 144 / 257 / 258 = force where the shape allows (tests, A/B timing)
+static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 129 / 256 / 144 / 257 / 258 = force where the shape allows (tests, A/B timing)
 extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
 int reed_gemm_forced_tile() { return g_force_tile; }
 
@@ -304,6 +306,11 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
         if (a.R) t.R = (const char*)a.R + (long)mfull * a.ldr * rb;
         const int rc = reed_gemm_launch(layout, epi, m, splits, stream);
         if (rc != REED_OK) return rc;
+        // the tail: a few rows against the whole weight matrix — bound by how many CUs stream it (gemm_skinny.hip: 16 x 64 tiles,
+        // one wave each; REED_GEMM_SKINNY=0: the 128^2 kernel as before, A/B)
+        static int skinny_on = -1;
+        if (skinny_on < 0) { const char* e = getenv("REED_GEMM_SKINNY"); skinny_on = e ? atoi(e) : 1; }
+        if (skinny_on && reed_gemm_skinny_eligible(layout, epi, t, splits)) return reed_gemm_skinny_launch(epi, t, stream);
         return reed_gemm_launch(layout, epi, t, splits, stream);
       }
     }
@@ -317,6 +324,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
         reed_gemm128c_eligible(layout, epi, a, splits) && want != EPI_BF16_DOT)
       return reed_gemm128c_launch(layout, epi, a, stream);
   }
+  if (g_force_tile == 64 && want != EPI_BF16_DOT && reed_gemm_skinny_eligible(layout, epi, a, splits))
+    return reed_gemm_skinny_launch(epi, a, stream);   // tests: the skinny kernel on any shape it accepts
   if ((g_force_tile == 257 || g_force_tile == 258) && reed_gemm256w_eligible(layout, epi, a, splits))
     return reed_gemm256w_launch(layout, want, a, stream);   // 257: one-shot form, 258: persistent form wherever it applies
   if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits)))) {

@@ -516,6 +516,29 @@ __global__ void reduce_mod_parts_kernel(PartList pl, bf16* __restrict__ dmod, lo
   for (int c = 0; c < chunks; ++c) s += p[(long)c * pl.stride[j]];
   dmod[(long)b * ld + pl.off[j] + d] = f2bf(s);
 }
+// the same sums in the same order, four columns per thread (16-byte loads) and 8 chunks in flight: 43 -> 2x us at b = 256, where the
+// one-column form moved 113 MB at 2.6 TB/s (D, the strides and the offsets multiples of 4: the host checks)
+__global__ __launch_bounds__(64) void reduce_mod_parts4_kernel(PartList pl, bf16* __restrict__ dmod, long ld, int D, int chunks) {
+  const int b = blockIdx.y, j = blockIdx.z;
+  const int d = (blockIdx.x * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  const long st = pl.stride[j];
+  const float* p = pl.ptr[j] + (long)b * chunks * st + d;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 8 <= chunks; c += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *(const f32x4*)(p + (long)(c + k) * st);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; c < chunks; ++c) s += *(const f32x4*)(p + (long)c * st);
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(s[e]);
+  *(bf16x4*)(dmod + (long)b * ld + pl.off[j] + d) = o;
+}
 
 __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, bf16* __restrict__ out,
                                                              int T, int D) {
@@ -706,8 +729,14 @@ extern "C" int reed_reduce_mod_parts(const float* const* parts, const int64_t* s
   PartList pl;
   pl.n = nparts;
   for (int i = 0; i < nparts; ++i) { pl.ptr[i] = parts[i]; pl.stride[i] = strides[i]; pl.off[i] = offs[i]; }
-  REED_KLAUNCH(reduce_mod_parts_kernel, dim3(cdiv(D, 256), B, nparts), dim3(256), 0, (hipStream_t)stream, pl,
-                     (bf16*)dmod, (long)lddmod, D, chunks);
+  bool four = (D % 4) == 0 && (lddmod % 4) == 0 && ((uintptr_t)dmod % 8) == 0;
+  for (int i = 0; i < nparts; ++i) four = four && (strides[i] % 4) == 0 && (offs[i] % 4) == 0 && ((uintptr_t)parts[i] % 16) == 0;
+  if (four)
+    REED_KLAUNCH(reduce_mod_parts4_kernel, dim3(cdiv(D, 256), B, nparts), dim3(64), 0, (hipStream_t)stream, pl,
+                 (bf16*)dmod, (long)lddmod, D, chunks);
+  else
+    REED_KLAUNCH(reduce_mod_parts_kernel, dim3(cdiv(D, 256), B, nparts), dim3(256), 0, (hipStream_t)stream, pl,
+                 (bf16*)dmod, (long)lddmod, D, chunks);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

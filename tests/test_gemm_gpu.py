@@ -8,12 +8,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 128, 256, 144, 257, 258, 129], autouse=True)
+@pytest.fixture(params=[0, 128, 256, 144, 257, 258, 129, 64], autouse=True)
 def force_tile(request):
     """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined with eight
     waves, 256x144 ring — only NT / NN shapes whose N is a multiple of 144 —, 257 = the 256^2 tile with four 128x128 waves —
     NT / NN with K >= 128 and the epilogues it builds —, 129 = the 128x256 tile of two workgroups per CU (csrc/gemm128c.hip: NT
-    plain / GELU / gate + residual, NN plain / dGELU); what a kernel does not take falls to the heuristic)."""
+    plain / GELU / gate + residual, NN plain / dGELU), 64 = the skinny kernel of 16 x 64 one-wave tiles (csrc/gemm_skinny.hip: NT,
+    the tail launch of the ragged-M split); what a kernel does not take falls to the heuristic)."""
     from reed_amd import ops
     ops.gemm_force_tile(request.param)
     yield request.param
@@ -304,8 +305,9 @@ def test_many_tiles(dev, lay, M, N, K):
             ops.gemm(ops.NN, ops.EPI_BF16, x, wq, M, N, K, out, K, N, N, bias=b)
         return out
 
-    o128, o256, o257, o258, o129 = run(128), run(256), run(257), run(258), run(129)
+    o128, o256, o257, o258, o129, o64 = run(128), run(256), run(257), run(258), run(129), run(64)
     ops.gemm_force_tile(0)
+    assert torch.isnan(o64[M]).all() and torch.equal(o64[:M], o256[:M])   # the one-wave 16 x 64 tiles (NT): the same bits
     assert torch.isnan(o128[M]).all() and torch.isnan(o256[M]).all()       # nothing written past row M-1
     assert torch.isnan(o257[M]).all() and torch.isnan(o258[M]).all() and torch.isnan(o129[M]).all()
     # four 128x128 waves, one tile per workgroup / the persistent walk over the tile list / 128x256 tiles, two workgroups per

@@ -47,6 +47,24 @@ def test_ln_modulate_fwd_bwd(dev, B, T, D):
     assert torch.equal(h.float(), bfr(x))
 
 
+@pytest.mark.parametrize("chunks", [16, 5, 24])
+def test_reduce_mod_parts_vector_form_equals_the_scalar_form(dev, chunks):
+    """The four-columns-per-thread form (aligned parts) and the one-column form (a part whose offset is not a multiple of 4
+    columns) sum the chunks in the same order: bit-equal, and equal to the fp64 sum within bf16 rounding."""
+    from reed_amd import ops
+    B, D = 6, 1152
+    g = torch.Generator().manual_seed(11)
+    part = torch.randn(B * chunks, 2, D, generator=g).to(dev)
+    a = torch.zeros(B, 2 * D + 8, dtype=torch.bfloat16, device=dev)
+    b = torch.zeros(B, 2 * D + 8, dtype=torch.bfloat16, device=dev)
+    ops.reduce_mod_parts([(part.data_ptr(), 2 * D, 0), (part.data_ptr() + 4 * D, 2 * D, D)], a, 2 * D + 8, B, D, chunks)
+    ops.reduce_mod_parts([(part.data_ptr(), 2 * D, 2), (part.data_ptr() + 4 * D, 2 * D, D + 6)], b, 2 * D + 8, B, D, chunks)
+    assert torch.equal(a[:, :D], b[:, 2:D + 2]) and torch.equal(a[:, D:2 * D], b[:, D + 6:2 * D + 6])
+    ref = part.double().view(B, chunks, 2, D).sum(1)
+    torch.testing.assert_close(a[:, :D].double(), ref[:, 0], atol=4e-2, rtol=1e-2)
+    torch.testing.assert_close(a[:, D:2 * D].double(), ref[:, 1], atol=4e-2, rtol=1e-2)
+
+
 def test_gate_bwd(dev):
     from reed_amd import ops
     B, T, D = 2, 64, 384
