@@ -113,7 +113,25 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   return fmaf(xs - xs * s, fmaf(d1, x * x, d0), s);
 }
 // nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2)) — the frozen ViT towers' Mlp activation (inference only)
+#if defined(REED_FP32)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
+#else
+// 16-bit builds (round 4): x Phi(x) with Phi from Abramowitz & Stegun 7.1.26 — 0.5 erfc(z) = 0.5 t (a1 + t (a2 + t (a3 + t (a4 + t a5))))
+// exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2, |error of erf| <= 1.5e-7 — formed on the side where it does not cancel (x < 0: Phi = that
+// value, x >= 0: 1 - it): 12 full-rate instructions + v_rcp_f32 + v_exp_f32 where libm's erff is about 60 per element (the fc1
+// GEMM of a DINOv2 / MAE / I-JEPA tower spent 58 of its 192 us there at batch 64).  The result is rounded to 16 bits (2^-9
+// relative); the fp32 build keeps erff.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.7071067811865476f;
+  const float t = fast_rcp(fmaf(0.3275911f, z, 1.f));
+  float q = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  q = fmaf(q, t, 0.5f * 1.421413741f);
+  q = fmaf(q, t, 0.5f * -0.284496736f);
+  q = fmaf(q, t, 0.5f * 0.254829592f);
+  q = q * t * fast_exp2(z * z * -1.4426950408889634f);
+  return x * (x < 0.f ? q : 1.f - q);
+}
+#endif
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
   float s = sigmoid_f(x);
