@@ -97,9 +97,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* p, long b
   if (bytes > 0x7FFF0000l) bytes = 0x7FFF0000l;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
 }
+template <int AUX = 0>
 __device__ __forceinline__ bf16x8 ld_bf16x8(__amdgpu_buffer_rsrc_t rs, int off, int soff = 0) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0));
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, AUX));
 }
+// REED_EPI_SAVED_NT (round 4): the arrays an epilogue writes for the BACKWARD pass only (fc1's pre-activation, the gate + residual
+// epilogue's y) and the saved activations a backward epilogue reads once (dGELU's pre-activation, the head-dot epilogue's O) with
+// the non-temporal policy: they do not displace what the next kernel reads back (the selective form of the store-policy experiment
+// above, where the consumers paid for an all-or-nothing policy)
+#ifndef REED_EPI_SAVED_NT
+#define REED_EPI_SAVED_NT 0
+#endif
+constexpr int EPI_SAVED_AUX = REED_EPI_SAVED_NT ? 2 : 0;
 // Cache policy of the epilogues' output stores (aux bits of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1).  Round 4, measured
 // (profiles/r4_epilogue_store_policy.txt): with its stores switched off a plain-output GEMM loses 43 us of its 430 at b = 256 while
 // its epilogues get only 0.4 us per tile shorter — the output stream costs by what it does to the K loops that follow (it
@@ -214,7 +223,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
       bf16x8 rr[NI][2];
       auto fetch = [&](int i) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) rr[i][h] = ld_bf16x8(rsR, orr + (2 * i + h) * r8);
+        for (int h = 0; h < 2; ++h) rr[i][h] = ld_bf16x8<EPI_SAVED_AUX>(rsR, orr + (2 * i + h) * r8);
       };
       auto sum8 = [](float x) {     // lanes 8 k .. 8 k + 7 -> their sum in lane 8 k
         x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -291,7 +300,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
             else
               act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
           }
-          st_bf16x8<SA>(pre, rsC, oc + h * s8);    // empty descriptor when the pre-activation is not wanted
+          st_bf16x8<SA | EPI_SAVED_AUX>(pre, rsC, oc + h * s8);    // empty descriptor when the pre-activation is not wanted
           st_bf16x8<SA>(act, rsC2, oc2 + h * t8);
         }
       }
@@ -374,7 +383,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
             st_f32x4<SA>(xo[0], rsC, dro);
             st_f32x4<SA>(xo[1], rsC, dro);
 #else
-            st_bf16x8<SA>(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
+            st_bf16x8<SA | EPI_SAVED_AUX>(y, rsY, oy + h * y8);      // empty descriptor when y is not wanted
             st_f32x4<SA>(xo[0], rsC, oc + h * s8);
             st_f32x4<SA>(xo[1], rsC, oc + h * s8 + 16);
 #endif
@@ -421,7 +430,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
       bf16x8 pre[NI][2];
       auto fetch = [&](int i) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) pre[i][h] = ld_bf16x8(rsR, orr + i * 2 * r8 + h * r8);
+        for (int h = 0; h < 2; ++h) pre[i][h] = ld_bf16x8<(EPI == EPI_DGELU || EPI == EPI_DSILU) ? EPI_SAVED_AUX : 0>(rsR, orr + i * 2 * r8 + h * r8);
       };
       constexpr int PFD = 2 * PF;   // 8 registers per row group: twice the depth of the fp32 residual's
 #pragma unroll

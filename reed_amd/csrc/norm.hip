@@ -239,52 +239,58 @@ struct HalfRow {
 #pragma unroll
     for (int t = 0; t < TS; ++t) vo[NF + t] = half0 + 256 * NF + 64 * t + lane;
   }
+  template <int AUX = 0>
   __device__ __forceinline__ void ld_f32(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const {
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-      f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] * 4, soff, 0));
+      f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[k] * 4, soff, AUX));
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * k + j] = t[j];
     }
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      v[4 * NF + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[NF + t] * 4, soff, 0));
+      v[4 * NF + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[NF + t] * 4, soff, AUX));
   }
+  template <int AUX = 0>
   __device__ __forceinline__ void st_f32(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const {
 #pragma unroll
     for (int k = 0; k < NF; ++k)
       __builtin_amdgcn_raw_buffer_store_b128(
-          __builtin_bit_cast(u32x4_t, f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]}), rs, vo[k] * 4, soff, 0);
+          __builtin_bit_cast(u32x4_t, f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]}), rs, vo[k] * 4, soff, AUX);
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[4 * NF + t]), rs, vo[NF + t] * 4, soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[4 * NF + t]), rs, vo[NF + t] * 4, soff, AUX);
   }
 #ifdef REED_FP32   // the "16-bit" arrays are fp32 arrays in this build (common.hpp): the same accesses as ld_f32 / st_f32
-  __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const { ld_f32(rs, soff, v); }
-  __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const { st_f32(rs, soff, v); }
+  template <int AUX = 0>
+  __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const { ld_f32<AUX>(rs, soff, v); }
+  template <int AUX = 0>
+  __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const { st_f32<AUX>(rs, soff, v); }
 #else
+  template <int AUX = 0>
   __device__ __forceinline__ void ld_bf(__amdgpu_buffer_rsrc_t rs, int soff, float (&v)[NE]) const {   // bf16 -> f32
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-      const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] * 2, soff, 0));
+      const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, vo[k] * 2, soff, AUX));
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * k + j] = bf2f(t[j]);
     }
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      v[4 * NF + t] = bf2f(__builtin_bit_cast(bf16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo[NF + t] * 2, soff, 0)));
+      v[4 * NF + t] = bf2f(__builtin_bit_cast(bf16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo[NF + t] * 2, soff, AUX)));
   }
+  template <int AUX = 0>
   __device__ __forceinline__ void st_bf(__amdgpu_buffer_rsrc_t rs, int soff, const float (&v)[NE]) const {
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
       bf16x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = f2bf(v[4 * k + j]);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), rs, vo[k] * 2, soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), rs, vo[k] * 2, soff, AUX);
     }
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f2bf(v[4 * NF + t])), rs, vo[NF + t] * 2, soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f2bf(v[4 * NF + t])), rs, vo[NF + t] * 2, soff, AUX);
   }
 #endif
   // LDS (column partials): plain pointers
@@ -296,6 +302,10 @@ struct HalfRow {
   }
 };
 
+#ifndef REED_LNB_NT
+#define REED_LNB_NT 1
+#endif
+constexpr int LNB_AUX = REED_LNB_NT ? 2 : 0;
 template <bool GATE, int NF, int TS>
 __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
     const bf16* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ mean,
@@ -332,10 +342,14 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
     const int lr = rg * 4 + rr;      // row inside the block; global row < M: the grid is M / 16 blocks, M % 16 == 0
     const float mu = mean[blk0 + lr], r = rstd[blk0 + lr];
     float xh[NE], gy[NE], o[NE], yin[GATE ? NE : 1];
-    hr.ld_f32(rsX, lr * D * 4, xh);   // all of the row's loads first
+    // REED_LNB_NT (round 4, default): the saved activations x and y (read once, from HBM) and the residual gradient (read and
+    // re-written in place, next touched two GEMMs and an attention later) with the non-temporal policy; dh (the dgrad GEMM's output)
+    // and dy (the next GEMMs' operand) stay cacheable.  Whole step at b = 256: 1269.9 -> 1279.3 images/s (three pairs), b = 32
+    // unchanged (profiles/r4_row_kernel_nt.txt); bit-identical
+    hr.template ld_f32<LNB_AUX>(rsX, lr * D * 4, xh);   // all of the row's loads first
     hr.ld_bf(rsDH, lr * D * HB, gy);
-    hr.ld_f32(rsDX, lr * D * 4, o);
-    if constexpr (GATE) hr.ld_bf(rsY, lr * D * HB, yin);
+    hr.template ld_f32<LNB_AUX>(rsDX, lr * D * 4, o);
+    if constexpr (GATE) hr.template ld_bf<LNB_AUX>(rsY, lr * D * HB, yin);
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(512, 4) void ln_mod_bwd2_kernel(
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) o[e] += r * (gy[e] - a1 - xh[e] * a2);
-    hr.st_f32(rsDX, lr * D * 4, o);
+    hr.template st_f32<LNB_AUX>(rsDX, lr * D * 4, o);
     if constexpr (GATE) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
