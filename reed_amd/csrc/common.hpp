@@ -112,6 +112,23 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   float xs = x * s;
   return fmaf(xs - xs * s, fmaf(d1, x * x, d0), s);
 }
+// Two elements at a time (round 4): the same operations as gelu_tanh_f / gelu_tanh_grad_f on v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32 — for ONE wave per SIMD a packed instruction issues in the 4 cycles of a plain one (tools/micro/valu_rate.hip), the
+// compiler's SLP pass packs only about a third of the scalar form's multiplies and adds, and the GELU / dGELU epilogues of the
+// four-wave GEMM are vector-issue-bound.  exp and rcp stay per element (8 cycles each).
+__device__ __forceinline__ f32x2 gelu_sig2(f32x2 x) {
+  const float c0 = -2.f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+  const f32x2 t = x * __builtin_elementwise_fma(f32x2{c1, c1}, x * x, f32x2{c0, c0});
+  const f32x2 d = f32x2{fast_exp2(t[0]), fast_exp2(t[1])} + 1.f;
+  return f32x2{fast_rcp(d[0]), fast_rcp(d[1])};
+}
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) { return x * gelu_sig2(x); }
+__device__ __forceinline__ f32x2 gelu_tanh_grad2(f32x2 x) {
+  const float d0 = 2.f * 0.7978845608028654f, d1 = d0 * 3.f * 0.044715f;
+  const f32x2 s = gelu_sig2(x);
+  const f32x2 xs = x * s;
+  return __builtin_elementwise_fma(xs - xs * s, __builtin_elementwise_fma(f32x2{d1, d1}, x * x, f32x2{d0, d0}), s);
+}
 // nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2)) — the frozen ViT towers' Mlp activation (inference only)
 #if defined(REED_FP32)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }

@@ -105,6 +105,10 @@ __device__ __forceinline__ bf16x8 ld_bf16x8(__amdgpu_buffer_rsrc_t rs, int off, 
 // epilogue's y) and the saved activations a backward epilogue reads once (dGELU's pre-activation, the head-dot epilogue's O) with
 // the non-temporal policy: they do not displace what the next kernel reads back (the selective form of the store-policy experiment
 // above, where the consumers paid for an all-or-nothing policy)
+// 1: the GELU / dGELU epilogues on packed fp32 pairs (common.hpp: gelu_tanh2, gelu_tanh_grad2); 0: the scalar forms (A/B build)
+#ifndef REED_EPI_PACKED
+#define REED_EPI_PACKED 1
+#endif
 #ifndef REED_EPI_SAVED_NT
 #define REED_EPI_SAVED_NT 0
 #endif
@@ -287,6 +291,15 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bf16x8 pre, act;
+          if constexpr (EPI == EPI_GELU && REED_EPI_PACKED) {   // two elements per instruction (common.hpp: gelu_tanh2)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bf16x2 p2 = __builtin_convertvector(f32x2{v[h][2 * k], v[h][2 * k + 1]}, bf16x2);
+              const bf16x2 a2 = __builtin_convertvector(gelu_tanh2(__builtin_convertvector(p2, f32x2)), bf16x2);
+              pre[2 * k] = p2[0]; pre[2 * k + 1] = p2[1];
+              act[2 * k] = a2[0]; act[2 * k + 1] = a2[1];
+            }
+          } else
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             pre[e] = f2bf(v[h][e]);
@@ -444,6 +457,15 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bf16x8 o;
+          if constexpr (EPI == EPI_DGELU && REED_EPI_PACKED) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x2 du = __builtin_convertvector(__builtin_convertvector(f32x2{v[h][2 * k], v[h][2 * k + 1]}, bf16x2), f32x2);
+              const f32x2 x = __builtin_convertvector(bf16x2{pre[i][h][2 * k], pre[i][h][2 * k + 1]}, f32x2);
+              const bf16x2 o2 = __builtin_convertvector(du * gelu_tanh_grad2(x), bf16x2);
+              o[2 * k] = o2[0]; o[2 * k + 1] = o2[1];
+            }
+          } else
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float du = bfround(v[h][e]);
