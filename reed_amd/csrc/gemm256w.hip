@@ -52,6 +52,10 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_EPI_DIRECT
 #define REED_EPI_DIRECT 0
 #endif
+// 1: the four-wave TN form (weight gradients, REED_WGRAD_W4=1) walks its K-tile buffers as a ring of four 32-row slices (below)
+#ifndef REED_TN_RING
+#define REED_TN_RING 1
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -388,6 +392,69 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
   int t = 0;
+#if REED_TN_RING
+  // TN (weight gradients), round 4: the two K-tile buffers as a RING of four 32-row slices.  Both operands of a weight gradient
+  // stream from HBM (a tile walks all b * 256 tokens of two column blocks), and with the loop above a slice is issued two phases
+  // before its wait: the K-tile took 1.5 us whatever its MFMA count (MODE 1-3 tiles included) — a latency, not a rate.  Here slice
+  // u + 4 is issued in phase u, right behind the barrier that says every wave has read slice u (same LDS bytes), and waited for
+  // at the start of phase u + 3: three phases in flight instead of two, 8 DMAs per phase instead of 16 in every second one, a
+  // barrier per phase.  Every slice is issued whatever its index (rows >= K are outside the descriptor: zeros, never read), so the
+  // wait is one counted vmcnt: the two youngest slices (ND pieces) may be outstanding — in phase 1, where the prologue's K-tile 1
+  // went out with its two slices interleaved, one (ND / 2).
+  if constexpr (LAY == LAY_TN && PM == 0) {
+    auto dmas32 = [&](int t64, int cur, int ks, int c) {
+#pragma unroll
+      for (int e = 0; e < ND; ++e) {
+        if (((e & 3) >> 1) != ks) continue;
+        const int p = (e >> 2) * 2 + (e & 1);
+        if (p * NCH / (ND / 2) == c) dma(t64, cur, e);
+      }
+    };
+    auto ring_wait = [&](bool one) {
+      if (one) {
+        if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+    };
+#define WRING(T, CUR)                                                                        \
+  do {                                                                                       \
+    const int t_ = (T);                                                                      \
+    asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));       \
+    /* phase 2 t: MFMAs of (t, ks0); reads of (t, ks1); DMAs of (t + 2, ks0) into the slice (t, ks0) came from */ \
+    ring_wait(false);                                                                        \
+    WLGKM0();                                                                                \
+    WBARRIER();                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                        \
+      ldfrag((CUR), 1, c);                                                                   \
+      dmas32(t_ + 2, (CUR), 0, c);                                                           \
+      WMMA4(0, c, 0);                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+    /* phase 2 t + 1: MFMAs of (t, ks1); reads of (t + 1, ks0); DMAs of (t + 2, ks1) */       \
+    ring_wait(t_ == 0);                                                                      \
+    WLGKM0();                                                                                \
+    WBARRIER();                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                        \
+      ldfrag(1 - (CUR), 0, c);                                                               \
+      dmas32(t_ + 2, (CUR), 1, c);                                                           \
+      WMMA4(1, c, 0);                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+  } while (0)
+    for (; t + 1 < nt; t += 2) {
+      WRING(t, 0);
+      WRING(t + 1, 1);
+    }
+    if (t < nt) { WRING(t, 0); ++t; }
+#undef WRING
+  } else
+#endif
+  {
   if constexpr (PM != 0) {   // nt >= 4 (the host checked): K-tile 0's first k-step starts the accumulation
     WKTILE_(0, 0, true, 0, 0, 1, !REED_PM_DRAIN);
     WKTILE(1, 1, true, 0, 0);
@@ -409,6 +476,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       WKTILE(t + 1, 1, t_ + 2 < nt, 0, 0);
     }
     if (t < nt) WKTILE(t, 0, false, 0, 0);
+  }
   }
 
   // the MFMAs are inline asm: the compiler does not know the accumulators were just written by the matrix pipe

@@ -16,7 +16,9 @@ typedef void __attribute__((address_space(3))) * lds_ptr_t;
 constexpr int HT = 16384;   // half-tile: 128 rows x 64 k bf16
 constexpr int LDS_BYTES = 8 * HT;
 
-template <int M32, int DMA_ON>
+// TR: every fragment through two ds_read_b64_tr_b16 (both operands k-strided: the weight gradients' TN product; 64 transposing
+// reads per K-tile and wave) instead of one ds_read_b128
+template <int M32, int DMA_ON, int TR = 0>
 __global__ __launch_bounds__(256, 1) void k(const __bf16* __restrict__ src, float* out, int iters, long long* cyc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -53,6 +55,14 @@ __global__ __launch_bounds__(256, 1) void k(const __bf16* __restrict__ src, floa
       a = ((t < 4 ? rA : rB) ^ (ks ? 64 : 0) ^ (s ? 32 : 0)) + cur * HT + (t & 3) * 4096;
     } else {
       a = ((f < 8 ? rA : rB) ^ (ks ? 64 : 0)) + cur * HT + (f & 7) * 2048;
+    }
+    if constexpr (TR) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 lo, hi;
+      const unsigned ad = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)(smem + a);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(hi) : "v"(ad));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     return *(const bf16x8*)(smem + a);
   };
@@ -111,16 +121,16 @@ __global__ __launch_bounds__(256, 1) void k(const __bf16* __restrict__ src, floa
   if (tid == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
-template <int M32, int DMA_ON>
+template <int M32, int DMA_ON, int TR = 0>
 static void run(const char* name, const __bf16* src, float* out, long long* cyc) {
-  hipFuncSetAttribute((const void*)k<M32, DMA_ON>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipFuncSetAttribute((const void*)k<M32, DMA_ON, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const int iters = 40000;   // ~ 50 ms
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<M32, DMA_ON>), dim3(256), dim3(256), LDS_BYTES, 0, src, out, iters, cyc);
+    hipLaunchKernelGGL((k<M32, DMA_ON, TR>), dim3(256), dim3(256), LDS_BYTES, 0, src, out, iters, cyc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -147,6 +157,8 @@ int main() {
   run<1, 1>("32x32x16, reads + DMA", src, out, cyc);
   run<0, 0>("16x16x32, reads only", src, out, cyc);
   run<1, 0>("32x32x16, reads only", src, out, cyc);
+  run<0, 1, 1>("16x16x32, 64 transposing reads + DMA", src, out, cyc);
+  run<0, 0, 1>("16x16x32, 64 transposing reads only", src, out, cyc);
   run<0, 1>("16x16x32, reads + DMA (again)", src, out, cyc);
   run<1, 1>("32x32x16, reads + DMA (again)", src, out, cyc);
   return 0;
