@@ -536,8 +536,8 @@ def main():
     T_TOK = 256
 
     def probe(tokens, shapes):
-        # the kernel with the largest share of the step (rocprofv3 --stats, profiles/): gemm_tn_group_kernel = the four weight
-        # gradients of a transformer block in one launch (csrc/gemm_tn.hip); key = its algorithmic flop
+        # the kernel with the largest share of the step (rocprofv3 --stats, profiles/): the four weight gradients of a transformer
+        # block in one launch (csrc/gemm256w.hip's four-wave TN form, or csrc/gemm_tn.hip's); key = its algorithmic flop
         if tokens == b * T_TOK and len(shapes) == 4:
             return 2.0 * tokens * sum(n * k for n, k in shapes)
         return None
@@ -731,10 +731,14 @@ def main():
                     "frac": round(ach * 1e12 / PEAK_BF16, 4),
                     "traffic": TRAFFIC_B256 if (b == 256 and args.model == "SiT-XL/2") else None,
                     "traffic_source": TRAFFIC_SOURCE if (b == 256 and args.model == "SiT-XL/2") else None,
-                    "kernel": "gemm_tn_group_kernel = the weight (+ bias) gradients of one transformer block's four linears (fc2, fc1, "
-                              "proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch of 256x128 / 128x256 tiles without split-K; "
-                              "algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration of every such launch "
-                              "INSIDE the timed region (events on the launch stream; the largest single share of the step)",
+                    "kernel": "the grouped weight-gradient launch = the weight (+ bias) gradients of one transformer block's four "
+                              "linears (fc2, fc1, proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch: gemm256w_tn_group_kernel "
+                              "(csrc/gemm256w.hip: 256^2 tiles of four 128x128 waves, one workgroup per CU, the ragged tiles cut along K "
+                              "and summed by wgrad_split_reduce_kernel, which the timing includes) or, with REED_WGRAD_W4=0 or where "
+                              "that form does not apply, gemm_tn_group_kernel (csrc/gemm_tn.hip: 256x128 / 128x256 tiles, two "
+                              "workgroups per CU); algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration "
+                              "of every such launch INSIDE the timed region (events on the launch stream; the largest single share "
+                              "of the step)",
                     "launches_timed": n_l, "avg_ms_per_launch": round(tot_ms / n_l, 4),
                     "flop_per_launch": next(iter(dom))}
             else:

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 
 #include "gemm_common.hpp"
@@ -74,6 +75,14 @@ __device__ __forceinline__ int wvoff_tr(int tid, long ld) {    // round 0 of a k
   return (int)(((long)r * ld + (chp ^ tr_sw(r)) * 8) * 2);
 }
 
+// the same on LDS byte addresses (TN: the lane bases already include the LDS base of the dynamic segment; no pointer arithmetic)
+template <int OFF>
+__device__ __forceinline__ bf16x8 wtr2u(unsigned a0, unsigned a1) {
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(OFF));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 template <int OFF>
 __device__ __forceinline__ bf16x8 wtr2(const char* a0, const char* a1) {
   bf16x4 lo = ds_read_tr16_off<OFF>(a0);
@@ -189,6 +198,10 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   const int trow = (8 * lg + lq) * 256 + ((lp >> 1) << 4) + ((lp & 1) << 3);
   int tA0 = wslotA(aHalf, 0) + trow, tB0 = wslotB(bHalf, 0) + trow;
   int tSA = (xe << 5) ^ (aQuart << 7), tSB = (xe << 5) ^ (bQuart << 7);
+  // TN (both operands transposing): the two read addresses of fragment i are (lane base) XOR (i << 5) — the row part of a base has
+  // no bit in 5..7, where the slot swizzle and the tile index live — one vector instruction per read instead of add / xor / add
+  const unsigned lds0 = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)smem;   // a multiple of 256 at least
+  unsigned uA0 = lds0 + tA0 + tSA, uA1 = lds0 + ((tA0 + 1024) ^ 16) + tSA, uB0 = lds0 + tB0 + tSB, uB1 = lds0 + ((tB0 + 1024) ^ 16) + tSB;
 
   bf16x8 Af[2][NA], Bf[2][NB];
   auto ldA = [&](int cur, int ks, int i) {
@@ -196,6 +209,12 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       const char* q = smem + (ks ? (rA ^ 64) : rA) + cur * HTW;
       Af[ks][i] = *(const bf16x8*)(q + i * 2048);
     } else {
+      if constexpr (LAY == LAY_TN) {
+        const unsigned q0 = uA0 ^ (unsigned)(i << 5), q1 = uA1 ^ (unsigned)(i << 5);
+        if (cur == 0) Af[ks][i] = ks ? wtr2u<8192>(q0, q1) : wtr2u<0>(q0, q1);
+        else Af[ks][i] = ks ? wtr2u<HTW + 8192>(q0, q1) : wtr2u<HTW>(q0, q1);
+        return;
+      }
       const int sl = tSA ^ (i << 5);
       const char* p0 = smem + (tA0 + sl);
       const char* p1 = smem + (((tA0 + 1024) ^ 16) + sl);
@@ -208,6 +227,12 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       const char* q = smem + (ks ? (rB ^ 64) : rB) + cur * HTW;
       Bf[ks][i] = *(const bf16x8*)(q + i * 2048);
     } else {
+      if constexpr (LAY == LAY_TN) {
+        const unsigned q0 = uB0 ^ (unsigned)(i << 5), q1 = uB1 ^ (unsigned)(i << 5);
+        if (cur == 0) Bf[ks][i] = ks ? wtr2u<8192>(q0, q1) : wtr2u<0>(q0, q1);
+        else Bf[ks][i] = ks ? wtr2u<HTW + 8192>(q0, q1) : wtr2u<HTW>(q0, q1);
+        return;
+      }
       const int sl = tSB ^ (i << 5);
       const char* p0 = smem + (tB0 + sl);
       const char* p1 = smem + (((tB0 + 1024) ^ 16) + sl);
@@ -421,10 +446,18 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       }
     };
+    // DB: this workgroup also forms the bias gradient (one more MFMA per row tile against a fragment of ones; the tiles of a problem's
+    // first column block only): its own copy of the loop — as a run-time condition it was a branch in every second chunk
+#define WMMA4R(KS, C)                                                                                    \
+  _Pragma("unroll") for (int j = W_CJ(C); j < W_CJ(C) + 4; ++j)                                          \
+    REED_MFMA_ACC(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);                                      \
+  if constexpr (DB) {                                                                                    \
+    if (W_CJ(C) == 0) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]);                           \
+  }
 #define WRING(T, CUR)                                                                        \
   do {                                                                                       \
     const int t_ = (T);                                                                      \
-    asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));       \
+    asm volatile("" : "+v"(uA0), "+v"(uA1), "+v"(uB0), "+v"(uB1));                            \
     /* phase 2 t: MFMAs of (t, ks0); reads of (t, ks1); DMAs of (t + 2, ks0) into the slice (t, ks0) came from */ \
     ring_wait(false);                                                                        \
     WLGKM0();                                                                                \
@@ -432,7 +465,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                        \
       ldfrag((CUR), 1, c);                                                                   \
       dmas32(t_ + 2, (CUR), 0, c);                                                           \
-      WMMA4(0, c, 0);                                                                        \
+      WMMA4R(0, c);                                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                     \
     }                                                                                        \
     /* phase 2 t + 1: MFMAs of (t, ks1); reads of (t + 1, ks0); DMAs of (t + 2, ks1) */       \
@@ -442,16 +475,22 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                        \
       ldfrag(1 - (CUR), 0, c);                                                               \
       dmas32(t_ + 2, (CUR), 1, c);                                                           \
-      WMMA4(1, c, 0);                                                                        \
+      WMMA4R(1, c);                                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                     \
     }                                                                                        \
   } while (0)
-    for (; t + 1 < nt; t += 2) {
-      WRING(t, 0);
-      WRING(t + 1, 1);
-    }
-    if (t < nt) { WRING(t, 0); ++t; }
+    auto ring = [&](auto db_c) {
+      constexpr bool DB = decltype(db_c)::value;
+      for (; t + 1 < nt; t += 2) {
+        WRING(t, 0);
+        WRING(t + 1, 1);
+      }
+      if (t < nt) { WRING(t, 0); ++t; }
+    };
+    if (do_dbias) ring(std::true_type{});
+    else ring(std::false_type{});
 #undef WRING
+#undef WMMA4R
   } else
 #endif
   {
@@ -667,12 +706,48 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
 // tiles: 243 tile equivalents for 256 CUs).  Workgroup order: every XCD gets a contiguous run of the full tiles (shared
 // operand column blocks stay in its L2), then a run of the ragged ones — the hardware dispatches in blockIdx order, so the
 // 275 - 256 workgroups that do not fit at once are short ones and start when the first short ones finish, at half time.
+// Round 4: the census.  A block's four weight matrices are 212 full + 61 half + 2 quarter tiles: 275 workgroups for 256 CUs — 34-35
+// per XCD of 32 CUs, and the hardware hands workgroup b to XCD b % 8: in every XCD three ragged tiles wait for the first ragged ones
+// to finish and the launch takes two ragged-tile times (1.8 ms) with the full tiles done at 1.45 (stamps: profiles/r4_wgrad_w4_ring.txt).
+// So the half tiles (MODE 1 / 2, except a bias-gradient tile) are cut in two along K: 0.45 ms pieces that fill the 5-6 CUs an XCD
+// has left beside its full tiles in three rounds.  The two pieces of a tile write fp32 partial tiles into a slab (plain stores,
+// local coordinates) and wgrad_split_reduce_kernel adds them in a fixed order (+ the old value when accumulating): deterministic;
+// the summation order of those tiles differs from the unsplit kernel's (two partial sums: 1e-7 relative).  Handing the pieces out as
+// workgroups of their own did not do it (the dispatcher places workgroups in order, each on XCD b % 8: 1.93 ms, the last piece
+// starting at 1.48 ms), so the form is STATIC: one workgroup per CU; in every XCD the first cf take one full tile each, the others walk
+// lists of ragged items the host has balanced (longest first: bias-gradient half tiles 2, quarter tiles 1.3, pieces 1 unit).
 struct TnGroupW {
   GemmArgs a[4];
   int n;
   int fm[4], fn[4], rm[4], rn[4];   // full tile rows / columns, ragged (128-wide) last row / column present
   int nfull, nrag;
+  int nitem;                        // > 0: static form — exactly one workgroup per CU, the ragged work is item[] dealt by the host
+  int wpx;                          // workgroups (= CUs) per XCD in that form
+  unsigned short wstart[66];        // ragged workgroup id -> its first item (wstart[id + 1]: one past its last)
+  unsigned item[176];               // p | mode << 2 | tm << 4 | tn << 12 | split << 21 | slab slot << 22
+  unsigned krange[176];             // first K-tile (of 64 tokens) | K-tiles << 16 of the item
+  float* slab;                      // [slots][256 * 128] partial tiles
 };
+constexpr int SPLIT_TILE = 256 * 128;
+constexpr int SPLIT_SLOTS = 176;
+struct SplitReduceArgs {
+  float* out[64];      // the tile's first element in its weight-gradient matrix
+  int ldc[64];
+  short cols[64];      // 128 (a 256 x 128 tile) or 256 (128 x 256)
+  short first[64], cnt[64];   // its partial tiles: slab slots first .. first + cnt - 1, added in that order
+  int n, accumulate;
+  const float* slab;
+};
+__global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(SplitReduceArgs r) {
+  const int q = blockIdx.y, i4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // 4 consecutive columns of one row of the tile
+  const int cols = r.cols[q], row = i4 / cols, col = i4 - row * cols;
+  const float* sp = r.slab + (long)r.first[q] * SPLIT_TILE + i4;
+  f32x4 v = *(const f32x4*)sp;
+  for (int k = 1; k < r.cnt[q]; ++k) v += *(const f32x4*)(sp + (long)k * SPLIT_TILE);
+  float* o = r.out[q] + (long)row * r.ldc[q] + col;
+  if (r.accumulate) v += *(const f32x4*)o;
+  *(f32x4*)o = v;
+}
 __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -680,14 +755,42 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   const int cf = qf + (xcd < rf), sf = xcd * qf + min(xcd, rf);
   const int cr = qr + (xcd < rr), sr = xcd * qr + min(xcd, rr);
   int p = 0, tm, tn, mode;
-  if (j < cf) {
+  int piece = -1;   // >= 0: the item is a K range of a split tile and writes slab slot `piece` (static form)
+  if (g.nitem > 0 && j >= cf) {   // static form: this workgroup walks its list of ragged items
+    const int id = g.wpx * xcd - sf + (j - cf);
+    for (int r = g.wstart[id]; r < g.wstart[id + 1]; ++r) {
+      const unsigned it = g.item[r], kr = g.krange[r];
+      p = it & 3; mode = (it >> 2) & 3; tm = (it >> 4) & 255; tn = (it >> 12) & 255;
+      piece = ((it >> 21) & 1) ? (int)(it >> 22) : -1;
+      GemmArgs a = g.a[p];
+      if (piece >= 0) {   // a sub-problem in local coordinates: the tile's rows x columns of C from the item's range of tokens
+        const long k0 = (long)(kr & 0xFFFF) * WBK;
+        a.P += k0 * a.ldp + tm * WBM;
+        a.Q += k0 * a.ldq + tn * WBN;
+        a.K = (int)(kr >> 16) * WBK;
+        a.M = mode == 1 ? WBM : 128;
+        a.N = mode == 1 ? 128 : WBN;
+        a.C = g.slab + (long)piece * SPLIT_TILE;
+        a.ldc = a.N;
+        a.dbias = nullptr;
+        a.accumulate = 0;
+        tm = 0;
+        tn = 0;
+      }
+      if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
+      else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);
+      else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
+      __syncthreads();   // every wave is out of the item's last K-tile before the next item's first DMA
+    }
+    return;
+  } else if (j < cf) {
     int F = sf + j;
     while (p < g.n - 1 && F >= g.fm[p] * g.fn[p]) { F -= g.fm[p] * g.fn[p]; ++p; }
     tm = F / g.fn[p];
     tn = F - tm * g.fn[p];
     mode = 0;
   } else {
-    if (j - cf >= cr) return;
+    if (g.nitem > 0 || j - cf >= cr) return;
     int R = sr + (j - cf);
     for (;;) {
       const int nr = g.rn[p] * g.fm[p] + g.rm[p] * g.fn[p] + g.rm[p] * g.rn[p];
@@ -863,12 +966,13 @@ int reed_gemm_forced_tile();  // gemm.hip
 // 1 = launched; 0 = the problems do not suit this kernel (the caller falls back to gemm_tn.hip's grouped launch)
 int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream, int* launched) {
   *launched = 0;
-  // Off by default.  Measured at b = 256 (tools/bench_wgrad_group.py): 2.70 ms against 2.00 ms for gemm_tn.hip's grouped launch.
-  // With both operands k-strided a K-tile costs this kernel 1.5 us whatever the MFMA count (64 transposing LDS reads per
-  // wave and K-tile: the LDS pipe, not the matrix pipe, paces it), so the 63 ragged tiles take ~0.8 of a full tile's time
-  // instead of half, and the 19 workgroups beyond the 256 CUs add that to the launch.  REED_WGRAD_W4=1 enables it.
-  static const bool on = getenv("REED_WGRAD_W4") && atoi(getenv("REED_WGRAD_W4")) == 1;
-  if (!on || reed_gemm_forced_tile() == 128) return REED_OK;   // force_tile 128: gemm_tn.hip's grouped kernel (tests, A/B)
+  // Round 4: the default where its static form applies (one workgroup per CU, ragged tiles cut along K: see TnGroupW) — with the
+  // K-tile buffers walked as a ring and one vector instruction per transposing read it measures 0.254-0.271 / 0.454 / 0.896 / 1.81 ms
+  // at b = 32 / 64 / 128 / 256 against 0.282-0.294 / 0.476 / 0.942 / 1.85 for gemm_tn.hip's grouped launch, and 1.72 against 1.82 ms
+  // inside the step (profiles/r4_wgrad_w4_ring.txt).  (Round 3's form of it: 2.70 ms.)  REED_WGRAD_W4=0: off; =1: also where only
+  // the dynamic form (one workgroup per tile, slower than gemm_tn.hip's) applies — A/B.
+  static const int w4mode = getenv("REED_WGRAD_W4") ? atoi(getenv("REED_WGRAD_W4")) : -1;   // -1 = auto
+  if (w4mode == 0 || reed_gemm_forced_tile() == 128) return REED_OK;   // force_tile 128: gemm_tn.hip's grouped kernel (tests, A/B)
   TnGroupW g;
   memset(&g, 0, sizeof(g));
   g.n = n;
@@ -893,9 +997,107 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
     if (e != hipSuccess) { reed_set_error("gemm256w: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  const int grid = 8 * (cdiv(g.nfull, 8) + cdiv(g.nrag, 8));
+  // the static form with the ragged tiles cut along K (see TnGroupW); REED_WGRAD_W4_SPLIT=0: the dynamic form (A/B)
+  static const bool split_on = !(getenv("REED_WGRAD_W4_SPLIT") && atoi(getenv("REED_WGRAD_W4_SPLIT")) == 0);
+  static float* slab = nullptr;
+  bool k_ok = true;
+  for (int i = 0; i < n; ++i)
+    k_ok = k_ok && (probs[i].K % WBK) == 0 && probs[i].K >= 16 * WBK && probs[i].K / WBK < 65536 && probs[i].slab_stride == 0 &&
+           probs[i].K == probs[0].K;
+  SplitReduceArgs rd;
+  memset(&rd, 0, sizeof(rd));
+  const int nw = ncu - g.nfull;
+  if (split_on && k_ok && g.nfull + g.nrag > ncu && nw >= 1 && nw <= 64 && (ncu & 7) == 0 && g.nrag <= 64) {
+    if (!slab) {
+      hipError_t e = hipMalloc(&slab, (size_t)SPLIT_SLOTS * SPLIT_TILE * sizeof(float));
+      if (e != hipSuccess) { reed_set_error("gemm256w: cannot allocate the split slab: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    // cost of a K-tile of a ragged tile relative to a 256 x 128 one (stamps: 1978 / 1853 / 1323 cycles)
+    const double wmode[4] = {0.0, 1.0, 0.94, 0.67};
+    struct Tile { unsigned desc; int mode; bool whole; int entry; };
+    std::vector<Tile> whole, cut;
+    auto pack = [](int p, int mode, int tm, int tn) { return (unsigned)(p | mode << 2 | tm << 4 | tn << 12); };
+    const int nk = probs[0].K / WBK;
+    for (int i = 0; i < n; ++i) {
+      if (g.rn[i])
+        for (int tm = 0; tm < g.fm[i]; ++tm) {
+          rd.out[rd.n] = (float*)probs[i].C + (long)tm * WBM * probs[i].ldc + (long)g.fn[i] * WBN;
+          rd.ldc[rd.n] = (int)probs[i].ldc;
+          rd.cols[rd.n] = 128;
+          cut.push_back({pack(i, 1, tm, g.fn[i]), 1, false, rd.n++});
+        }
+      if (g.rm[i])
+        for (int tn = 0; tn < g.fn[i]; ++tn) {
+          if (tn == 0 && probs[i].dbias) { whole.push_back({pack(i, 2, g.fm[i], 0), 2, true, -1}); continue; }
+          rd.out[rd.n] = (float*)probs[i].C + (long)g.fm[i] * WBM * probs[i].ldc + (long)tn * WBN;
+          rd.ldc[rd.n] = (int)probs[i].ldc;
+          rd.cols[rd.n] = 256;
+          cut.push_back({pack(i, 2, g.fm[i], tn), 2, false, rd.n++});
+        }
+      if (g.rm[i] && g.rn[i]) whole.push_back({pack(i, 3, g.fm[i], g.fn[i]), 3, true, -1});
+    }
+    double total = 0.0;
+    for (const Tile& t : whole) total += wmode[t.mode] * nk;
+    for (const Tile& t : cut) total += wmode[t.mode] * nk;
+    const double target = total / nw;
+    std::vector<std::vector<std::pair<unsigned, unsigned>>> lists(nw);
+    std::vector<double> load(nw, 0.0);
+    // the tiles that stay whole (bias-gradient half tiles, quarter tiles) open a workgroup's list each
+    int kw = 0;
+    for (const Tile& t : whole) {
+      lists[kw % nw].push_back({t.desc, (unsigned)nk << 16});
+      load[kw % nw] += wmode[t.mode] * nk;
+      ++kw;
+    }
+    // the rest as one tape of K-tiles, cut where a workgroup's share is full (pieces of at least 8 K-tiles)
+    int slot = 0, k = 0;
+    bool fits = true;
+    for (const Tile& t : cut) {
+      int k0 = 0, pieces = 0;
+      rd.first[t.entry] = (short)slot;
+      while (k0 < nk) {
+        while (k < nw - 1 && (target - load[k]) / wmode[t.mode] < 8.0) ++k;
+        int take = k == nw - 1 ? nk - k0 : std::min(nk - k0, (int)((target - load[k]) / wmode[t.mode] + 0.5));
+        if (nk - k0 - take < 8) take = nk - k0;
+        if (slot >= SPLIT_SLOTS) { fits = false; break; }
+        lists[k].push_back({t.desc | 1u << 21 | (unsigned)slot << 22, (unsigned)k0 | (unsigned)take << 16});
+        load[k] += wmode[t.mode] * take;
+        k0 += take;
+        ++slot;
+        ++pieces;
+      }
+      rd.cnt[t.entry] = (short)pieces;
+    }
+    g.nitem = 0;
+    for (int w = 0; w < nw && fits; ++w) {
+      g.wstart[w] = (unsigned short)g.nitem;
+      for (auto& it : lists[w]) {
+        if (g.nitem >= 176) { fits = false; break; }
+        g.item[g.nitem] = it.first;
+        g.krange[g.nitem++] = it.second;
+      }
+    }
+    if (fits) {
+      g.wstart[nw] = (unsigned short)g.nitem;
+      g.wpx = ncu / 8;
+      g.slab = slab;
+      rd.accumulate = probs[0].accumulate;
+      rd.slab = slab;
+    } else {
+      g.nitem = 0;
+      rd.n = 0;
+    }
+  } else {
+    rd.n = 0;
+  }
+  if (g.nitem == 0 && w4mode != 1) return REED_OK;   // only the dynamic form applies: gemm_tn.hip's grouped launch is the faster one
+  const int grid = g.nitem > 0 ? ncu : 8 * (cdiv(g.nfull, 8) + cdiv(g.nrag, 8));
   REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(grid), dim3(256), LDS_W, stream, g);
   REED_LAUNCH_CHECK();
+  if (rd.n > 0) {
+    REED_KLAUNCH(wgrad_split_reduce_kernel, dim3(SPLIT_TILE / 4 / 256, rd.n), dim3(256), 0, stream, rd);
+    REED_LAUNCH_CHECK();
+  }
   *launched = 1;
   return REED_OK;
 }

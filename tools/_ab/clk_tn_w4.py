@@ -35,3 +35,9 @@ for mode in (0, 1, 2, 3):
     if w:
         print(f"MODE {mode}: {len(w)} records, clock {statistics.median([x[0]/x[1]*0.1 for x in w]):.3f} GHz, {statistics.median([x[0]/x[2] for x in w]):.1f} cycles per K-tile of 64 (MFMA floor 2048 full tile), loop {statistics.median([x[1] for x in w])/100:.1f} us")
 print(f"REED_WGRAD_W4={os.environ.get('REED_WGRAD_W4')}: {ms:.4f} ms per launch, {flop/ms/1e9:.1f} TF")
+# timeline of the last launch: loop start / end of every recorded tile on the 100 MHz clock
+t0 = min(x[4] for x in W)
+ends = sorted((x[5] - t0) / 100.0 for x in W)
+print(f"timeline: {len(W)} tiles recorded; last K loop ends {ends[-1]:.0f} us after the first one starts; K-loop start times (us): "
+      + ", ".join(f"mode {m}: " + " ".join(f"{v:.0f}" for v in sorted((x[4] - t0) / 100.0 for x in W if x[3] == m)[::max(1, len([x for x in W if x[3] == m]) // 8)]) for m in (0, 1, 2, 3) if any(x[3] == m for x in W)))
+print("K-loop end times (us), every 16th: " + " ".join(f"{v:.0f}" for v in ends[::16]))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Tiny workload for rocprofv3 --pmc passes: 3 launches each of the dominant GEMM kernels at the bench shapes (b=256), through
-the product entry points: the block's grouped weight gradients (gemm_tn_group_kernel), fwd fc1 (NT 256^2 four-wave kernel, GELU
+the product entry points: the block's grouped weight gradients (gemm256w_tn_group_kernel + wgrad_split_reduce_kernel since round 4; gemm_tn_group_kernel with REED_WGRAD_W4=0), fwd fc1 (NT 256^2 four-wave kernel, GELU
 epilogue), dgrad fc1 (NN 256^2 four-wave kernel)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
