@@ -63,6 +63,7 @@ using namespace gemm_detail;
 constexpr int WBM = 256, WBN = 256, WBK = 64;
 constexpr int HTW = 16384;                                  // half-tile bytes
 constexpr int LDS_W = 8 * HTW + 4 * EPI_STAGE_BYTES;        // 144 KiB
+constexpr int LDS_TN = 10 * HTW;                            // 160 KiB: the grouped weight gradients (tall / wide tiles: ten slots)
 __device__ __forceinline__ constexpr int wslotA(int h, int cur) { return (h * 2 + cur) * HTW; }
 __device__ __forceinline__ constexpr int wslotB(int h, int cur) { return (4 + h * 2 + cur) * HTW; }
 
@@ -106,19 +107,28 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
                                               const int prev_mode = -1, const int nx_mode = -1, const int nx_tm = 0,
                                               const int nx_tn = 0) {
   const bool first = prev_mode < 0;
-  constexpr bool RN = (MODE & 1) != 0, RM = (MODE & 2) != 0;
+  // MODE 4 / 5 (TN, one-shot only; round 4): a TALL tile of 512 rows x 128 columns = two vertically adjacent MODE-1 tiles, wave w on
+  // A half-tile w x B half-tile 0, and a WIDE one of 128 x 512 = two MODE-2 tiles, A half-tile 0 x B half-tile w: 128 x 128 per wave
+  // like a full tile (the same reads per MFMA), five half-tiles per K-tile buffer = all ten 16 KiB slots of the LDS
+  static_assert(MODE <= 3 || (LAY == LAY_TN && PM == 0), "tall / wide tiles: weight gradients only");
+  constexpr bool RN = MODE <= 3 && (MODE & 1) != 0, RM = MODE <= 3 && (MODE & 2) != 0;
   constexpr int NA = RN ? 4 : 8;              // 16-row tiles per wave
   constexpr int NB = RM ? 4 : 8;              // 16-column tiles per wave
   constexpr int NCH = NA * NB / 4;            // chunks of 4 MFMAs per phase
   constexpr int NF = NA + NB;                 // fragment reads per k-step
-  constexpr int ND = 4 * ((RM ? 1 : 2) + (RN ? 1 : 2));   // DMA instructions per K-tile per wave
+  constexpr int NAH = MODE == 4 ? 4 : (MODE == 5 || RM) ? 1 : 2;   // A / B half-tiles staged per K-tile
+  constexpr int NBH = MODE == 5 ? 4 : (MODE == 4 || RN) ? 1 : 2;
+  constexpr int ND = 4 * (NAH + NBH);         // DMA instructions per K-tile per wave
   constexpr bool A_TR = LAY == LAY_TN, B_TR = LAY != LAY_NT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int aHalf = MODE == 0 ? (wave >> 1) : MODE == 1 ? (wave >> 1) : 0;
+  const int aHalf = MODE == 4 ? wave : (MODE == 0 || MODE == 1) ? (wave >> 1) : 0;
   const int aQuart = MODE == 1 ? (wave & 1) : MODE == 3 ? (wave >> 1) : 0;
-  const int bHalf = MODE == 0 ? (wave & 1) : MODE == 2 ? (wave >> 1) : 0;
+  const int bHalf = MODE == 5 ? wave : MODE == 0 ? (wave & 1) : MODE == 2 ? (wave >> 1) : 0;
   const int bQuart = (MODE == 2 || MODE == 3) ? (wave & 1) : 0;
+  // LDS slot of half-tile h of buffer cur (modes 0-3: A 0..3, B 4..7; tall: A 0..7, B 8..9; wide: B 0..7, A 8..9)
+  auto slotA = [](int h, int cur) constexpr { return MODE == 5 ? (8 + cur) * HTW : wslotA(h, cur); };
+  auto slotB = [](int h, int cur) constexpr { return MODE == 4 ? (8 + cur) * HTW : MODE == 5 ? (h * 2 + cur) * HTW : wslotB(h, cur); };
   const int mrow = aHalf * 128 + aQuart * 64, ncol = bHalf * 128 + bQuart * 64;
   const int m0 = tm * WBM, n0 = tn * WBN;
   const int nt = (a.K + WBK - 1) / WBK;
@@ -139,15 +149,14 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   const int halfB = B_TR ? 128 * 2 : (int)(128 * a.ldq * 2);
   // DMA e of the K-tile's ND: the existing half-tiles in the order A0 [A1] B0 [B1], 4 staging rounds each
   auto dma = [&](int t, int cur, int e) {
-    constexpr int NAH = RM ? 1 : 2;
     const int hh = e >> 2, i = e & 3;
     if (hh < NAH) {
-      char* ht = smem + wslotA(hh, cur);
+      char* ht = smem + slotA(hh, cur);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vA0,
                                                t * kstepA + hh * halfA + i * rsA, 0, 0);
     } else {
       const int hb = hh - NAH;
-      char* ht = smem + wslotB(hb, cur);
+      char* ht = smem + slotB(hb, cur);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vB0,
                                                t * kstepB + hb * halfB + i * rsB, 0, 0);
     }
@@ -190,13 +199,13 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   const int li = lane & 15, lg = lane >> 4, lq = li >> 2, lp = li & 3;
   const int rsw = (li >> 1) & 7;
   // k-contiguous: row tile i -> + 2048 i, k-step 1 -> ^ 64
-  int rA = wslotA(aHalf, 0) + aQuart * 8192 + li * 128 + ((lg ^ rsw) << 4);
-  int rB = wslotB(bHalf, 0) + bQuart * 8192 + li * 128 + ((lg ^ rsw) << 4);
+  int rA = slotA(aHalf, 0) + aQuart * 8192 + li * 128 + ((lg ^ rsw) << 4);
+  int rB = slotB(bHalf, 0) + bQuart * 8192 + li * 128 + ((lg ^ rsw) << 4);
   // k-strided (transposing read): byte = row*256 + ((i' ^ xe)<<5) + (((p>>1)^hh)<<4) + ((p&1)<<3), row = ks*32 + 8g + q + 4hh,
   // i' = 16-column tile index inside the half-tile (a quarter starts at i' = 4)
   const int xe = (lq << 1) | (lg & 1);
   const int trow = (8 * lg + lq) * 256 + ((lp >> 1) << 4) + ((lp & 1) << 3);
-  int tA0 = wslotA(aHalf, 0) + trow, tB0 = wslotB(bHalf, 0) + trow;
+  int tA0 = slotA(aHalf, 0) + trow, tB0 = slotB(bHalf, 0) + trow;
   int tSA = (xe << 5) ^ (aQuart << 7), tSB = (xe << 5) ^ (bQuart << 7);
   // TN (both operands transposing): the two read addresses of fragment i are (lane base) XOR (i << 5) — the row part of a base has
   // no bit in 5..7, where the slot swizzle and the tile index live — one vector instruction per read instead of add / xor / add
@@ -402,7 +411,8 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     if (nt > 1) {
 #pragma unroll
       for (int d = 0; d < ND; ++d) dma(1, 1, d);
-      if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
@@ -437,11 +447,13 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     };
     auto ring_wait = [&](bool one) {
       if (one) {
-        if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
-        if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       }
@@ -535,7 +547,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   {
     unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    const int pidx = tm * ((a.N + WBN - 1) / WBN) + tn;   // one record per tile
+    const int pidx = a.act_variant >= 1000 ? a.act_variant : tm * ((a.N + WBN - 1) / WBN) + tn;   // one record per tile (static items: 1000 + index)
     if (tid == 0 && pidx < 8192) {
       reed_clk_buf[8 * pidx + 0] = ck1 - ck0;
       reed_clk_buf[8 * pidx + 1] = cr1 - cr0;
@@ -724,22 +736,24 @@ struct TnGroupW {
   int nitem;                        // > 0: static form — exactly one workgroup per CU, the ragged work is item[] dealt by the host
   int wpx;                          // workgroups (= CUs) per XCD in that form
   unsigned short wstart[66];        // ragged workgroup id -> its first item (wstart[id + 1]: one past its last)
-  unsigned item[176];               // p | mode << 2 | tm << 4 | tn << 12 | split << 21 | slab slot << 22
+  unsigned item[176];               // p | mode << 2 | tm << 5 | tn << 13 | split << 21 | slab slot << 22 (mode 4 / 5: tall / wide pair)
   unsigned krange[176];             // first K-tile (of 64 tokens) | K-tiles << 16 of the item
   float* slab;                      // [slots][256 * 128] partial tiles
 };
-constexpr int SPLIT_TILE = 256 * 128;
+constexpr int SPLIT_TILE = 512 * 128;   // a tall / wide pair; a single half tile uses the first half of its slot
 constexpr int SPLIT_SLOTS = 176;
 struct SplitReduceArgs {
   float* out[64];      // the tile's first element in its weight-gradient matrix
   int ldc[64];
-  short cols[64];      // 128 (a 256 x 128 tile) or 256 (128 x 256)
+  short cols[64];      // 128 (a 256 x 128 or 512 x 128 tile), 256 (128 x 256) or 512 (128 x 512)
+  int nel[64];         // elements of the tile: 32768 or 65536
   short first[64], cnt[64];   // its partial tiles: slab slots first .. first + cnt - 1, added in that order
   int n, accumulate;
   const float* slab;
 };
 __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(SplitReduceArgs r) {
   const int q = blockIdx.y, i4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // 4 consecutive columns of one row of the tile
+  if (i4 >= r.nel[q]) return;
   const int cols = r.cols[q], row = i4 / cols, col = i4 - row * cols;
   const float* sp = r.slab + (long)r.first[q] * SPLIT_TILE + i4;
   f32x4 v = *(const f32x4*)sp;
@@ -760,16 +774,19 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
     const int id = g.wpx * xcd - sf + (j - cf);
     for (int r = g.wstart[id]; r < g.wstart[id + 1]; ++r) {
       const unsigned it = g.item[r], kr = g.krange[r];
-      p = it & 3; mode = (it >> 2) & 3; tm = (it >> 4) & 255; tn = (it >> 12) & 255;
+      p = it & 3; mode = (it >> 2) & 7; tm = (it >> 5) & 255; tn = (it >> 13) & 255;
       piece = ((it >> 21) & 1) ? (int)(it >> 22) : -1;
       GemmArgs a = g.a[p];
+#ifdef REED_CLK_PROBE
+      a.act_variant = 1000 + r;
+#endif
       if (piece >= 0) {   // a sub-problem in local coordinates: the tile's rows x columns of C from the item's range of tokens
         const long k0 = (long)(kr & 0xFFFF) * WBK;
         a.P += k0 * a.ldp + tm * WBM;
         a.Q += k0 * a.ldq + tn * WBN;
         a.K = (int)(kr >> 16) * WBK;
-        a.M = mode == 1 ? WBM : 128;
-        a.N = mode == 1 ? 128 : WBN;
+        a.M = mode == 1 ? WBM : mode == 4 ? 2 * WBM : 128;
+        a.N = mode == 2 ? WBN : mode == 5 ? 2 * WBN : 128;
         a.C = g.slab + (long)piece * SPLIT_TILE;
         a.ldc = a.N;
         a.dbias = nullptr;
@@ -779,6 +796,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
       }
       if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
       else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);
+      else if (mode == 4) gemm256w_body<LAY_TN, EPI_F32, 4>(a, smem, tm, tn);
+      else if (mode == 5) gemm256w_body<LAY_TN, EPI_F32, 5>(a, smem, tm, tn);
       else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
       __syncthreads();   // every wave is out of the item's last K-tile before the next item's first DMA
     }
@@ -1001,7 +1020,7 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
   if (g.nfull > ncu || equiv > ncu || equiv < minfill * ncu) return REED_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
     if (e != hipSuccess) { reed_set_error("gemm256w: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
@@ -1021,27 +1040,41 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
       if (e != hipSuccess) { reed_set_error("gemm256w: cannot allocate the split slab: %s", hipGetErrorString(e)); return (int)e; }
     }
     // cost of a K-tile of a ragged tile relative to a 256 x 128 one (stamps: 1978 / 1853 / 1323 cycles)
-    const double wmode[4] = {0.0, 1.0, 0.94, 0.67};
+    const double wmode[6] = {0.0, 1.0, 0.94, 0.67, 1.6, 1.6};   // (a tall / wide pair: 1.1-1.2 of a full tile's 2688 cycles)
     struct Tile { unsigned desc; int mode; bool whole; int entry; };
     std::vector<Tile> whole, cut;
-    auto pack = [](int p, int mode, int tm, int tn) { return (unsigned)(p | mode << 2 | tm << 4 | tn << 12); };
+    auto pack = [](int p, int mode, int tm, int tn) { return (unsigned)(p | mode << 2 | tm << 5 | tn << 13); };
     const int nk = probs[0].K / WBK;
-    for (int i = 0; i < n; ++i) {
-      if (g.rn[i])
-        for (int tm = 0; tm < g.fm[i]; ++tm) {
-          rd.out[rd.n] = (float*)probs[i].C + (long)tm * WBM * probs[i].ldc + (long)g.fn[i] * WBN;
-          rd.ldc[rd.n] = (int)probs[i].ldc;
-          rd.cols[rd.n] = 128;
-          cut.push_back({pack(i, 1, tm, g.fn[i]), 1, false, rd.n++});
-        }
-      if (g.rm[i])
-        for (int tn = 0; tn < g.fn[i]; ++tn) {
-          if (tn == 0 && probs[i].dbias) { whole.push_back({pack(i, 2, g.fm[i], 0), 2, true, -1}); continue; }
-          rd.out[rd.n] = (float*)probs[i].C + (long)g.fm[i] * WBM * probs[i].ldc + (long)tn * WBN;
-          rd.ldc[rd.n] = (int)probs[i].ldc;
-          rd.cols[rd.n] = 256;
-          cut.push_back({pack(i, 2, g.fm[i], tn), 2, false, rd.n++});
-        }
+    // two vertically adjacent 256 x 128 tiles of a ragged column = one tall tile, two 128 x 256 tiles of a ragged row = one wide
+    // tile (MODE 4 / 5: two half tiles' work at 1.1-1.2 of a full tile's time instead of 1.44); the bias-gradient tile of a ragged
+    // row stays a whole tile of its own; everything else is tape.  REED_WGRAD_W4_PAIRS=0: no pairs (A/B)
+    static const bool pairs_on = !(getenv("REED_WGRAD_W4_PAIRS") && atoi(getenv("REED_WGRAD_W4_PAIRS")) == 0);
+    auto add_cut = [&](unsigned desc, int mode, float* out, long ldc, int cols) {
+      if (rd.n >= 64) return false;
+      rd.out[rd.n] = out;
+      rd.ldc[rd.n] = (int)ldc;
+      rd.cols[rd.n] = (short)cols;
+      rd.nel[rd.n] = (mode >= 4 ? 2 : 1) * 32768;
+      cut.push_back({desc, mode, false, rd.n++});
+      return true;
+    };
+    bool room = true;
+    for (int i = 0; i < n && room; ++i) {
+      float* C = (float*)probs[i].C;
+      const long ldc = probs[i].ldc;
+      if (g.rn[i]) {   // the ragged column: tiles (tm, fn), 256 rows x 128 columns
+        int tm = 0;
+        if (pairs_on)
+          for (; tm + 1 < g.fm[i] && room; tm += 2) room = add_cut(pack(i, 4, tm, g.fn[i]), 4, C + (long)tm * WBM * ldc + (long)g.fn[i] * WBN, ldc, 128);
+        for (; tm < g.fm[i] && room; ++tm) room = add_cut(pack(i, 1, tm, g.fn[i]), 1, C + (long)tm * WBM * ldc + (long)g.fn[i] * WBN, ldc, 128);
+      }
+      if (g.rm[i]) {   // the ragged row: tiles (fm, tn), 128 rows x 256 columns
+        int tn = 0;
+        if (probs[i].dbias) { whole.push_back({pack(i, 2, g.fm[i], 0), 2, true, -1}); tn = 1; }
+        if (pairs_on)
+          for (; tn + 1 < g.fn[i] && room; tn += 2) room = add_cut(pack(i, 5, g.fm[i], tn), 5, C + (long)g.fm[i] * WBM * ldc + (long)tn * WBN, ldc, 512);
+        for (; tn < g.fn[i] && room; ++tn) room = add_cut(pack(i, 2, g.fm[i], tn), 2, C + (long)g.fm[i] * WBM * ldc + (long)tn * WBN, ldc, 256);
+      }
       if (g.rm[i] && g.rn[i]) whole.push_back({pack(i, 3, g.fm[i], g.fn[i]), 3, true, -1});
     }
     double total = 0.0;
@@ -1051,6 +1084,7 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
     std::vector<std::vector<std::pair<unsigned, unsigned>>> lists(nw);
     std::vector<double> load(nw, 0.0);
     // the tiles that stay whole (bias-gradient half tiles, quarter tiles) open a workgroup's list each
+    std::stable_sort(whole.begin(), whole.end(), [&](const Tile& x, const Tile& y) { return wmode[x.mode] > wmode[y.mode]; });
     int kw = 0;
     for (const Tile& t : whole) {
       lists[kw % nw].push_back({t.desc, (unsigned)nk << 16});
@@ -1085,6 +1119,7 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
         g.krange[g.nitem++] = it.second;
       }
     }
+    fits = fits && room && (int)whole.size() <= nw;
     if (fits) {
       g.wstart[nw] = (unsigned short)g.nitem;
       g.wpx = ncu / 8;
@@ -1100,7 +1135,7 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
   }
   if (g.nitem == 0 && w4mode != 1) return REED_OK;   // only the dynamic form applies: gemm_tn.hip's grouped launch is the faster one
   const int grid = g.nitem > 0 ? ncu : 8 * (cdiv(g.nfull, 8) + cdiv(g.nrag, 8));
-  REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(grid), dim3(256), LDS_W, stream, g);
+  REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(grid), dim3(256), LDS_TN, stream, g);
   REED_LAUNCH_CHECK();
   if (rd.n > 0) {
     REED_KLAUNCH(wgrad_split_reduce_kernel, dim3(SPLIT_TILE / 4 / 256, rd.n), dim3(256), 0, stream, rd);

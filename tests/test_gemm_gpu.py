@@ -192,6 +192,8 @@ def test_tn_wgrad_tall_wide_tiles(dev, lay, Mtok, N, K, split, force_tile):
 @pytest.mark.parametrize("tokens,shapes", [
     (512, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),     # the SiT-XL/2 block: 162 + 162 + 45 + 126 tiles
     (1000, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),    # ragged token count
+    (2048, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),    # long enough for the four-wave form's static deal (force_tile 0):
+                                                                         # tall / wide tile pairs, K-cut leftovers, the slab reduce
     (256, [(384, 256), (640, 128)]),                                     # ragged last tile rows (1.5 and 2.5 tiles of 256)
     (300, [(128, 128)]),
 ])

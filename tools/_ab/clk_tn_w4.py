@@ -26,11 +26,11 @@ e0.record()
 for _ in range(10): ops.wgrad_group(probs, M)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
-n = 512
+n = 2048
 buf = (ctypes.c_ulonglong * (8 * n))()
 assert rd(buf, 8 * n) == 0
 W = [[buf[8 * i + j] for j in range(8)] for i in range(n) if buf[8 * i + 1] > 0]
-for mode in (0, 1, 2, 3):
+for mode in (0, 1, 2, 3, 4, 5):
     w = [x for x in W if x[3] == mode]
     if w:
         print(f"MODE {mode}: {len(w)} records, clock {statistics.median([x[0]/x[1]*0.1 for x in w]):.3f} GHz, {statistics.median([x[0]/x[2] for x in w]):.1f} cycles per K-tile of 64 (MFMA floor 2048 full tile), loop {statistics.median([x[1] for x in w])/100:.1f} us")
@@ -39,5 +39,15 @@ print(f"REED_WGRAD_W4={os.environ.get('REED_WGRAD_W4')}: {ms:.4f} ms per launch,
 t0 = min(x[4] for x in W)
 ends = sorted((x[5] - t0) / 100.0 for x in W)
 print(f"timeline: {len(W)} tiles recorded; last K loop ends {ends[-1]:.0f} us after the first one starts; K-loop start times (us): "
-      + ", ".join(f"mode {m}: " + " ".join(f"{v:.0f}" for v in sorted((x[4] - t0) / 100.0 for x in W if x[3] == m)[::max(1, len([x for x in W if x[3] == m]) // 8)]) for m in (0, 1, 2, 3) if any(x[3] == m for x in W)))
+      + ", ".join(f"mode {m}: " + " ".join(f"{v:.0f}" for v in sorted((x[4] - t0) / 100.0 for x in W if x[3] == m)[::max(1, len([x for x in W if x[3] == m]) // 8)]) for m in (0, 1, 2, 3, 4, 5) if any(x[3] == m for x in W)))
 print("K-loop end times (us), every 16th: " + " ".join(f"{v:.0f}" for v in ends[::16]))
+
+# static items (records 1000 + item index): per mode, cycles per K-tile and the items' K-tile counts
+items = [[buf[8 * i + j] for j in range(8)] for i in range(1000, n) if buf[8 * i + 1] > 0]
+for mode in (1, 2, 3, 4, 5):
+    w = [x for x in items if x[3] == mode]
+    if w:
+        print(f"static items MODE {mode}: {len(w)} items, {statistics.median([x[0]/x[2] for x in w]):.1f} cycles per K-tile, K-tiles per item {sorted(int(x[2]) for x in w)[:40]}, loop us {sorted(int(x[1]/100) for x in w)[:40]}")
+if items:
+    t0 = min(x[4] for x in W)
+    print("static items: K-loop end times (us): " + " ".join(f"{(x[5]-t0)/100:.0f}" for x in sorted(items, key=lambda x: x[5])[::4]))
