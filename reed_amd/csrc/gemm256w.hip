@@ -57,6 +57,9 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_TN_RING
 #define REED_TN_RING 1
 #endif
+#ifndef REED_TN_Q_NT
+#define REED_TN_Q_NT 0
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -157,8 +160,10 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     } else {
       const int hb = hh - NAH;
       char* ht = smem + slotB(hb, cur);
+      // REED_TN_Q_NT (build parameter, A/B): the weight gradients' X operand — a saved activation nobody reads after this kernel —
+      // with the non-temporal policy
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(ht + (i * 256 + wave * 64) * 16), 16, vB0,
-                                               t * kstepB + hb * halfB + i * rsB, 0, 0);
+                                               t * kstepB + hb * halfB + i * rsB, 0, (LAY == LAY_TN && REED_TN_Q_NT) ? 2 : 0);
     }
   };
 
@@ -555,6 +560,10 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       reed_clk_buf[8 * pidx + 3] = MODE;
       reed_clk_buf[8 * pidx + 4] = cr0;   // K loop start / end on the 100 MHz clock (the kernel stamps entry and exit)
       reed_clk_buf[8 * pidx + 5] = cr1;
+      if constexpr (LAY == LAY_TN) {      // the grouped weight gradients: where the tile ran (tools/_ab/clk_tn_w4.py)
+        reed_clk_buf[8 * pidx + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;   // XCC_ID
+        reed_clk_buf[8 * pidx + 7] = blockIdx.x;
+      }
     }
   }
 #endif
@@ -834,7 +843,12 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   }
   // by value: through a reference into the kernel-argument array the compiler re-loads M, N, ldc (s_load + lgkmcnt(0)) in the
   // middle of the hand-placed K loop, where the SIMD's only wave then stands still (tools/isa_sload_scan.py)
+#ifdef REED_CLK_PROBE
+  GemmArgs a = g.a[p];
+  a.act_variant = 2000 + (int)blockIdx.x;
+#else
   const GemmArgs a = g.a[p];
+#endif
   if (mode == 0) gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, tm, tn);
   else if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
   else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);

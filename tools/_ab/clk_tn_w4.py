@@ -26,7 +26,7 @@ e0.record()
 for _ in range(10): ops.wgrad_group(probs, M)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
-n = 2048
+n = 4096
 buf = (ctypes.c_ulonglong * (8 * n))()
 assert rd(buf, 8 * n) == 0
 W = [[buf[8 * i + j] for j in range(8)] for i in range(n) if buf[8 * i + 1] > 0]
@@ -51,3 +51,12 @@ for mode in (1, 2, 3, 4, 5):
 if items:
     t0 = min(x[4] for x in W)
     print("static items: K-loop end times (us): " + " ".join(f"{(x[5]-t0)/100:.0f}" for x in sorted(items, key=lambda x: x[5])[::4]))
+
+# full tiles by XCD (records 2000 + blockIdx): loop time per XCC
+full = [[buf[8 * i + j] for j in range(8)] for i in range(2000, min(n, 2000 + 300)) if buf[8 * i + 1] > 0 and buf[8 * i + 3] == 0]
+byx = {}
+for x in full:
+    byx.setdefault(int(x[6]), []).append(x[1] / 100.0)
+for k in sorted(byx):
+    v = sorted(byx[k])
+    print(f"full tiles on XCC {k}: {len(v)} tiles, K loop {v[0]:.0f} .. {v[len(v)//2]:.0f} .. {v[-1]:.0f} us (blockIdx % 8 = {sorted(set(int(x[7]) % 8 for x in full if int(x[6]) == k))})")
