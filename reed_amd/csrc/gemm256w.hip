@@ -289,9 +289,17 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   // own the tile's first columns of the first column tile; these accumulators live in VGPRs (the AGPRs are full)
   f32x4 accb[LAY == LAY_TN ? NA : 1];
   bool do_dbias = false;
+  // MODE 0 with the ring loop: the two waves that share an A half-tile split its eight bias-gradient MFMAs per k-step by row-tile
+  // parity (stamps: a bias-gradient tile ran 160 us longer than its XCD's other full tiles — the 16 extra MFMAs per K-tile of two
+  // of its waves, which the barrier charges to all four).  db_par: -1 = this wave takes every row tile it owns
+  int db_par = -1;
   bf16x8 ones;
   if constexpr (LAY == LAY_TN) {
     do_dbias = a.dbias != nullptr && tn == 0 && ncol == 0;
+    if (MODE == 0 && PM == 0 && REED_TN_RING && a.dbias != nullptr && tn == 0) {
+      do_dbias = true;
+      db_par = wave & 1;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -468,8 +476,10 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #define WMMA4R(KS, C)                                                                                    \
   _Pragma("unroll") for (int j = W_CJ(C); j < W_CJ(C) + 4; ++j)                                          \
     REED_MFMA_ACC(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);                                      \
-  if constexpr (DB) {                                                                                    \
+  if constexpr (DB == 1) {                                                                               \
     if (W_CJ(C) == 0) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]);                           \
+  } else if constexpr (DB >= 2) {                                                                        \
+    if (W_CJ(C) == 0 && (W_CI(C) & 1) == DB - 2) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]); \
   }
 #define WRING(T, CUR)                                                                        \
   do {                                                                                       \
@@ -497,15 +507,17 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     }                                                                                        \
   } while (0)
     auto ring = [&](auto db_c) {
-      constexpr bool DB = decltype(db_c)::value;
+      constexpr int DB = decltype(db_c)::value;   // 0: no bias gradient, 1: every row tile, 2 / 3: the even / odd ones
       for (; t + 1 < nt; t += 2) {
         WRING(t, 0);
         WRING(t + 1, 1);
       }
       if (t < nt) { WRING(t, 0); ++t; }
     };
-    if (do_dbias) ring(std::true_type{});
-    else ring(std::false_type{});
+    if (!do_dbias) ring(std::integral_constant<int, 0>{});
+    else if (db_par < 0) ring(std::integral_constant<int, 1>{});
+    else if (db_par == 0) ring(std::integral_constant<int, 2>{});
+    else ring(std::integral_constant<int, 3>{});
 #undef WRING
 #undef WMMA4R
   } else
@@ -589,7 +601,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int m = m0 + mrow + i * 16 + (lane & 15);
-        if (m < a.M) {
+        if (m < a.M && (db_par < 0 || (i & 1) == db_par)) {
           if (a.accumulate) a.dbias[m] += accb[i][0];
           else a.dbias[m] = accb[i][0];
         }
