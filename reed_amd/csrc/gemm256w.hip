@@ -60,6 +60,12 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_TN_Q_NT
 #define REED_TN_Q_NT 0
 #endif
+// 1: a tile row's bias gradient dealt over its first four tiles (two row tiles each) — measured WORSE than 0, the split over the two
+// waves of the row's first tile (1.688 vs 1.644 ms per launch in-step: the tiles of an XCD run in lockstep through the L2 they
+// share, and four slightly slower tiles per row slow every XCD where one clearly slower tile per row delays only itself)
+#ifndef REED_DB_DEAL
+#define REED_DB_DEAL 0
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -291,12 +297,19 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   bool do_dbias = false;
   // MODE 0 with the ring loop: the two waves that share an A half-tile split its eight bias-gradient MFMAs per k-step by row-tile
   // parity (stamps: a bias-gradient tile ran 160 us longer than its XCD's other full tiles — the 16 extra MFMAs per K-tile of two
-  // of its waves, which the barrier charges to all four).  db_par: -1 = this wave takes every row tile it owns
+  // of its waves, which the barrier charges to all four).  db_par: -1 = this wave takes every row tile it owns, 0 / 1 = the even /
+  // odd ones, 2 + q = row tiles 2 q and 2 q + 1
   int db_par = -1;
   bf16x8 ones;
   if constexpr (LAY == LAY_TN) {
     do_dbias = a.dbias != nullptr && tn == 0 && ncol == 0;
-    if (MODE == 0 && PM == 0 && REED_TN_RING && a.dbias != nullptr && tn == 0) {
+    if (MODE == 0 && PM == 0 && REED_TN_RING && REED_DB_DEAL && a.dbias != nullptr && a.N / WBN >= 4) {
+      // a matrix with at least four full tile columns: the bias gradient of a tile row's 16 row tiles is dealt over its first
+      // four tiles — tile tn takes row tiles 2 tn, 2 tn + 1 of each A half-tile, in the wave that owns the tile's first columns:
+      // two more MFMAs per k-step in two waves instead of eight in two (or four in four)
+      do_dbias = tn < 4 && (wave & 1) == 0;
+      db_par = 2 + tn;
+    } else if (MODE == 0 && PM == 0 && REED_TN_RING && a.dbias != nullptr && tn == 0) {
       do_dbias = true;
       db_par = wave & 1;
     }
@@ -478,8 +491,10 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     REED_MFMA_ACC(acc[W_CI(C)][j], Bf[(KS)][j], Af[(KS)][W_CI(C)]);                                      \
   if constexpr (DB == 1) {                                                                               \
     if (W_CJ(C) == 0) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]);                           \
-  } else if constexpr (DB >= 2) {                                                                        \
+  } else if constexpr (DB == 2 || DB == 3) {                                                             \
     if (W_CJ(C) == 0 && (W_CI(C) & 1) == DB - 2) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]); \
+  } else if constexpr (DB >= 4) {                                                                        \
+    if (W_CJ(C) == 0 && (W_CI(C) >> 1) == DB - 4) REED_MFMA_ACC_V(accb[W_CI(C)], ones, Af[(KS)][W_CI(C)]); \
   }
 #define WRING(T, CUR)                                                                        \
   do {                                                                                       \
@@ -507,7 +522,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     }                                                                                        \
   } while (0)
     auto ring = [&](auto db_c) {
-      constexpr int DB = decltype(db_c)::value;   // 0: no bias gradient, 1: every row tile, 2 / 3: the even / odd ones
+      constexpr int DB = decltype(db_c)::value;   // 0: no bias gradient, 1: every row tile, 2 / 3: the even / odd ones, 4 + q: 2 q, 2 q + 1
       for (; t + 1 < nt; t += 2) {
         WRING(t, 0);
         WRING(t + 1, 1);
@@ -516,8 +531,16 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     };
     if (!do_dbias) ring(std::integral_constant<int, 0>{});
     else if (db_par < 0) ring(std::integral_constant<int, 1>{});
-    else if (db_par == 0) ring(std::integral_constant<int, 2>{});
-    else ring(std::integral_constant<int, 3>{});
+    else if constexpr (MODE == 0) {
+      if (db_par == 0) ring(std::integral_constant<int, 2>{});
+      else if (db_par == 1 || !REED_DB_DEAL) ring(std::integral_constant<int, 3>{});
+      else if constexpr (REED_DB_DEAL != 0) {
+        if (db_par == 2) ring(std::integral_constant<int, 4>{});
+        else if (db_par == 3) ring(std::integral_constant<int, 5>{});
+        else if (db_par == 4) ring(std::integral_constant<int, 6>{});
+        else ring(std::integral_constant<int, 7>{});
+      }
+    }
 #undef WRING
 #undef WMMA4R
   } else
@@ -601,7 +624,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int m = m0 + mrow + i * 16 + (lane & 15);
-        if (m < a.M && (db_par < 0 || (i & 1) == db_par)) {
+        if (m < a.M && (db_par < 0 || (db_par < 2 ? (i & 1) == db_par : (i >> 1) == db_par - 2))) {
           if (a.accumulate) a.dbias[m] += accb[i][0];
           else a.dbias[m] = accb[i][0];
         }
