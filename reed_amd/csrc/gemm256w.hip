@@ -66,6 +66,11 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_DB_DEAL
 #define REED_DB_DEAL 0
 #endif
+// 1: the static form's full tiles dealt so that the bias-gradient tiles run on the even XCDs (see the launcher); 0: compact runs in
+// problem order (A/B)
+#ifndef REED_W4_DB_EVEN
+#define REED_W4_DB_EVEN 1
+#endif
 namespace {
 using namespace gemm_detail;
 
@@ -782,6 +787,8 @@ struct TnGroupW {
   unsigned short wstart[66];        // ragged workgroup id -> its first item (wstart[id + 1]: one past its last)
   unsigned item[176];               // p | mode << 2 | tm << 5 | tn << 13 | split << 21 | slab slot << 22 (mode 4 / 5: tall / wide pair)
   unsigned krange[176];             // first K-tile (of 64 tokens) | K-tiles << 16 of the item
+  unsigned short fstart[9];         // static form: XCD x takes the full tiles ftab[fstart[x] .. fstart[x + 1])
+  unsigned ftab[256];               // p | tm << 2 | tn << 10
   float* slab;                      // [slots][256 * 128] partial tiles
 };
 constexpr int SPLIT_TILE = 512 * 128;   // a tall / wide pair; a single half tile uses the first half of its slot
@@ -814,8 +821,21 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   const int cr = qr + (xcd < rr), sr = xcd * qr + min(xcd, rr);
   int p = 0, tm, tn, mode;
   int piece = -1;   // >= 0: the item is a K range of a split tile and writes slab slot `piece` (static form)
-  if (g.nitem > 0 && j >= cf) {   // static form: this workgroup walks its list of ragged items
-    const int id = g.wpx * xcd - sf + (j - cf);
+  if (g.nitem > 0) {   // static form: the host's deal of the full tiles (see reed_gemm256w_tn_group_launch)
+    const int f0 = g.fstart[xcd], nf = g.fstart[xcd + 1] - f0;
+    if (j < nf) {
+      const unsigned e = g.ftab[f0 + j];
+      p = e & 3;
+#ifdef REED_CLK_PROBE
+      GemmArgs a = g.a[p];
+      a.act_variant = 2000 + (int)blockIdx.x;
+#else
+      const GemmArgs a = g.a[p];
+#endif
+      gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, (e >> 2) & 255, (e >> 10) & 255);
+      return;
+    }
+    const int id = g.wpx * xcd - f0 + (j - nf);   // this workgroup walks its list of ragged items
     for (int r = g.wstart[id]; r < g.wstart[id + 1]; ++r) {
       const unsigned it = g.item[r], kr = g.krange[r];
       p = it & 3; mode = (it >> 2) & 7; tm = (it >> 5) & 255; tn = (it >> 13) & 255;
@@ -1170,6 +1190,53 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
     }
     fits = fits && room && (int)whole.size() <= nw;
     if (fits) {
+      // Full tiles: in every stamp the odd XCCs' full tiles run 4-5 % behind the even ones', and the tiles that carry a bias gradient
+      // (the first tile column of a matrix) 5 % behind their XCD's others — so the even XCDs take all of those and the odd ones only
+      // tiles without: [the other tiles in compact order | the bias-gradient tiles], odd XCDs the first runs of it.
+      std::vector<unsigned> rest, dbt, natural;
+      for (int i = 0; i < n; ++i) {
+        const bool colmajor = g.fm[i] < g.fn[i];
+        const int n1 = colmajor ? g.fn[i] : g.fm[i], n2 = colmajor ? g.fm[i] : g.fn[i];
+        for (int u = 0; u < n1; ++u)
+          for (int v = 0; v < n2; ++v) {
+            const int tm = colmajor ? v : u, tn = colmajor ? u : v;
+            ((tn == 0 && probs[i].dbias) ? dbt : rest).push_back((unsigned)(i | tm << 2 | tn << 10));
+            natural.push_back((unsigned)(i | tm << 2 | tn << 10));
+          }
+      }
+      const int per = ncu / 8, nwx = nw / 8, nwr = nw % 8;   // CUs per XCD; ragged workgroups per XCD (the first nwr XCDs one more)
+      int cnt[8], need_even = 0, need_odd = 0;
+      // (the odd XCDs first take the nw % 8 extra ragged workgroups: one full tile fewer there)
+      for (int x = 0; x < 8; ++x) cnt[x] = per - nwx - (((x & 1) ? (x >> 1) : 4 + (x >> 1)) < nwr ? 1 : 0);
+      // the counts as they are (sum = nfull); if the odd XCDs can be filled from `rest` alone, deal it that way
+      for (int x = 0; x < 8; ++x) (x & 1 ? need_odd : need_even) += cnt[x];
+      std::vector<unsigned> seq;
+      int pos[9];
+      if (REED_W4_DB_EVEN && need_odd <= (int)rest.size()) {
+        size_t r = 0;
+        std::vector<std::vector<unsigned>> px(8);
+        for (int x = 1; x < 8; x += 2) for (int c = 0; c < cnt[x]; ++c) px[x].push_back(rest[r++]);
+        // the even XCDs share the bias-gradient tiles evenly (an XCD of nothing but those runs at their pace: 1747 us against
+        // 1623-1651 for the other even ones in the stamps) and fill up with the other tiles
+        size_t d = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int x = 2 * k;
+          const size_t nd = dbt.size() / 4 + ((size_t)k < dbt.size() % 4 ? 1 : 0);
+          for (int c = 0; c < cnt[x]; ++c) {
+            if ((size_t)c < (size_t)cnt[x] - std::min(nd, (size_t)cnt[x]) && r < rest.size()) px[x].push_back(rest[r++]);
+            else if (d < dbt.size()) px[x].push_back(dbt[d++]);
+            else px[x].push_back(rest[r++]);
+          }
+        }
+        for (int x = 0; x < 8; ++x) { pos[x] = (int)seq.size(); seq.insert(seq.end(), px[x].begin(), px[x].end()); }
+      } else {
+        seq = natural;
+        int acc0 = 0;
+        for (int x = 0; x < 8; ++x) { pos[x] = acc0; acc0 += cnt[x]; }
+      }
+      pos[8] = (int)seq.size();
+      for (int x = 0; x <= 8; ++x) g.fstart[x] = (unsigned short)pos[x];
+      for (size_t q = 0; q < seq.size() && q < 256; ++q) g.ftab[q] = seq[q];
       g.wstart[nw] = (unsigned short)g.nitem;
       g.wpx = ncu / 8;
       g.slab = slab;
