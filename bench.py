@@ -734,8 +734,8 @@ def main():
                     "kernel": "the grouped weight-gradient launch = the weight (+ bias) gradients of one transformer block's four "
                               "linears (fc2, fc1, proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch: gemm256w_tn_group_kernel "
                               "(csrc/gemm256w.hip: 256^2 tiles of four 128x128 waves, one workgroup per CU, the ragged tiles cut along K "
-                              "and summed by wgrad_split_reduce_kernel, which the timing includes) or, with REED_WGRAD_W4=0 or where "
-                              "that form does not apply, gemm_tn_group_kernel (csrc/gemm_tn.hip: 256x128 / 128x256 tiles, two "
+                              "and summed by wgrad_split_reduce_kernel, which the timing includes) or — with REED_WGRAD_W4=0, where that form "
+                              "does not apply, and beside gradient buckets in flight (N > 1) — gemm_tn_group_kernel (csrc/gemm_tn.hip: 256x128 / 128x256 tiles, two "
                               "workgroups per CU); algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration "
                               "of every such launch INSIDE the timed region (events on the launch stream; the largest single share "
                               "of the step)",

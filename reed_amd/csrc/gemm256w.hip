@@ -1069,6 +1069,12 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
   // the dynamic form (one workgroup per tile, slower than gemm_tn.hip's) applies — A/B.
   static const int w4mode = getenv("REED_WGRAD_W4") ? atoi(getenv("REED_WGRAD_W4")) : -1;   // -1 = auto
   if (w4mode == 0 || reed_gemm_forced_tile() == 128) return REED_OK;   // force_tile 128: gemm_tn.hip's grouped kernel (tests, A/B)
+  // Beside a collective (reed_set_concurrent_comm: the data-parallel backward) the static form is the wrong shape: its workgroups
+  // take a whole CU's LDS each and every one of them carries 1 / 256 of the launch, so the ones that find their CU held by an RCCL
+  // channel start when another workgroup has finished its ENTIRE list — the launch takes twice as long (measured with a stand-in
+  // that holds 16 CUs: profiles/r4_wgrad_under_cu_hog.txt).  gemm_tn.hip's launch has half-size tiles in dynamic order: it loses
+  // what the missing CUs carried.  REED_WGRAD_W4=1 forces this kernel there too (A/B on a multi-GPU node).
+  if (reed_concurrent_comm() && w4mode != 1) return REED_OK;
   TnGroupW g;
   memset(&g, 0, sizeof(g));
   g.n = n;

@@ -238,6 +238,44 @@ def test_wgrad_group(dev, tokens, shapes, force_tile):
     assert torch.equal(d2[:min(n_out, tokens)], xx.float()[:min(n_out, tokens)])
 
 
+def test_wgrad_group_beside_a_collective_is_the_two_workgroup_kernel(dev):
+    """While gradient buckets are in flight (ops.set_concurrent_comm: the data-parallel backward) the grouped launch keeps to
+    gemm_tn.hip's half-size tiles in dynamic order — the static one-workgroup-per-CU form of gemm256w.hip takes twice as long when
+    RCCL's channels hold CUs (profiles/r4_wgrad_under_cu_hog.txt).  Seen from outside: with the flag set the default plan gives
+    force_tile 128's bits, and without it the K-cut tiles of the static form differ from them in summation order."""
+    from reed_amd import ops
+    tokens, shapes = 4096, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]
+    g = torch.Generator().manual_seed(23)
+    probs = []
+    for n_out, k_in in shapes:
+        dy = _bf(torch.randn(tokens, n_out, generator=g)).to(dev)
+        x = _bf(torch.randn(tokens, k_in, generator=g)).to(dev)
+        out = torch.full((n_out * k_in + n_out,), float("nan"), device=dev)
+        probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:], n_out, k_in))
+
+    def run(tile, comm):
+        ops.gemm_force_tile(tile)
+        ops.set_concurrent_comm(comm)
+        try:
+            for q in probs:
+                q[2].fill_(float("nan"))
+            assert ops.wgrad_group(probs, tokens)
+            return [(q[2].clone(), q[3].clone()) for q in probs]
+        finally:
+            ops.set_concurrent_comm(False)
+            ops.gemm_force_tile(0)
+
+    two = run(128, False)
+    beside = run(0, True)
+    alone = run(0, False)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(two, beside))
+    import os
+    if os.environ.get("REED_WGRAD_W4", "") not in ("0", "1") and ops.wgrad_slots() == 512:
+        assert any(not torch.equal(a[0], b[0]) for a, b in zip(two, alone))      # the static form did run without the flag
+    for a, b in zip(two, alone):
+        torch.testing.assert_close(a[0], b[0], atol=2e-3, rtol=1e-4)
+
+
 def test_wgrad_group_planning(dev):
     """The SiT-XL/2 block fills the 512 workgroup slots exactly and is grouped; small models are left to split-K; a group
     that does not fit one round is refused without launching."""
