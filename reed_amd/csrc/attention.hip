@@ -2569,6 +2569,9 @@ int set_lds(K kernel, int bytes) {
   return 0;
 }
 
+}  // namespace
+int reed_concurrent_comm();   // gemm256.hip
+namespace {
 int num_cus() {
   static int n = 0;
   if (!n) {
@@ -2721,7 +2724,14 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
   const long nseg = (long)B * T * H;
   int ncu = num_cus();
   ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
-  const dim3 pgrid(nitems < ncu ? nitems : ncu);
+  // Beside a collective (reed_set_concurrent_comm: the data-parallel backward) RCCL's channels hold CUs, and a grid of one workgroup
+  // per CU with the items in a static stride then waits for the workgroups that found no CU to run their WHOLE lists after the
+  // others (+ 42 % with 8-32 CUs held: profiles/r4_kernels_under_cu_hog.txt).  Several short lists per CU instead: the dispatcher
+  // hands the next workgroup to whichever CU is free.  REED_ATTN_BWD_GRID=<m>: m workgroups per CU whatever the flag (A/B).
+  static const int gm_env = getenv("REED_ATTN_BWD_GRID") ? atoi(getenv("REED_ATTN_BWD_GRID")) : 0;
+  const int gmult = gm_env > 0 ? gm_env : reed_concurrent_comm() ? 4 : 1;
+  const long gwant = (long)ncu * gmult;
+  const dim3 pgrid((unsigned)(nitems < gwant ? nitems : gwant));
   hipStream_t s = (hipStream_t)stream;
   static const int dbg = getenv("REED_ATTN_KSP_DBG") ? atoi(getenv("REED_ATTN_KSP_DBG")) : 0;   // diagnosis: skip parts of the work
 #define REED_DELTA(HD)                                                                                                    \

@@ -193,3 +193,31 @@ def test_attention_small_t_item_loop_is_deterministic_and_matches_the_plain_form
     a, b = outs[0].float(), outs[2].float()
     assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
     assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.99999
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(80, 256, 16, 72), (40, 256, 16, 72), (70, 128, 16, 72), (33, 256, 12, 64)])
+def test_attention_bwd_beside_a_collective_is_the_same_bits(dev, B, T, H, hd):
+    """ops.set_concurrent_comm(True) — what the data-parallel backward sets while gradient buckets are in flight — makes the
+    persistent backward launch four short item lists per CU instead of one long one (csrc/attention.hip:attention_bwd_persistent;
+    with CUs held by RCCL's channels the one-per-CU grid takes + 42 %, profiles/r4_kernels_under_cu_hog.txt).  The items are the
+    same and independent: identical bits, with more items than 4 x CUs (1280), fewer (640, 528: lists of 1-3), and the T < 256 kernel."""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(B + T)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g).to(torch.bfloat16).to(dev)
+    do = torch.randn(B, T, H * hd, generator=g).to(torch.bfloat16).to(dev)
+    o = torch.zeros(B, T, H * hd, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B, H, T, device=dev)
+    ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+    ws = torch.empty(ops.attention_bwd_ws_floats(B, T, H), device=dev)
+    outs = []
+    for comm in (False, True, True):
+        dqkv = torch.full_like(qkv, float("nan"))
+        ops.set_concurrent_comm(comm)
+        try:
+            ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd, ws=ws)
+        finally:
+            ops.set_concurrent_comm(False)
+        torch.cuda.synchronize()
+        outs.append(dqkv)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
