@@ -13,7 +13,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reed_amd import ops  # noqa: E402
 
-hog = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhog.so"))
+_here = os.path.dirname(os.path.abspath(__file__))
+if not os.path.exists(os.path.join(_here, "libhog.so")):   # built artefacts are not in history
+    import subprocess
+    subprocess.check_call(["hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(_here, "hog.hip"), "-o",
+                           os.path.join(_here, "libhog.so")])
+hog = ctypes.CDLL(os.path.join(_here, "libhog.so"))
 hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda")
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 256
