@@ -578,6 +578,7 @@ def main():
 
     def plan_of_step():
         return (f"{getattr(reducer, 'binding', None)} binding, {getattr(reducer, 'algo', None)} buckets, CU reserve {step.cu_reserve}, "
+                f"kernel forms beside collectives {'on' if getattr(step, 'comm_forms', True) else 'off'}, "
                 f"{'sharded' if getattr(opt, '_shard', False) else 'replicated'} optimiser pass") if reducer is not None else "single GPU"
 
     # W untimed warm-up steps — more when the caller asked for a run-time measurement through the environment (trainer.py): that
@@ -676,7 +677,7 @@ def main():
     dp = {"world": world, "buckets": len(bk), "gradient_bytes": int(4 * L.n_train),
           "largest_bucket_bytes": int(4 * max(e - b0 for _, (b0, e) in bk)),
           # CUs the GEMM grids leave to RCCL's channels: measured by the first steps (reserve -> ms per step, MAX over ranks)
-          "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning, "algo_in_use": getattr(reducer, "algo", None),
+          "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning, "comm_forms": getattr(step, "comm_forms", True), "algo_in_use": getattr(reducer, "algo", None),
           "tune_error": step.tune_error, "optimizer_sharded": bool(getattr(opt, "_shard", False)),
           "optimizer_shard_tuning": step.shard_tuning,
           "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}

@@ -187,11 +187,27 @@ def set_cu_reserve(n):
         _lib.load(prec).reed_set_cu_reserve(_CU_RESERVE)
 
 
+_COMM_FORMS = __import__("os").environ.get("REED_COMM_FORMS", "1") != "0"   # REED_COMM_FORMS=0: off from the start (A/B on a node)
+
+
+def set_comm_forms(on):
+    """Whether set_concurrent_comm(True) selects the kernel forms that degrade gracefully beside a collective (the default) or leaves
+    the single-GPU forms in place (one workgroup per CU for its whole run: faster while no RCCL channel holds a CU, + 40-60 % per
+    kernel while one does — profiles/r4_wgrad_under_cu_hog.txt, r4_kernels_under_cu_hog.txt).  Which wins depends on how long the
+    buckets are in flight on the node at hand: TrainStep.plan_tuning measures both."""
+    global _COMM_FORMS
+    _COMM_FORMS = bool(on)
+
+
+def comm_forms():
+    return _COMM_FORMS
+
+
 def set_concurrent_comm(on):
     """Collectives run beside the GEMMs from now on (data-parallel training): the library keeps to kernels that degrade
     gracefully when RCCL's channels hold CUs (csrc/gemm256.hip:reed_set_concurrent_comm)."""
     for prec in ("bf16", "fp16") + (("fp32",) if "fp32" in _lib.loaded() else ()):
-        _lib.load(prec).reed_set_concurrent_comm(1 if on else 0)
+        _lib.load(prec).reed_set_concurrent_comm(1 if (on and _COMM_FORMS) else 0)
 
 
 def wgrad_slots():

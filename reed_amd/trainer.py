@@ -76,6 +76,10 @@ class TrainStep:
         #   REED_COMM_CUS=auto          the first optimiser steps run with each candidate of REED_COMM_CUS_CANDIDATES (0,16,32):
         #                               one settling step + REED_COMM_TUNE_STEPS (3) event-timed steps; per candidate the MEDIAN,
         #                               MAX over ranks; the fastest is kept and logged on rank 0.  bench.py asks for this.
+        #                               Then, at that reserve, one more candidate ("static"): the backward WITHOUT the kernel forms
+        #                               ops.set_concurrent_comm selects beside a collective (ops.set_comm_forms) — they cost ~ 3 % of
+        #                               a step while no RCCL channel holds a CU and save ~ 6 % while 16 CUs are held (one-GPU
+        #                               rehearsal, profiles/r4_step_under_cu_hog.txt); how long buckets are in flight is the node's.
         #   REED_COMM_ALGO=auto         afterwards the same measurement for the bucket form (ncclAllReduce vs ncclReduceScatter +
         #                               ncclAllGather, parallel.py); otherwise the form stays what REED_COMM_ALGO names
         #                               (default allreduce): the fp32 summation order is then fixed from run to run.
@@ -85,6 +89,8 @@ class TrainStep:
         #                               arithmetic and the operand copies are identical either way).  bench.py asks for this.
         # Any failure inside the measurement's bookkeeping ends it with reserve 0 / allreduce on every rank (tune_error).
         self.cu_reserve = 0
+        self.comm_forms = os.environ.get("REED_COMM_FORMS", "1") != "0"   # ops.set_comm_forms: the kernel forms the backward
+        ops.set_comm_forms(self.comm_forms)                                # selects beside gradient buckets
         self.cu_tuning = None
         self.tune_error = None
         self._tune = []
@@ -111,6 +117,8 @@ class TrainStep:
                 nt = max(1, int(os.environ.get("REED_COMM_TUNE_STEPS", "3")))
                 self._tune = [(c, k) for c in cands for k in range(nt + 1)]   # k = 0: settling step, k >= 1: timed
                 self._tune_times = {}
+                if mode == "auto":
+                    self._tune += [("static", k) for k in range(nt + 1)]
                 self._tune_algo = algo == "auto" and hasattr(reducer, "algo")
                 if self._tune_algo:
                     self._tune += [("rsag", k) for k in range(nt + 1)]
@@ -132,6 +140,8 @@ class TrainStep:
         if tune is not None:
             if tune[0] == "rsag":
                 self.reducer.algo = "rsag"
+            elif tune[0] == "static":
+                ops.set_comm_forms(False)
             elif tune[0] == "shard":
                 if tune[1] == 0 and not self._shard_start():      # self-test failed somewhere: the candidate is dropped
                     tune = None
@@ -204,6 +214,8 @@ class TrainStep:
         self.tune_error = repr(err)
         self.cu_reserve = 0
         ops.set_cu_reserve(0)
+        self.comm_forms = os.environ.get("REED_COMM_FORMS", "1") != "0"
+        ops.set_comm_forms(self.comm_forms)
         if self._tune_algo:
             self.reducer.algo = "allreduce"
         if self._tune_shard:
@@ -227,8 +239,8 @@ class TrainStep:
                 self._tune_ev[1].record()
                 self._tune_times.setdefault(cand, []).append(self._tune_ev)
             nxt = self._tune[0][0] if self._tune else None
-            if self.cu_tuning is None and (nxt is None or nxt in ("rsag", "shard")):   # every reserve candidate is timed: keep the fastest
-                cands = sorted(c for c in self._tune_times if c not in ("rsag", "shard"))
+            if self.cu_tuning is None and (nxt is None or nxt in ("static", "rsag", "shard")):   # every reserve candidate is timed: keep the fastest
+                cands = sorted(c for c in self._tune_times if c not in ("static", "rsag", "shard"))
                 t = self._agree([self._median_ms(c) for c in cands])
                 best = min(range(len(cands)), key=lambda i: t[i])
                 self.cu_reserve = cands[best]
@@ -236,6 +248,14 @@ class TrainStep:
                 self._best_ms = t[best]
                 ops.set_cu_reserve(self.cu_reserve)
                 self._log(f"CU reserve {self.cu_reserve} kept (median ms per step, MAX over ranks: {self.cu_tuning})")
+            if "static" in self._tune_times and nxt != "static" and "static" not in self.cu_tuning:   # the kernel forms beside buckets
+                t = self._agree([self._median_ms("static")])[0]
+                self.cu_tuning["static"] = round(t, 3)
+                self.comm_forms = not (t < self._best_ms)
+                ops.set_comm_forms(self.comm_forms)
+                self._log(f"kernel forms beside collectives {'kept' if self.comm_forms else 'dropped'} "
+                          f"(without them {t:.3f} ms vs {self._best_ms:.3f} ms per step)")
+                self._best_ms = min(t, self._best_ms)
             if self._tune_algo and "rsag" in self._tune_times and nxt != "rsag" and "rsag" not in self.cu_tuning:   # the bucket form
                 t = self._agree([self._median_ms("rsag")])[0]
                 self.cu_tuning["rsag"] = round(t, 3)

@@ -119,7 +119,8 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
     """Data-parallel TrainStep (RCCL process group at world 1, forced).  The measurement is opt-in: without
     REED_COMM_CUS nothing is tuned and the bucket form stays "allreduce".  With REED_COMM_CUS=auto the first optimiser steps
     run with a CU reserve of 0 / 16 / 32 for the GEMM grids (one settling + three timed steps each, the median counts), the
-    fastest is kept and reported; REED_COMM_ALGO=auto then measures the reduce-scatter + all-gather bucket form the same way;
+    fastest is kept and reported; then the backward without the kernel forms it selects beside collectives ("static":
+    ops.set_comm_forms) is measured at that reserve and kept if faster; REED_COMM_ALGO=auto then measures the reduce-scatter + all-gather bucket form the same way;
     REED_COMM_CUS=<n> fixes the reserve; a failure inside the bookkeeping ends the measurement with the safe plan."""
     import copy
     import torch.distributed as dist
@@ -158,32 +159,36 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
         red = GradReducer(m)
         assert red.algo == "allreduce"
         ts = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red, diffusion_warm_up_steps=0)
-        assert ts.tune_steps_left() == 16         # 3 reserves + the reduce-scatter / all-gather bucket form, 1 + 3 steps each
-        full = _lib.load().reed_planning_cus()
-        seen, algos = [], []
-        for _ in range(17):
+        assert ts.tune_steps_left() == 20         # 3 reserves + the backward without the kernel forms it selects beside collectives
+        full = _lib.load().reed_planning_cus()    # ("static") + the reduce-scatter / all-gather bucket form, 1 + 3 steps each
+        seen, algos, forms = [], [], []
+        for _ in range(21):
             algos.append(red.algo)
+            forms.append(ops.comm_forms())
             r = ts(x, y, zs)
             seen.append(_lib.load().reed_planning_cus())
         torch.cuda.synchronize()
         assert torch.isfinite(r["loss"]).item() and ts.tune_error is None
         # (read after each step: the twelfth ends the reserve phase)
         assert seen[:11] == [full] * 4 + [full - 16] * 4 + [full - 32] * 3
-        assert ts.tune_steps_left() == 0 and set(ts.cu_tuning) == {"0", "16", "32", "rsag"} and ts.cu_reserve in (0, 16, 32)
-        assert seen[11] == seen[12] == seen[16] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
-        assert algos[:13] == ["allreduce"] * 13 and algos[13:16] == ["rsag"] * 3 and red.algo in ("allreduce", "rsag")
-        assert red.algo == ("rsag" if ts.cu_tuning["rsag"] < ts.cu_tuning[str(ts.cu_reserve)] else "allreduce")
+        assert ts.tune_steps_left() == 0 and set(ts.cu_tuning) == {"0", "16", "32", "static", "rsag"} and ts.cu_reserve in (0, 16, 32)
+        assert seen[11] == seen[12] == seen[20] == full - ts.cu_reserve == _lib.load("fp16").reed_planning_cus()
+        assert forms[:13] == [True] * 13 and forms[13:16] == [False] * 3 and forms[17:] == [ts.comm_forms] * 4
+        assert ts.comm_forms == ops.comm_forms() == (not ts.cu_tuning["static"] < ts.cu_tuning[str(ts.cu_reserve)])
+        assert algos[:17] == ["allreduce"] * 17 and algos[17:20] == ["rsag"] * 3 and red.algo in ("allreduce", "rsag")
+        assert red.algo == ("rsag" if ts.cu_tuning["rsag"] < min(ts.cu_tuning[str(ts.cu_reserve)], ts.cu_tuning["static"]) else "allreduce")
+        ops.set_comm_forms(True)
         red.close()
         # a failure inside the bookkeeping is never fatal: reserve 0, all-reduce buckets, the error kept for the report
         os.environ.pop("REED_COMM_ALGO", None)
         red3 = GradReducer(m)
         ts3 = TrainStep(m, lf, FusedAdamWEMA(m, None, lr=1e-4), red3, diffusion_warm_up_steps=0)
-        assert ts3.tune_steps_left() == 12
+        assert ts3.tune_steps_left() == 16
         ts3._agree = lambda times: (_ for _ in ()).throw(RuntimeError("injected"))
         for _ in range(13):
             r = ts3(x, y, zs)
         torch.cuda.synchronize()
-        assert "injected" in ts3.tune_error and ts3.tune_steps_left() == 0 and ts3.cu_reserve == 0
+        assert "injected" in ts3.tune_error and ts3.tune_steps_left() == 0 and ts3.cu_reserve == 0 and ts3.comm_forms and ops.comm_forms()
         assert _lib.load().reed_planning_cus() == full and red3.algo == "allreduce" and torch.isfinite(r["loss"]).item()
         red3.close()
         os.environ["REED_COMM_CUS"] = "24"
@@ -196,6 +201,7 @@ def test_cu_reserve_is_measured_under_a_reducer(dev):
         os.environ.pop("REED_COMM_CUS", None)
         os.environ.pop("REED_COMM_ALGO", None)
         ops.set_cu_reserve(0)
+        ops.set_comm_forms(True)
 
 
 @pytest.mark.parametrize("algo", ["allreduce", "rsag"])
