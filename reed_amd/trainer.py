@@ -117,7 +117,7 @@ class TrainStep:
                 nt = max(1, int(os.environ.get("REED_COMM_TUNE_STEPS", "3")))
                 self._tune = [(c, k) for c in cands for k in range(nt + 1)]   # k = 0: settling step, k >= 1: timed
                 self._tune_times = {}
-                if mode == "auto":
+                if mode == "auto" and self.comm_forms:   # (REED_COMM_FORMS=0: already off, nothing to compare)
                     self._tune += [("static", k) for k in range(nt + 1)]
                 self._tune_algo = algo == "auto" and hasattr(reducer, "algo")
                 if self._tune_algo:
