@@ -202,6 +202,7 @@ def test_attention_bwd_beside_a_collective_is_the_same_bits(dev, B, T, H, hd):
     with CUs held by RCCL's channels the one-per-CU grid takes + 42 %, profiles/r4_kernels_under_cu_hog.txt).  The items are the
     same and independent: identical bits, with more items than 4 x CUs (1280), fewer (640, 528: lists of 1-3), and the T < 256 kernel."""
     from reed_amd import ops
+    ops.set_comm_forms(True)   # (a tuner or REED_COMM_FORMS=0 may have switched them off)
     g = torch.Generator().manual_seed(B + T)
     qkv = torch.randn(B, T, 3, H, hd, generator=g).to(torch.bfloat16).to(dev)
     do = torch.randn(B, T, H * hd, generator=g).to(torch.bfloat16).to(dev)

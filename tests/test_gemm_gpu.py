@@ -244,6 +244,7 @@ def test_wgrad_group_beside_a_collective_is_the_two_workgroup_kernel(dev):
     RCCL's channels hold CUs (profiles/r4_wgrad_under_cu_hog.txt).  Seen from outside: with the flag set the default plan gives
     force_tile 128's bits, and without it the K-cut tiles of the static form differ from them in summation order."""
     from reed_amd import ops
+    ops.set_comm_forms(True)   # (a tuner or REED_COMM_FORMS=0 may have switched them off)
     tokens, shapes = 4096, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]
     g = torch.Generator().manual_seed(23)
     probs = []
