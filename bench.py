@@ -47,6 +47,7 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the C4 (text + image alignment), C5 (sampler) and N2 (frozen encoder) legs the N = 1 run appends")
     ap.add_argument("--no-vae-leg", action="store_true", help="skip the SD-VAE decode leg (SURVEY.md N4) the N = 1 run appends")
+    ap.add_argument("--no-loss-vs-ref", action="store_true", help="skip the loss-vs-reference leg (the C2 fixture's 5 injected steps) the N = 1 run appends")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the b = 32 per-GPU leg (the 8-GPU shape) the N = 1 run appends")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("REED_BENCH_LAUNCH_TIMEOUT", "2400")),
                     help="seconds the self-launcher lets its ranks run before it ends them (a hung collective must not hang the caller)")
@@ -431,6 +432,47 @@ def n2_encoder_leg(dev, batch=64, reps=3):
                     "features are not precomputed"}
 
 
+def loss_vs_ref_leg(dev, steps=5, B=8):
+    """BASELINE.json's second number, "loss-vs-ref delta": the C2 fixture tests/golden/xl2_c2.npz — SiT-XL/2 + 1024-d projector,
+    B = 8, 5 optimiser steps on injected (x, t, noise, labels, zs) with deterministically filled weights; the per-step total loss
+    (image/train.py:396-398) of the reference under bf16 autocast and in fp32, written by tools/gen_golden.py from the imported
+    reference — run on the HIP path here, after the timed region.  Nothing of oracle/ or the reference is imported: the fixture
+    holds the reference's numbers and reed_amd/detfill.py rebuilds weights and inputs."""
+    import copy
+    import numpy as np
+    from reed_amd import detfill
+    from reed_amd.loss import SILoss
+    from reed_amd.models.sit import SiT_models
+    from reed_amd.optim import FusedAdamWEMA
+    g = np.load(os.path.join(ROOT, "tests", "golden", "xl2_c2.npz"))
+    m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8)
+    detfill.fill_model(m.state_dict(), base_seed=0)
+    m = m.to(dev).train()
+    ema = copy.deepcopy(m).requires_grad_(False).eval()
+    opt = FusedAdamWEMA(m, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
+    lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
+    losses = []
+    for s_ in range(steps):
+        x, noise, t, y, drop_u, zs = detfill.step_inputs(B, s_, [1024])
+        m.force_drop_mask = drop_u < 0.1
+        out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+        total = out["denoising_loss"].mean() + 0.5 * out["proj_loss"].mean()
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        losses.append(float(total))
+    opt.flush()
+    ref_b, ref_f = g["bf16.loss"][:steps], g["fp32.loss"][:steps]
+    d_b, d_f = np.abs(np.array(losses) - ref_b), np.abs(np.array(losses) - ref_f)
+    return {"max_abs_delta_bf16": float(round(d_b.max(), 7)), "bar": 1e-3, "steps": steps, "batch": B,
+            "within_bar": bool((d_b <= 1e-3).all()),
+            "hip_loss": [round(v, 6) for v in losses], "reference_bf16_autocast_loss": [round(float(v), 6) for v in ref_b],
+            "abs_delta_per_step_bf16": [float(round(v, 7)) for v in d_b],
+            "max_abs_delta_vs_fp32_reference": float(round(d_f.max(), 7)),
+            "reference_own_bf16_vs_fp32_gap": float(round(np.abs(ref_b - ref_f).max(), 7)),
+            "fixture": "tests/golden/xl2_c2.npz (tools/gen_golden.py, the imported reference; image/train.py:396-398)"}
+
+
 def n4_vae_leg(dev, batch=8, reps=3):
     """SURVEY.md §8f N4 beside the headline: the SD-VAE decoder of generate.py / the previews (published sd-vae-ft configuration,
     random weights, 32x32 latents -> 256x256 images) on the HIP kernels, fp16 operands = what generate.py uses under the
@@ -772,6 +814,11 @@ def main():
                     out[key] = fn(dev)
                 except Exception as e:
                     out[key] = {"error": repr(e)}
+        if world == 1 and args.mixed_precision == "bf16" and not args.no_loss_vs_ref:
+            try:
+                out["loss_vs_ref"] = loss_vs_ref_leg(dev)
+            except Exception as e:
+                out["loss_vs_ref"] = {"error": repr(e)}
         if world == 1 and not args.no_vae_leg:
             try:
                 out["n4_vae_decode"] = n4_vae_leg(dev)

@@ -40,7 +40,9 @@ int reed_half_kind(void);
  *   5 dsilu, 6 f32 (+=), 7 f32 += bf16-rounded, 8 f32 atomic, 9 QuickGELU, 10 + bf16 residual, 12 LayerScale + fp32 residual:
  *   C f32 = R f32 + gamma[n] * float(bf16(acc + bias)) with `gate` = the fp32 gamma vector, NT only; 13 = 0 plus the per-row,
  *   per-head partial dot products with R for reed_attention_bwd_dp (NN; returns 1002 without launching where the shape's
- *   kernel has no such epilogue).  N%128==0 (NT/NN with a
+ *   kernel has no such epilogue); 14 / 15 = 1 / 2 with C = the activation's DERIVATIVE at the pre-activation instead of the
+ *   pre-activation itself (what the backward needs: nothing else read the saved pre-activation), 16 = C bf16 =
+ *   bf16(bf16(acc) * R): the activation backward as one multiply by that saved derivative.  N%128==0 (NT/NN with a
  *   bf16-output epilogue also N%144==0: the 256x144 tile of csrc/gemm144.hip); K%64==0 (NT/NN);
  *   M%128==0 (TN).  split_k>1 only with epilogue 8, or 6 with slab_stride>0 (C then holds split_k slabs;
  *   dbias likewise holds split_k slabs of M floats AT THE SAME slab_stride — put slab 0 of dbias right behind slab 0

@@ -54,14 +54,15 @@ extern "C" int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, c
     epilogue = EPI_QGELU;   // the fp32-operand GEMM switches on the variant at run time (gemm_f32.hip)
 #endif
   }
-  const bool act_epi = epilogue == EPI_GELU || epilogue == EPI_SILU || epilogue == EPI_QGELU || epilogue == EPI_GELU_ERF;
+  const bool act_epi = epilogue == EPI_GELU || epilogue == EPI_SILU || epilogue == EPI_QGELU || epilogue == EPI_GELU_ERF ||
+                       epilogue == EPI_GELU_G || epilogue == EPI_SILU_G;
   REED_CHECK_ARG(P && Q && (C || act_epi), "reed_gemm: null operand");
   if (act_epi) REED_CHECK_ARG(C2, "reed_gemm: activation epilogue needs C2");
   if (epilogue == EPI_RES_BF16) REED_CHECK_ARG(R, "reed_gemm: residual epilogue needs R");
   if (epilogue == EPI_GATE_RES) REED_CHECK_ARG(R && gate, "reed_gemm: gate-residual epilogue needs R and gate");
   if (epilogue == EPI_LS_RES)
     REED_CHECK_ARG(R && gate && layout == LAY_NT && split_k <= 1, "reed_gemm: LayerScale-residual epilogue: NT, R and gamma (gate)");
-  if (epilogue == EPI_DGELU || epilogue == EPI_DSILU) REED_CHECK_ARG(R, "reed_gemm: activation-grad epilogue needs R");
+  if (epilogue == EPI_DGELU || epilogue == EPI_DSILU || epilogue == EPI_MUL) REED_CHECK_ARG(R, "reed_gemm: activation-grad epilogue needs R");
   return reed_gemm_launch(layout, epilogue, a, split_k, (hipStream_t)stream);
 }
 

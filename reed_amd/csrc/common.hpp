@@ -129,6 +129,21 @@ __device__ __forceinline__ f32x2 gelu_tanh_grad2(f32x2 x) {
   const f32x2 xs = x * s;
   return __builtin_elementwise_fma(xs - xs * s, __builtin_elementwise_fma(f32x2{d1, d1}, x * x, f32x2{d0, d0}), s);
 }
+// Round 5: activation AND derivative from the one sigmoid (the forward epilogues EPI_GELU_G / EPI_SILU_G save the derivative for
+// the backward's one-multiply epilogue EPI_MUL): gelu = x s, gelu' = s + (x s - x s s)(d0 + d1 x^2) — three more packed
+// instructions per pair on top of gelu_tanh2.
+__device__ __forceinline__ void gelu_tanh_both2(f32x2 x, f32x2& act, f32x2& grad) {
+  const float d0 = 2.f * 0.7978845608028654f, d1 = d0 * 3.f * 0.044715f;
+  const f32x2 s = gelu_sig2(x);
+  act = x * s;
+  grad = __builtin_elementwise_fma(act - act * s, __builtin_elementwise_fma(f32x2{d1, d1}, x * x, f32x2{d0, d0}), s);
+}
+__device__ __forceinline__ void gelu_tanh_both(float x, float& act, float& grad) {
+  const float d0 = 2.f * 0.7978845608028654f, d1 = d0 * 3.f * 0.044715f;
+  const float s = gelu_sig(x);
+  act = x * s;
+  grad = fmaf(act - act * s, fmaf(d1, x * x, d0), s);
+}
 // nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2)) — the frozen ViT towers' Mlp activation (inference only)
 #if defined(REED_FP32)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
@@ -153,6 +168,11 @@ __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
   float s = sigmoid_f(x);
   return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ void silu_both(float x, float& act, float& grad) {
+  const float s = sigmoid_f(x);
+  act = x * s;
+  grad = s * (1.f + x * (1.f - s));
 }
 
 // ---- wave / block reductions (wave = 64 lanes) -----------------------------

@@ -23,8 +23,14 @@ enum {
                       //   (64: S = 1, 72: S = 2) the partial dot products of the stored row with R bf16 [M, N]: slot s of head h is the
                       //   part inside the (s + 1)-th 64-column strip the head touches.  NN, 256^2 four-wave kernel only: the attention
                       //   backward's delta = rowsum(dO * O) formed where dO is produced (reed_attention_bwd_dp adds the slots)
-  EPI_GELU_ERF = 11   // C2 bf16 = GELU(erf)(pre): nn.GELU() of the timm / I-JEPA towers' Mlp (its own instantiation since round 4;
+  EPI_GELU_ERF = 11,  // C2 bf16 = GELU(erf)(pre): nn.GELU() of the timm / I-JEPA towers' Mlp (its own instantiation since round 4;
                       //   the fp32-operand build folds it into EPI_QGELU with GemmArgs::act_variant = 1)
+  // Round 5: the activation's DERIVATIVE is formed where the activation is (the forward epilogue holds sigmoid(2u) already) and
+  // saved in the array the pre-activation used to occupy — the pre-activation of fc1 / the projector layers was kept for the
+  // backward's dGELU / dSiLU epilogue only — so that epilogue becomes one multiply per element (EPI_MUL):
+  EPI_GELU_G = 14,    // C bf16 = bf16(gelu_tanh'(pre)) (optional), C2 bf16 = gelu_tanh(pre), pre = bf16(acc+bias)
+  EPI_SILU_G = 15,    // same with SiLU
+  EPI_MUL = 16        // C bf16 = bf16(bf16(acc) * R bf16)
 };
 
 struct GemmArgs {

@@ -31,8 +31,6 @@ int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm256w.hip: 4 waves x 128x128
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 int reed_num_cus();   // gemm256.hip
-bool reed_gemm128c_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm128c.hip: 128x256 tiles, two workgroups per CU
-int reed_gemm128c_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 bool reed_gemm_skinny_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm_skinny.hip: 16 x 64 tiles, one wave each
 int reed_gemm_skinny_launch(int epi, GemmArgs a, hipStream_t stream);
 
@@ -212,6 +210,9 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
     case EPI_GATE_RES: return launch<LAY, EPI_GATE_RES>(a, splits, s);
     case EPI_DGELU: return launch<LAY, EPI_DGELU>(a, splits, s);
     case EPI_DSILU: return launch<LAY, EPI_DSILU>(a, splits, s);
+    case EPI_GELU_G: return launch<LAY, EPI_GELU_G>(a, splits, s);
+    case EPI_SILU_G: return launch<LAY, EPI_SILU_G>(a, splits, s);
+    case EPI_MUL: return launch<LAY, EPI_MUL>(a, splits, s);
     case EPI_F32: return launch<LAY, EPI_F32>(a, splits, s);
     case EPI_ADDF32_RB: return launch<LAY, EPI_ADDF32_RB>(a, splits, s);
     case EPI_ATOMIC_F32: return launch<LAY, EPI_ATOMIC_F32>(a, splits, s);
@@ -228,7 +229,7 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 129 / 256 / 144 / 257 / 258 = force where the shape allows (tests, A/B timing)
+static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 256 / 144 / 257 / 258 = force where the shape allows (tests, A/B timing)
 extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
 int reed_gemm_forced_tile() { return g_force_tile; }
 
@@ -290,7 +291,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
     static int split_on = -1;
     if (split_on < 0) { const char* e = getenv("REED_GEMM_SPLIT_M"); split_on = e ? atoi(e) : 1; }
     const bool epi_rows_free = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_QGELU || epi == EPI_GELU_ERF ||
-                               epi == EPI_RES_BF16 || epi == EPI_LS_RES || epi == EPI_DGELU || epi == EPI_DSILU;
+                               epi == EPI_RES_BF16 || epi == EPI_LS_RES || epi == EPI_DGELU || epi == EPI_DSILU ||
+                               epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_MUL;
     const int r = a.M % 256, mfull = a.M - r;
     if (split_on && g_force_tile == 0 && want != EPI_BF16_DOT && epi_rows_free && splits <= 1 && (layout == LAY_NT || layout == LAY_NN) &&
         r > 0 && r <= 128 && mfull >= 2048) {
@@ -315,15 +317,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
       }
     }
   }
-  // the two-workgroups-per-CU kernel (gemm128c.hip): force_tile 129 wherever it is built; REED_GEMM128C=<mask> (bit e = epilogue
-  // id e) selects it for those epilogues on problems of at least 16384 rows
-  {
-    static int cmask = -1;
-    if (cmask < 0) { const char* e = getenv("REED_GEMM128C"); cmask = e ? atoi(e) : 0; }
-    if ((g_force_tile == 129 || (g_force_tile == 0 && ((cmask >> epi) & 1) && a.M >= 16384 && want != EPI_BF16_DOT)) &&
-        reed_gemm128c_eligible(layout, epi, a, splits) && want != EPI_BF16_DOT)
-      return reed_gemm128c_launch(layout, epi, a, stream);
-  }
+  // (a 128x256 tile with two workgroups per CU — an epilogue overlapping the other workgroup's K loop — was built in round 4,
+  // bit-identical and slower: its operand stream is 1.5x per flop; profiles/r4_gemm128c_*.txt, DESIGN_HISTORY.md; removed in round 5)
   if (g_force_tile == 64 && want != EPI_BF16_DOT && reed_gemm_skinny_eligible(layout, epi, a, splits))
     return reed_gemm_skinny_launch(epi, a, stream);   // tests: the skinny kernel on any shape it accepts
   if ((g_force_tile == 257 || g_force_tile == 258) && reed_gemm256w_eligible(layout, epi, a, splits))

@@ -78,13 +78,20 @@ __device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
       *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
-    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF) {
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF || EPI == EPI_GELU_G ||
+                         EPI == EPI_SILU_G) {
       bf16x4 pre, act;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pre[e] = f2bf(v[e]);
         const float x = bf2f(pre[e]);
-        if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+        if constexpr (EPI == EPI_GELU_G || EPI == EPI_SILU_G) {   // the saved array carries the derivative (gemm.h)
+          float av, gv;
+          if constexpr (EPI == EPI_GELU_G) gelu_tanh_both(x, av, gv);
+          else silu_both(x, av, gv);
+          pre[e] = f2bf(gv);
+          act[e] = f2bf(av);
+        } else if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
         else if constexpr (EPI == EPI_GELU_ERF) act[e] = f2bf(gelu_erf_f(x));
         else act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
       }
@@ -110,6 +117,7 @@ __device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&
         const float du = bfround(v[e]);
         const float x = bf2f(pre[e]);
         if constexpr (EPI == EPI_RES_BF16) o[e] = f2bf(du + x);
+        else if constexpr (EPI == EPI_MUL) o[e] = f2bf(du * x);
         else o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
       }
       *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
@@ -408,7 +416,8 @@ static bool use_loader_waves() {
 template <int LAY, int EPI>
 int launch144(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr bool HAS_LW = EPI == EPI_BF16 || EPI == EPI_GATE_RES || EPI == EPI_GELU || EPI == EPI_DGELU;
+  constexpr bool HAS_LW = EPI == EPI_BF16 || EPI == EPI_GATE_RES || EPI == EPI_GELU || EPI == EPI_DGELU || EPI == EPI_GELU_G ||
+                          EPI == EPI_MUL;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm144_kernel<LAY, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        LDS4);
@@ -441,6 +450,9 @@ int dispatch144(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_GATE_RES: return launch144<LAY, EPI_GATE_RES>(a, s);
     case EPI_DGELU: return launch144<LAY, EPI_DGELU>(a, s);
     case EPI_DSILU: return launch144<LAY, EPI_DSILU>(a, s);
+    case EPI_GELU_G: return launch144<LAY, EPI_GELU_G>(a, s);
+    case EPI_SILU_G: return launch144<LAY, EPI_SILU_G>(a, s);
+    case EPI_MUL: return launch144<LAY, EPI_MUL>(a, s);
     case EPI_QGELU: return launch144<LAY, EPI_QGELU>(a, s);
     case EPI_GELU_ERF: return launch144<LAY, EPI_GELU_ERF>(a, s);
     case EPI_RES_BF16: return launch144<LAY, EPI_RES_BF16>(a, s);
@@ -454,7 +466,8 @@ int dispatch144(int epi, const GemmArgs& a, hipStream_t s) {
 // shapes the 256x144 kernel can take: NT / NN, bf16-output epilogue, N a multiple of 144, no split-K
 bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits) {
   const bool bf16_epi = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES || epi == EPI_DGELU ||
-                        epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_GELU_ERF || epi == EPI_RES_BF16;
+                        epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_GELU_ERF || epi == EPI_RES_BF16 || epi == EPI_GELU_G ||
+                        epi == EPI_SILU_G || epi == EPI_MUL;
   return (layout == LAY_NT || layout == LAY_NN) && bf16_epi && splits <= 1 && a.N % BN4 == 0 && a.K % BK4 == 0 &&
          a.K >= BK4;
 }

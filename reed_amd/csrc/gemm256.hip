@@ -368,6 +368,9 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
       case EPI_GATE_RES: return launch256<LAY, EPI_GATE_RES>(a, splits, s);
       case EPI_DGELU: return launch256<LAY, EPI_DGELU>(a, splits, s);
       case EPI_DSILU: return launch256<LAY, EPI_DSILU>(a, splits, s);
+      case EPI_GELU_G: return launch256<LAY, EPI_GELU_G>(a, splits, s);
+      case EPI_SILU_G: return launch256<LAY, EPI_SILU_G>(a, splits, s);
+      case EPI_MUL: return launch256<LAY, EPI_MUL>(a, splits, s);
       case EPI_F32: return launch256<LAY, EPI_F32>(a, splits, s);
       case EPI_ADDF32_RB: return launch256<LAY, EPI_ADDF32_RB>(a, splits, s);
       case EPI_ATOMIC_F32: return launch256<LAY, EPI_ATOMIC_F32>(a, splits, s);
@@ -435,7 +438,8 @@ bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits) 
   // (A/B at b = 128: fc2 forward 0.407 -> 0.362 ms, fc1 / qkv dgrads 0.385 -> 0.322 / 0.285 -> 0.237 ms on 256^2)
   const bool ragged = (a.N % BN2) != 0 && (a.N % BN2) <= 128 &&
                       (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES || epi == EPI_DGELU ||
-                       epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_GELU_ERF || epi == EPI_RES_BF16 || epi == EPI_LS_RES);
+                       epi == EPI_DSILU || epi == EPI_QGELU || epi == EPI_GELU_ERF || epi == EPI_RES_BF16 || epi == EPI_LS_RES ||
+                       epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_MUL);
   double rounds256;
   if (ragged) {
     const double w = (double)tm * (tn - 1) + 0.6 * tm;

@@ -42,17 +42,9 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_EPI_PF
 #define REED_EPI_PF 4
 #endif
-// 1: the epilogues that have an MFMA-layout form (gemm_common.hpp: tile_epilogue_direct) use it — bit-identical, and SLOWER (plain
-// 4.9 vs 4.4 us per tile, gate + residual 27 vs 22: profiles/r4_epilogue_forms.txt), so 0, the LDS-patch forms, is the product
-// 1: the full drain (vmcnt(0)) at a persistent tile's start and at its K-tile 0; 0: counted waits that leave the previous tile's
-// epilogue stores in flight under K-tile 0 (wait_staged below).  Measured equal (block table 5.728 / 5.715 / 5.724 ms drained,
-// 5.732 / 5.715 / 5.723 counted: profiles/r4_epilogue_forms.txt): the drain is not what a tile's first 0.7 us are.  Default: drain.
-#ifndef REED_PM_DRAIN
-#define REED_PM_DRAIN 1
-#endif
-#ifndef REED_EPI_DIRECT
-#define REED_EPI_DIRECT 0
-#endif
+// (Round 4 measured and round 5 removed two variants: an MFMA-layout epilogue without the LDS patch — bit-identical, plain 4.9 vs
+// 4.4 us per tile, gate + residual 27 vs 22 — and counted waits that leave the previous persistent tile's epilogue stores in flight
+// under K-tile 0 — equal; profiles/r4_epilogue_forms.txt.  A persistent tile drains (vmcnt(0)) at its start and at its K-tile 0.)
 // 1: the four-wave TN form (weight gradients, REED_WGRAD_W4=1) walks its K-tile buffers as a ring of four 32-row slices (below)
 #ifndef REED_TN_RING
 #define REED_TN_RING 1
@@ -369,7 +361,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   } while (0)
 
   // PF: K-tile t+2 exists (literal true in the steady-state loop: no branch around the DMAs)
-#define WKTILE(T, CUR, PF, KIND, KT) WKTILE_(T, CUR, PF, KIND, KT, 0, 0)
+#define WKTILE(T, CUR, PF, KIND, KT) WKTILE_(T, CUR, PF, KIND, KT, 0)
 #ifdef REED_CLK_PHASE   /* diagnostic build: cycles per phase (A, the waits + barrier, B), one stamp = s_memtime + lgkmcnt(0) */
 #define WSTAMP(K)                                                                          \
   do {                                                                                     \
@@ -384,7 +376,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #else
 #define WSTAMP(K)
 #endif
-#define WKTILE_(T, CUR, PF, KIND, KT, Z, CW)                                                \
+#define WKTILE_(T, CUR, PF, KIND, KT, Z)                                                    \
   do {                                                                                     \
     const int t_ = (T);                                                                    \
     asm volatile("" : "+v"(rA), "+v"(rB), "+v"(tA0), "+v"(tB0), "+v"(tSA), "+v"(tSB));     \
@@ -394,8 +386,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     WPHASE(0, (CUR), 1, false, 0, 0, 0, Z);                                                \
     WSTAMP(0);                                                                             \
     /* phase B: K-tile t+1 landed, every wave done with K-tile t; MFMAs of (t, ks1); reads of (t+1, ks0); DMAs of t+2 */ \
-    if constexpr ((CW) != 0) wait_staged(0);                                               \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
     WLGKM0();                                                                              \
     WBARRIER();                                                                            \
     WSTAMP(1);                                                                             \
@@ -407,32 +398,9 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   } while (0)
 
   // PM: the previous tile staged this tile's K-tiles 0 and 1 beside its last two K-tiles; its epilogue's loads and stores are
-  // YOUNGER than those DMAs and counted in the same vmcnt, which retires in issue order: K-tile 0 has landed once at most
-  // (16 DMAs of K-tile 1 + the epilogue's instructions) are outstanding, K-tile 1 once at most the epilogue's are — capped at the
-  // 63 a counted wait can express.  (REED_PM_DRAIN=0 only; the default drains everything, vmcnt(0), at both points.)  The counts are
-  // lower bounds of what a wave issues in the epilogue (gemm_common.hpp: EpiOps per 64-column strip; fewer allowed = stricter = safe).
-  auto wait_staged = [&](const int extra) {
-    constexpr bool direct = REED_EPI_DIRECT && EpiDirect<EPI>::value;
-    constexpr int s8 = direct ? EpiDirectOps<EPI, 8>::value : EpiOps<EPI, 8>::value;   // previous tile MODE 0: two strips of 8 row groups
-    constexpr int s4 = direct ? EpiDirectOps<EPI, 4>::value : EpiOps<EPI, 4>::value;   // MODE 1: two strips of 4
-    constexpr int e0 = s8 < 0 ? 0 : 2 * s8, e1 = s4 < 0 ? 0 : 2 * s4;
-    constexpr int c0 = e0 > 63 ? 63 : e0, c1 = e1 > 63 ? 63 : e1;
-    constexpr int d0 = e0 + 16 > 63 ? 63 : e0 + 16, d1 = e1 + 16 > 63 ? 63 : e1 + 16;   // dmas_next issues 16 pieces per K-tile
-    if (prev_mode < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (extra) {
-      if (prev_mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d0) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(d1) : "memory");
-    } else {
-      if (prev_mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c0) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(c1) : "memory");
-    }
-  };
+  // YOUNGER than those DMAs in the same vmcnt: everything is drained here and at K-tile 0.
   if (PM != 0 && !first) {
-#if REED_PM_DRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-    wait_staged(1);
-#endif
     WBARRIER();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
@@ -552,7 +520,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #endif
   {
   if constexpr (PM != 0) {   // nt >= 4 (the host checked): K-tile 0's first k-step starts the accumulation
-    WKTILE_(0, 0, true, 0, 0, 1, !REED_PM_DRAIN);
+    WKTILE_(0, 0, true, 0, 0, 1);
     WKTILE(1, 1, true, 0, 0);
     t = 2;
   }
@@ -609,12 +577,6 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
 #endif
   // epilogue: the wave's piece in 64-column groups through gemm_common.hpp's tile_epilogue (fp32 outputs: its pointer path)
   char* stage = smem + 8 * HTW + wave * EPI_STAGE_BYTES;
-#if REED_EPI_DIRECT
-  if constexpr (EpiDirect<EPI>::value) {
-    tile_epilogue_direct<EPI, NA, NB, 0, REED_EPI_PF>(a, acc, m0, mrow, n0 + ncol);
-    if constexpr (NB == 8) tile_epilogue_direct<EPI, NA, NB, 4, REED_EPI_PF>(a, acc, m0, mrow, n0 + ncol + 64);
-  } else
-#endif
 #pragma unroll
   for (int h = 0; h < NB / 4; ++h) {
     f32x4 part[NA][4];
@@ -1021,6 +983,8 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
       case EPI_BF16: return launch256w<LAY, EPI_BF16>(a, s);
       case EPI_GELU: return launch256w<LAY, EPI_GELU>(a, s);
       case EPI_SILU: return launch256w<LAY, EPI_SILU>(a, s);
+      case EPI_GELU_G: return launch256w<LAY, EPI_GELU_G>(a, s);
+      case EPI_SILU_G: return launch256w<LAY, EPI_SILU_G>(a, s);
       case EPI_GATE_RES: return launch256w<LAY, EPI_GATE_RES>(a, s);
       case EPI_RES_BF16: return launch256w<LAY, EPI_RES_BF16>(a, s);
       case EPI_LS_RES: return launch256w<LAY, EPI_LS_RES>(a, s);
@@ -1033,6 +997,7 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
       case EPI_BF16_DOT: return launch256w<LAY, EPI_BF16_DOT>(a, s);
       case EPI_DGELU: return launch256w<LAY, EPI_DGELU>(a, s);
       case EPI_DSILU: return launch256w<LAY, EPI_DSILU>(a, s);
+      case EPI_MUL: return launch256w<LAY, EPI_MUL>(a, s);
     }
   }
   reed_set_error("reed_gemm(256w): epilogue %d not built for this layout", epi);
@@ -1047,8 +1012,8 @@ bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) 
   // round 4: each of the two is now its own instantiation (gemm_common.hpp); REED_QGELU_W4=1 sends them to this kernel (A/B)
   static const bool qw4 = getenv("REED_QGELU_W4") && atoi(getenv("REED_QGELU_W4")) == 1;
   const bool epi_ok = layout == LAY_NT ? (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES ||
-                                          epi == EPI_RES_BF16 || epi == EPI_LS_RES || (qw4 && (epi == EPI_QGELU || epi == EPI_GELU_ERF)))
-                                       : (epi == EPI_BF16 || epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_DSILU);
+                                          epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_RES_BF16 || epi == EPI_LS_RES || (qw4 && (epi == EPI_QGELU || epi == EPI_GELU_ERF)))
+                                       : (epi == EPI_BF16 || epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL);
   return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 && epi_ok;
 }
 

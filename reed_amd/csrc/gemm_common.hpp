@@ -83,6 +83,7 @@ template <int EPI, int NI>
 struct EpiOps {
   static constexpr int value = EPI == EPI_BF16 ? 1 + NI * 2
                                : (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_DGELU || EPI == EPI_DSILU ||
+                                  EPI == EPI_GELU_G || EPI == EPI_SILU_G || EPI == EPI_MUL ||
                                   EPI == EPI_QGELU || EPI == EPI_GELU_ERF || EPI == EPI_RES_BF16) ? 1 + NI * 4
                                : EPI == EPI_BF16_DOT ? 1 + NI * 4
                                : EPI == EPI_GATE_RES ? 1 + NI * 12
@@ -280,7 +281,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
 #endif
         }
       }
-    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF) {
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF || EPI == EPI_GELU_G ||
+                         EPI == EPI_SILU_G) {
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsC2 = tile_rsrc(a.C2, a.ldc2, 2);
       int oc = lane_off(a.ldc, 2), oc2 = lane_off(a.ldc2, 2);
       const int s8 = (int)(8 * a.ldc * 2), t8 = (int)(8 * a.ldc2 * 2);
@@ -291,7 +293,25 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bf16x8 pre, act;
-          if constexpr (EPI == EPI_GELU && REED_EPI_PACKED) {   // two elements per instruction (common.hpp: gelu_tanh2)
+          if constexpr (EPI == EPI_GELU_G) {   // `pre` carries gelu'(pre): what the backward multiplies by (EPI_MUL)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bf16x2 p2 = __builtin_convertvector(f32x2{v[h][2 * k], v[h][2 * k + 1]}, bf16x2);
+              f32x2 av, gv;
+              gelu_tanh_both2(__builtin_convertvector(p2, f32x2), av, gv);
+              const bf16x2 a2 = __builtin_convertvector(av, bf16x2), g2 = __builtin_convertvector(gv, bf16x2);
+              pre[2 * k] = g2[0]; pre[2 * k + 1] = g2[1];
+              act[2 * k] = a2[0]; act[2 * k + 1] = a2[1];
+            }
+          } else if constexpr (EPI == EPI_SILU_G) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float av, gv;
+              silu_both(bfround(v[h][e]), av, gv);
+              pre[e] = f2bf(gv);
+              act[e] = f2bf(av);
+            }
+          } else if constexpr (EPI == EPI_GELU && REED_EPI_PACKED) {   // two elements per instruction (common.hpp: gelu_tanh2)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const bf16x2 p2 = __builtin_convertvector(f32x2{v[h][2 * k], v[h][2 * k + 1]}, bf16x2);
@@ -436,14 +456,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
           st_f32x4<SA>(xo[1], rsC, oc + h * s8 + 16);
         }
       }
-    } else {  // EPI_DGELU / EPI_DSILU / EPI_RES_BF16
+    } else {  // EPI_DGELU / EPI_DSILU / EPI_MUL / EPI_RES_BF16
       const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsR = tile_rsrc(a.R, a.ldr, 2);
       int oc = lane_off(a.ldc, 2), orr = lane_off(a.ldr, 2);
       const int s8 = (int)(8 * a.ldc * 2), r8 = (int)(8 * a.ldr * 2);
       bf16x8 pre[NI][2];
       auto fetch = [&](int i) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) pre[i][h] = ld_bf16x8<(EPI == EPI_DGELU || EPI == EPI_DSILU) ? EPI_SAVED_AUX : 0>(rsR, orr + i * 2 * r8 + h * r8);
+        for (int h = 0; h < 2; ++h) pre[i][h] = ld_bf16x8<(EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_MUL) ? EPI_SAVED_AUX : 0>(rsR, orr + i * 2 * r8 + h * r8);
       };
       constexpr int PFD = 2 * PF;   // 8 registers per row group: twice the depth of the fp32 residual's
 #pragma unroll
@@ -457,7 +477,15 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           bf16x8 o;
-          if constexpr (EPI == EPI_DGELU && REED_EPI_PACKED) {
+          if constexpr (EPI == EPI_MUL) {   // the saved factor IS the activation's derivative (EPI_GELU_G / EPI_SILU_G)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f32x2 du = __builtin_convertvector(__builtin_convertvector(f32x2{v[h][2 * k], v[h][2 * k + 1]}, bf16x2), f32x2);
+              const f32x2 x = __builtin_convertvector(bf16x2{pre[i][h][2 * k], pre[i][h][2 * k + 1]}, f32x2);
+              const bf16x2 o2 = __builtin_convertvector(du * x, bf16x2);
+              o[2 * k] = o2[0]; o[2 * k + 1] = o2[1];
+            }
+          } else if constexpr (EPI == EPI_DGELU && REED_EPI_PACKED) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const f32x2 du = __builtin_convertvector(__builtin_convertvector(f32x2{v[h][2 * k], v[h][2 * k + 1]}, bf16x2), f32x2);
@@ -479,231 +507,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x4 (&a
     }
   }
 }
-
-// ---- MFMA-layout epilogues (round 4): no LDS round trip -------------------------------------------------------------------
-// In-kernel stamps (tools/r4/epi_phase.py) showed what the patch costs: the plain bf16 epilogue of a 256^2 tile takes 4.2-4.5 us
-// whether 30 or 250 other CUs store at the same moment (16 row groups per wave x {4 ds_write_b128, 4 ds_read_b128, wait}: the four
-// waves' 32 KiB per group step through a 128 B/clk LDS write port, in a serial chain the scheduling fence keeps serial), and the
-// gate + residual one has a floor of 14 us under its HBM-bound 21.  Here nothing goes through LDS: fp32 operands and outputs are
-// accessed as the accumulator stands (lane (i, g) of tile j owns row i, columns 16 j + 4 g .. + 3: 16 bytes per lane, a wave
-// instruction covers 64 contiguous bytes of each of 16 rows, and the four tiles of a strip complete every 256-byte row
-// segment), and 16-bit ones after one v_permlane16_swap per dword of a tile PAIR, which exchanges the odd 16-lane rows of tile
-// 2p with the even rows of tile 2p + 1: lane row g then holds columns 32 p + 16 (g & 1) + 8 (g >> 1) .. + 7 of its row, 16 bytes
-// (the swap is its own inverse: 16-bit OPERANDS are loaded in that layout and swapped back).  Same arithmetic per element as the
-// patch forms above: results are bit-identical.  Branch-free like them (range-checked descriptors, out-of-range offsets for
-// columns >= N); vector-memory instructions per wave and strip: EpiDirectOps.
-template <int EPI>
-struct EpiDirect {
-  static constexpr bool value = EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF ||
-                                EPI == EPI_GATE_RES || EPI == EPI_DGELU || EPI == EPI_DSILU || EPI == EPI_RES_BF16;
-};
-template <int EPI, int NI>
-struct EpiDirectOps {   // 4 bias loads, then per row group
-  static constexpr int value = 4 + (EPI == EPI_BF16 ? NI * 2 : EPI == EPI_GATE_RES ? 4 + NI * 10 : NI * 4);
-};
-__device__ __forceinline__ unsigned pk_16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ u32x4 pair_fwd(u32x2 x, u32x2 y) {   // tiles 2p, 2p + 1 (4 columns each) -> 8 consecutive columns
-  const auto r0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
-  const auto r1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
-  return u32x4{r0[0], r1[0], r0[1], r1[1]};
-}
-__device__ __forceinline__ void pair_inv(u32x4 w, bf16x4& x, bf16x4& y) {
-  const auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
-  const auto r1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
-  x = __builtin_bit_cast(bf16x4, u32x2{r0[0], r1[0]});
-  y = __builtin_bit_cast(bf16x4, u32x2{r0[1], r1[1]});
-}
-__device__ __forceinline__ bf16x4 ld_bf16x4(__amdgpu_buffer_rsrc_t rs, unsigned off, int soff = 0) {
-  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, soff, 0));
-}
-
-// one row group at a time (as the patch forms): left free, the compiler interleaves the groups, runs out of registers beside the
-// 256 accumulators and spills K-loop values.  PF: row groups of operand loads kept in flight ahead of the one being written.
-#define GROUP_FENCE()                        \
-  do {                                       \
-    __builtin_amdgcn_sched_barrier(0);       \
-    asm volatile("" ::: "memory");           \
-  } while (0)
-// The strip is columns 16 J0 .. 16 J0 + 63 of the wave's accumulator grid, read in place: a copy of the strip made by the caller
-// sits in front of the first fence (128 live registers where the patch forms wrote LDS straight from the AGPRs).
-// AGPR: the caller's accumulators live in AGPRs (inline-asm MFMAs): each element is read where its row group is formed.  Left to the
-// compiler the AGPR -> VGPR copies of the WHOLE grid are placed right behind the K loop (256 live registers, dozens of spills).
-template <bool AGPR>
-__device__ __forceinline__ float acc_rd(const float& x) {
-  if constexpr (AGPR) {
-    float r;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
-    return r;
-  } else {
-    return x;
-  }
-}
-template <int EPI, int NI, int NBT, int J0, int PF = 4, bool AGPR = true>
-__device__ __forceinline__ void tile_epilogue_direct(const GemmArgs& a, const f32x4 (&acc)[NI][NBT], int m0, int mw, int nbase) {
-  int lane;
-  static_assert(EpiDirect<EPI>::value, "no MFMA-layout form of this epilogue");
-  // opaque: everything below is a handful of VALU instructions per tile; hoisted out of a persistent kernel's tile loop it becomes
-  // registers that live across the K loop, and the compiler spills them (scratch reloads + vmcnt(0) in the middle of the stores)
-  // (and the lane index itself comes from v_mbcnt here: as a value of the caller it was spilled at kernel entry and re-loaded
-  // from scratch at every strip, with an s_waitcnt vmcnt(0) — the previous strip's stores — in front of its first use)
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-  const int li = lane & 15, g = lane >> 4;
-  const long rows = a.M - m0;
-  const int rt = mw + li;                                     // the lane's row inside the tile (row group 0)
-  const int cq = nbase + 4 * g;                               // accumulator layout: tile j at columns cq + 16 j .. + 3
-  const int c8 = nbase + 16 * (g & 1) + 8 * (g >> 1);         // paired layout: pair p at columns c8 + 32 p .. + 7
-  auto tile_rsrc = [&](const void* p, long ld, int es) {
-    return epi_rsrc(p ? (const char*)p + (long)m0 * ld * es : nullptr, ((rows - 1) * ld + a.N) * es);
-  };
-  // byte offsets of row group 0 (N is a multiple of 16: a 16-column tile / an 8-column piece exists or not as a whole)
-  auto offq = [&](long ld, int es, int j) { return cq + 16 * j < a.N ? (unsigned)((rt * ld + cq + 16 * j) * es) : (unsigned)EPI_OOB; };
-  auto off8 = [&](long ld, int es, int p) { return c8 + 32 * p < a.N ? (unsigned)((rt * ld + c8 + 32 * p) * es) : (unsigned)EPI_OOB; };
-  float bs[4][4];
-  {
-    const __amdgpu_buffer_rsrc_t rsB = epi_rsrc(a.bias, (long)a.N * 2);   // empty if absent -> zeros
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x4 b = ld_bf16x4(rsB, cq + 16 * j < a.N ? (unsigned)((cq + 16 * j) * 2) : (unsigned)EPI_OOB);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bs[j][e] = bf2f(b[e]);
-    }
-  }
-  auto store_pairs = [&](const bf16x4 (&t)[4], __amdgpu_buffer_rsrc_t rs, const unsigned (&o8)[2], unsigned add) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const u32x4 w = pair_fwd(__builtin_bit_cast(u32x2, t[2 * p]), __builtin_bit_cast(u32x2, t[2 * p + 1]));
-      __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(o8[p] + add), 0, EpiStoreAux<EPI>::value);
-    }
-  };
-
-  if constexpr (EPI == EPI_BF16) {
-    const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2);
-    const unsigned oc[2] = {off8(a.ldc, 2, 0), off8(a.ldc, 2, 1)}, cs = (unsigned)(16 * a.ldc * 2);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      GROUP_FENCE();
-      bf16x4 t[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[j][e] = f2bf(acc_rd<AGPR>(acc[i][J0 + j][e]) + bs[j][e]);
-      store_pairs(t, rsC, oc, i * cs);
-    }
-  } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF) {
-    const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsC2 = tile_rsrc(a.C2, a.ldc2, 2);
-    const unsigned oc[2] = {off8(a.ldc, 2, 0), off8(a.ldc, 2, 1)}, cs = (unsigned)(16 * a.ldc * 2);
-    const unsigned oc2[2] = {off8(a.ldc2, 2, 0), off8(a.ldc2, 2, 1)}, cs2 = (unsigned)(16 * a.ldc2 * 2);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      GROUP_FENCE();
-      bf16x4 pre[4], act[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pre[j][e] = f2bf(acc_rd<AGPR>(acc[i][J0 + j][e]) + bs[j][e]);
-          const float x = bf2f(pre[j][e]);
-          if constexpr (EPI == EPI_QGELU) act[j][e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
-          else if constexpr (EPI == EPI_GELU_ERF) act[j][e] = f2bf(gelu_erf_f(x));
-          else
-            act[j][e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
-        }
-      store_pairs(pre, rsC, oc, i * cs);     // empty descriptor when the pre-activation is not wanted
-      store_pairs(act, rsC2, oc2, i * cs2);
-    }
-  } else if constexpr (EPI == EPI_GATE_RES) {
-    // y = bf16(acc+bias); x_out = x_in + float(bf16(gate*y))   (sit.py:134-135 under bf16 autocast)
-    const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 4), rsR = tile_rsrc(a.R, a.ldr, 4), rsY = tile_rsrc(a.C2, a.ldc2, 2);
-    const long grows = (a.M + a.rows_per_gate - 1) / a.rows_per_gate;
-    const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(a.gate, ((grows - 1) * a.ldgate + a.N) * 2);
-    unsigned ocq[4], orq[4], ogq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ocq[j] = offq(a.ldc, 4, j);
-      orq[j] = offq(a.ldr, 4, j);
-      ogq[j] = cq + 16 * j < a.N ? (unsigned)((cq + 16 * j) * 2) : (unsigned)EPI_OOB;
-    }
-    const unsigned oy[2] = {off8(a.ldc2, 2, 0), off8(a.ldc2, 2, 1)};
-    const unsigned cs = (unsigned)(16 * a.ldc * 4), rs = (unsigned)(16 * a.ldr * 4), ys = (unsigned)(16 * a.ldc2 * 2);
-    // one gate row for the whole strip (SiT: rows_per_gate = T = the tile height): loaded once; otherwise per row group and lane
-    const int grow0 = (m0 + mw) / a.rows_per_gate;
-    const bool one = (m0 + mw) - grow0 * a.rows_per_gate + 16 * NI <= a.rows_per_gate;
-    f32x4 xin[NI][4];
-    auto fetch = [&](int i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xin[i][j] = ld_f32x4(rsR, (int)(orq[j] + i * rs));
-    };
-#pragma unroll
-    for (int i = 0; i < PF && i < NI; ++i) fetch(i);
-    bf16x4 gv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gv[j] = ld_bf16x4(rsG, ogq[j], one ? grow0 * (int)a.ldgate * 2 : 0);
-    auto body = [&](auto one_c) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        GROUP_FENCE();
-        if (i + PF < NI) fetch(i + PF);
-        bf16x4 gl[4];
-        if constexpr (!decltype(one_c)::value) {
-          const int gr = (m0 + rt + 16 * i) / a.rows_per_gate;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            gl[j] = ld_bf16x4(rsG, cq + 16 * j < a.N ? (unsigned)(((long)gr * a.ldgate + cq + 16 * j) * 2) : (unsigned)EPI_OOB);
-        }
-        bf16x4 y[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 xo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            y[j][e] = f2bf(acc_rd<AGPR>(acc[i][J0 + j][e]) + bs[j][e]);
-            const bf16 gg = decltype(one_c)::value ? gv[j][e] : gl[j][e];
-            xo[e] = xin[i][j][e] + bfround(bf2f(gg) * bf2f(y[j][e]));
-          }
-          st_f32x4<EpiStoreAux<EPI>::value>(xo, rsC, (int)(ocq[j] + i * cs));
-        }
-        store_pairs(y, rsY, oy, i * ys);      // empty descriptor when y is not wanted
-      }
-    };
-    if (one) body(std::true_type{});
-    else body(std::false_type{});
-  } else {  // EPI_DGELU / EPI_DSILU / EPI_RES_BF16
-    const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(a.C, a.ldc, 2), rsR = tile_rsrc(a.R, a.ldr, 2);
-    const unsigned oc[2] = {off8(a.ldc, 2, 0), off8(a.ldc, 2, 1)}, cs = (unsigned)(16 * a.ldc * 2);
-    const unsigned orr[2] = {off8(a.ldr, 2, 0), off8(a.ldr, 2, 1)}, rs = (unsigned)(16 * a.ldr * 2);
-    u32x4 pw[NI][2];
-    auto fetch = [&](int i) {
-#pragma unroll
-      for (int p = 0; p < 2; ++p) pw[i][p] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)(orr[p] + i * rs), 0, 0);
-    };
-    constexpr int PFD = 2 * PF;   // 8 registers per row group
-#pragma unroll
-    for (int i = 0; i < PFD && i < NI; ++i) fetch(i);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      GROUP_FENCE();
-      if (i + PFD < NI) fetch(i + PFD);
-      bf16x4 pre[4], o[4];
-      pair_inv(pw[i][0], pre[0], pre[1]);
-      pair_inv(pw[i][1], pre[2], pre[3]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float du = bfround(acc_rd<AGPR>(acc[i][J0 + j][e]) + bs[j][e]);
-          const float x = bf2f(pre[j][e]);
-          if constexpr (EPI == EPI_RES_BF16) o[j][e] = f2bf(du + x);   // bf16 residual stream (frozen encoder)
-          else o[j][e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
-        }
-      store_pairs(o, rsC, oc, i * cs);
-    }
-  }
-}
-
-#undef GROUP_FENCE
 
 // fp32-output epilogues (weight gradients, accumulating variants): plain pointers, guarded per row / column group.
 template <int EPI, int NI>

@@ -252,6 +252,14 @@ __global__ __launch_bounds__(64 * W * W, W == 2 ? 2 : 1) void gemm_f32_kernel(Ge
         C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + g * v;
       } break;
       case EPI_LS_RES: C[(long)m * a.ldc + n] = Rf[(long)m * a.ldr + n] + a.gate[n] * v; break;
+      case EPI_GELU_G: case EPI_SILU_G: {   // C carries the activation's derivative (fp32 here: no rounding), gemm.h
+        float av, gv;
+        if (epi == EPI_GELU_G) gelu_tanh_both(v, av, gv);
+        else silu_both(v, av, gv);
+        if (C) C[(long)m * a.ldc + n] = gv;
+        C2[(long)m * a.ldc2 + n] = av;
+      } break;
+      case EPI_MUL: C[(long)m * a.ldc + n] = v * Rf[(long)m * a.ldr + n]; break;
       case EPI_DGELU: C[(long)m * a.ldc + n] = v * gelu_tanh_grad_f(Rf[(long)m * a.ldr + n]); break;
       case EPI_DSILU: C[(long)m * a.ldc + n] = v * silu_grad_f(Rf[(long)m * a.ldr + n]); break;
       case EPI_RES_BF16: C[(long)m * a.ldc + n] = v + Rf[(long)m * a.ldr + n]; break;
@@ -358,7 +366,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
   else REED_CHECK_ARG(a.K % 4 == 0, "reed_gemm(NT/NN, fp32): K=%d must be a multiple of 4", a.K);
   switch (epi) {
     case EPI_BF16: case EPI_GELU: case EPI_SILU: case EPI_GATE_RES: case EPI_DGELU: case EPI_DSILU: case EPI_F32:
-    case EPI_ADDF32_RB: case EPI_ATOMIC_F32: case EPI_QGELU: case EPI_RES_BF16: case EPI_LS_RES: break;
+    case EPI_ADDF32_RB: case EPI_ATOMIC_F32: case EPI_QGELU: case EPI_RES_BF16: case EPI_LS_RES:
+    case EPI_GELU_G: case EPI_SILU_G: case EPI_MUL: break;
     default: reed_set_error("reed_gemm: unknown epilogue %d", epi); return REED_ERR_ARG;
   }
   if (splits < 1) splits = 1;

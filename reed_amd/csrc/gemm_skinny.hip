@@ -121,6 +121,7 @@ int launch_skinny(const GemmArgs& a, hipStream_t stream) {
 // NT, the row-free bf16 / fp32-residual epilogues of a frozen tower's forward, K a multiple of 64, N of 64, no split-K
 bool reed_gemm_skinny_eligible(int layout, int epi, const GemmArgs& a, int splits) {
   const bool epi_ok = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_QGELU || epi == EPI_GELU_ERF ||
+                      epi == EPI_GELU_G || epi == EPI_SILU_G ||
                       epi == EPI_RES_BF16 || epi == EPI_LS_RES || epi == EPI_GATE_RES;
   return layout == LAY_NT && epi_ok && splits <= 1 && a.K % SK == 0 && a.K >= SK && a.N % 64 == 0 && a.M >= 1 &&
          (long)cdiv(a.M, 16) * (a.N / 64) < (1l << 30);
@@ -131,6 +132,8 @@ int reed_gemm_skinny_launch(int epi, GemmArgs a, hipStream_t stream) {
     case EPI_BF16: return launch_skinny<EPI_BF16>(a, stream);
     case EPI_GELU: return launch_skinny<EPI_GELU>(a, stream);
     case EPI_SILU: return launch_skinny<EPI_SILU>(a, stream);
+    case EPI_GELU_G: return launch_skinny<EPI_GELU_G>(a, stream);
+    case EPI_SILU_G: return launch_skinny<EPI_SILU_G>(a, stream);
     case EPI_QGELU: return launch_skinny<EPI_QGELU>(a, stream);
     case EPI_GELU_ERF: return launch_skinny<EPI_GELU_ERF>(a, stream);
     case EPI_RES_BF16: return launch_skinny<EPI_RES_BF16>(a, stream);

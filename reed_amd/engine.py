@@ -17,7 +17,8 @@ import types
 import torch
 
 from . import ops
-from .ops import NT, NN, TN, EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB
+from .ops import (NT, NN, TN, EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB,
+                  EPI_GELU_G, EPI_SILU_G, EPI_MUL)
 
 
 class Engine:
@@ -43,7 +44,7 @@ class Engine:
         self.tap_depth = [model.encoder_depth if (zt == "i" or not split) else model.encoder_depth_text
                           for zt in model.z_types]
         self.reducer = None      # set by reed_amd.parallel.GradReducer
-        self._dot_delta = {}     # (tokens, operand type, reducing, forced tile) -> the dO GEMM has the head-dot epilogue
+        self._dot_delta = {}     # (tokens, operand type, reducing, forced tile, CU reserve, comm forms) -> the dO GEMM has the head-dot epilogue
         self._ws = None
         self._named = None       # [(name, parameter)] and the first trainable parameter, cached for backward
         self._sentinel = None
@@ -57,6 +58,11 @@ class Engine:
         self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
         self.table_rows = model.num_classes + (1 if model.class_dropout_prob > 0 else 0)
         self._hb = 2             # bytes per element of the current build's operand arrays (set per forward / backward)
+        # Round 5: the forward epilogues of fc1 / the t-MLP / the projector layers save the activation's DERIVATIVE at the
+        # pre-activation (in the array that used to hold the pre-activation: nothing but the backward's dGELU / dSiLU epilogue
+        # read it), so that backward epilogue is one multiply per element.  False: the pre-activation and the recomputing
+        # epilogues (the form the round-1..4 records were measured with; tests compare the two).
+        self.save_act_grad = os.environ.get("REED_SAVE_ACT_GRAD", "1") != "0"
         self._err = None         # sticky device flag: a label outside the embedding table was seen (see check_errors)
 
     def _check_dims(self, prec):
@@ -143,7 +149,10 @@ class Engine:
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
 
-        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x, prec=prec) if need_grad else None
+        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x, prec=prec, act_grad=self.save_act_grad) if need_grad else None
+        # epilogues of a layer whose saved array feeds the backward (gemm.h): derivative-saving forms when there is a backward
+        epi_silu = EPI_SILU_G if need_grad and self.save_act_grad else EPI_SILU
+        epi_gelu = EPI_GELU_G if need_grad and self.save_act_grad else EPI_GELU
         # -- embedders
         tok = f32(M, D)
         ops.patch_embed_fwd(x, self.W("x_embedder.proj.weight"), self.W("x_embedder.proj.bias"), self.Wf("pos_embed"),
@@ -152,7 +161,7 @@ class Engine:
         ops.timestep_sinusoid(t, sin, B)
         t1p = bf(B, D) if need_grad else None
         t1 = bf(B, D)
-        ops.gemm(NT, EPI_SILU, sin, self.W("t_embedder.mlp.0.weight"), B, D, 256, t1p, 256, 256, D, C2=t1, ldc2=D,
+        ops.gemm(NT, epi_silu, sin, self.W("t_embedder.mlp.0.weight"), B, D, 256, t1p, 256, 256, D, C2=t1, ldc2=D,
                  bias=self.W("t_embedder.mlp.0.bias"))
         temb = bf(B, D)
         ops.gemm(NT, EPI_BF16, t1, self.W("t_embedder.mlp.2.weight"), B, D, D, temb, D, D, D,
@@ -221,7 +230,7 @@ class Engine:
             ops.gemm(NT, EPI_GATE_RES, o, self.W(b + "attn.proj.weight"), M, D, D, xmid, D, D, D, C2=y1, ldc2=D,
                      R=xcur, ldr=D, bias=self.W(b + "attn.proj.bias"), gate=mb + 2 * hb * D, ldgate=Nall, rows_per_gate=T)
             ops.ln_modulate_fwd(xmid, mb + 3 * hb * D, mb + 4 * hb * D, Nall, h2, mean2, rstd2, M, D, T)
-            ops.gemm(NT, EPI_GELU, h2, self.W(b + "mlp.fc1.weight"), M, Hm, D, a1, D, D, Hm, C2=u, ldc2=Hm,
+            ops.gemm(NT, epi_gelu, h2, self.W(b + "mlp.fc1.weight"), M, Hm, D, a1, D, D, Hm, C2=u, ldc2=Hm,
                      bias=self.W(b + "mlp.fc1.bias"))
             ops.gemm(NT, EPI_GATE_RES, u, self.W(b + "mlp.fc2.weight"), M, D, Hm, xout, Hm, Hm, D, C2=y2, ldc2=D,
                      R=xmid, ldr=D, bias=self.W(b + "mlp.fc2.bias"), gate=mb + 5 * hb * D, ldgate=Nall, rows_per_gate=T)
@@ -278,11 +287,12 @@ class Engine:
         else:
             ops.token_mean_fwd(x, xin, B, T, D)
         pre = f"projectors.{j}."
+        epi_silu = EPI_SILU_G if need_grad and self.save_act_grad else EPI_SILU
         p1p, p1 = (bf(R, Pd) if need_grad else None), bf(R, Pd)
-        ops.gemm(NT, EPI_SILU, xin, self.W(pre + "0.weight"), R, Pd, D, p1p, D, D, Pd, C2=p1, ldc2=Pd,
+        ops.gemm(NT, epi_silu, xin, self.W(pre + "0.weight"), R, Pd, D, p1p, D, D, Pd, C2=p1, ldc2=Pd,
                  bias=self.W(pre + "0.bias"))
         p2p, p2 = (bf(R, Pd) if need_grad else None), bf(R, Pd)
-        ops.gemm(NT, EPI_SILU, p1, self.W(pre + "2.weight"), R, Pd, Pd, p2p, Pd, Pd, Pd, C2=p2, ldc2=Pd,
+        ops.gemm(NT, epi_silu, p1, self.W(pre + "2.weight"), R, Pd, Pd, p2p, Pd, Pd, Pd, C2=p2, ldc2=Pd,
                  bias=self.W(pre + "2.bias"))
         zt = bf(R, Z)
         ops.gemm(NT, EPI_BF16, p2, self.W(pre + "4.weight"), R, Z, Pd, zt, Pd, Pd, Z, bias=self.W(pre + "4.bias"))
@@ -381,7 +391,9 @@ class Engine:
         # keeps off the persistent kernels) and a forced tile — all in the key (a 1002 seen once under one of
         # them was remembered for the rest of the run under the token count alone).  With REED_ATTN_BWD / REED_ATTN_BWD_W4 set
         # (the A/B switches of the other backward kernels, honoured by reed_attention_bwd_ws only) the fused path is skipped.
-        dkey = (M, str(hdt), self.reducer is not None and self.reducer.active(), ops.gemm_forced_tile())
+        # (and the CU reserve and the forms-beside-collectives switch, which the tuner cycles under one token count)
+        dkey = (M, str(hdt), self.reducer is not None and self.reducer.active(), ops.gemm_forced_tile(), ops.cu_reserve(),
+                ops.comm_forms())
         ab = os.environ.get("REED_ATTN_BWD") is not None or os.environ.get("REED_ATTN_BWD_W4", "0") == "1"
         dot_delta = (self._dot_delta if os.environ.get("REED_ATTN_DP", "1") != "0" and hdt != torch.float32 and not ab
                      else {dkey: False})
@@ -500,7 +512,7 @@ class Engine:
             else:
                 self._wgrad(dy2, bk.u, b + "mlp.fc2.weight", M, D, Hm, acc, dev, side=side)
             da1 = bf(M, Hm)
-            self._dgrad(EPI_DGELU, dy2, b + "mlp.fc2.weight", M, D, Hm, da1, R=bk.a1, ldr=Hm)
+            self._dgrad(EPI_MUL if tp.act_grad else EPI_DGELU, dy2, b + "mlp.fc2.weight", M, D, Hm, da1, R=bk.a1, ldr=Hm)
             if wg is not None:
                 wg.append((da1, bk.h2, b + "mlp.fc1.weight", Hm, D))
             else:
@@ -598,7 +610,7 @@ class Engine:
         ops.linear_wgrad(dtemb, tp.t1, self.G("t_embedder.mlp.2.weight"), dbias=self.G("t_embedder.mlp.2.bias"),
                          accumulate=acc, Mtok=B, N=D, K=D)
         dt1 = bf(B, D)
-        ops.gemm(NN, EPI_DSILU, dtemb, self.W("t_embedder.mlp.2.weight"), B, D, D, dt1, D, D, D, R=tp.t1p, ldr=D)
+        ops.gemm(NN, EPI_MUL if tp.act_grad else EPI_DSILU, dtemb, self.W("t_embedder.mlp.2.weight"), B, D, D, dt1, D, D, D, R=tp.t1p, ldr=D)
         ops.linear_wgrad(dt1, tp.sin, self.G("t_embedder.mlp.0.weight"), dbias=self.G("t_embedder.mlp.0.bias"),
                          accumulate=acc, Mtok=B, N=D, K=256)
         # -- patch embed: dW[d,k] = sum_tokens bf16(dx)[token,d] * patch[token,k]
@@ -641,10 +653,11 @@ class Engine:
         bf = lambda *s: torch.empty(s, dtype=hdt, device=dev)  # noqa: E731
         self._wgrad(dz, pj.p2, pre + "4.weight", R, Z, Pd, acc, dev)
         d2 = bf(R, Pd)
-        ops.gemm(NN, EPI_DSILU, dz, self.W(pre + "4.weight"), R, Pd, Z, d2, Z, Pd, Pd, R=pj.p2p, ldr=Pd)
+        epi_dsilu = EPI_MUL if tp.act_grad else EPI_DSILU
+        ops.gemm(NN, epi_dsilu, dz, self.W(pre + "4.weight"), R, Pd, Z, d2, Z, Pd, Pd, R=pj.p2p, ldr=Pd)
         self._wgrad(d2, pj.p1, pre + "2.weight", R, Pd, Pd, acc, dev)
         d1 = bf(R, Pd)
-        ops.gemm(NN, EPI_DSILU, d2, self.W(pre + "2.weight"), R, Pd, Pd, d1, Pd, Pd, Pd, R=pj.p1p, ldr=Pd)
+        ops.gemm(NN, epi_dsilu, d2, self.W(pre + "2.weight"), R, Pd, Pd, d1, Pd, Pd, Pd, R=pj.p1p, ldr=Pd)
         self._wgrad(d1, pj.xin, pre + "0.weight", R, Pd, D, acc, dev)
         if m.z_types[j] == "i":
             ops.gemm(NN, EPI_ADDF32_RB, d1, self.W(pre + "0.weight"), R, D, Pd, dx, Pd, D, D)

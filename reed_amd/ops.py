@@ -15,7 +15,7 @@ from . import _lib
 NT, NN, TN = 0, 1, 2
 TN_TALL, TN_WIDE = 3, 4   # TN on the 256x128 / 128x256 tile of csrc/gemm_tn.hip (weight gradients)
 (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_ADDF32_RB, EPI_ATOMIC_F32, EPI_QGELU,
- EPI_RES_BF16, EPI_GELU_ERF, EPI_LS_RES, EPI_BF16_DOT) = range(14)
+ EPI_RES_BF16, EPI_GELU_ERF, EPI_LS_RES, EPI_BF16_DOT, EPI_GELU_G, EPI_SILU_G, EPI_MUL) = range(17)
 
 
 def _p(t):
@@ -165,7 +165,7 @@ def gemm_forced_tile():
 
 def gemm_force_tile(tile):
     """0 = heuristic; 128 / 256 (eight waves) / 257 (four 128x128 waves, one tile per workgroup) / 258 (the same, persistent
-    form wherever it applies) / 144 / 129 (128x256 tiles, two workgroups per CU: csrc/gemm128c.hip) = force that GEMM kernel
+    form wherever it applies) / 144 / 64 (the skinny one-wave tiles) = force that GEMM kernel
     where it applies (tests and A/B timing).  Set in both builds of the library."""
     global _FORCED_TILE
     _FORCED_TILE = int(tile)
@@ -201,6 +201,10 @@ def set_comm_forms(on):
 
 def comm_forms():
     return _COMM_FORMS
+
+
+def cu_reserve():
+    return _CU_RESERVE
 
 
 def set_concurrent_comm(on):

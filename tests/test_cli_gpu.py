@@ -604,6 +604,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and rf["launches_timed"] == 3 * 28
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
     assert "cpu_baseline" not in d      # --no-cpu-baseline; the default run adds {"value", "unit", "cores", "kind", "sample"}
+    # BASELINE.json's second number: the C2 fixture's 5 injected steps on the HIP path against the reference's recorded losses
+    lv = d["loss_vs_ref"]
+    assert "error" not in lv, lv
+    assert lv["steps"] == 5 and lv["bar"] == 1e-3 and lv["within_bar"] is True and lv["max_abs_delta_bf16"] <= 1e-3, lv
+    assert len(lv["hip_loss"]) == 5 and len(lv["reference_bf16_autocast_loss"]) == 5
 
 
 def test_bench_stdout_is_one_line_under_a_reducer(dev):

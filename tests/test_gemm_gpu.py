@@ -8,12 +8,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 128, 256, 144, 257, 258, 129, 64], autouse=True)
+@pytest.fixture(params=[0, 128, 256, 144, 257, 258, 64], autouse=True)
 def force_tile(request):
     """Run every GEMM test with the tile heuristic and with each kernel forced (128^2 2-stage, 256^2 pipelined with eight
     waves, 256x144 ring — only NT / NN shapes whose N is a multiple of 144 —, 257 = the 256^2 tile with four 128x128 waves —
-    NT / NN with K >= 128 and the epilogues it builds —, 129 = the 128x256 tile of two workgroups per CU (csrc/gemm128c.hip: NT
-    plain / GELU / gate + residual, NN plain / dGELU), 64 = the skinny kernel of 16 x 64 one-wave tiles (csrc/gemm_skinny.hip: NT,
+    NT / NN with K >= 128 and the epilogues it builds —, 64 = the skinny kernel of 16 x 64 one-wave tiles (csrc/gemm_skinny.hip: NT,
     the tail launch of the ragged-M split); what a kernel does not take falls to the heuristic)."""
     from reed_amd import ops
     ops.gemm_force_tile(request.param)
@@ -74,6 +73,20 @@ def test_epilogues(dev, N):
         ops.linear_fwd(x, w, b, pre, epi=epi, act_out=act)
         torch.testing.assert_close(pre.float(), pre_ref.float(), atol=2e-2, rtol=2e-2)
         torch.testing.assert_close(act.float(), _bf(fn(pre.float())).float(), atol=1e-2, rtol=1e-2)
+    # the derivative-saving forms (round 5): the same activation bit for bit, and act'(pre) where the pre-activation was
+    for epi, epi_g, fn in ((ops.EPI_GELU, ops.EPI_GELU_G, _gelu), (ops.EPI_SILU, ops.EPI_SILU_G, torch.nn.functional.silu)):
+        pre = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        act, act_g, der = torch.zeros_like(pre), torch.zeros_like(pre), torch.zeros_like(pre)
+        ops.linear_fwd(x, w, b, pre, epi=epi, act_out=act)
+        ops.linear_fwd(x, w, b, der, epi=epi_g, act_out=act_g)
+        assert torch.equal(act, act_g)
+        p32 = pre.float().requires_grad_(True)
+        fn(p32).sum().backward()
+        torch.testing.assert_close(der.float(), _bf(p32.grad).float(), atol=2 ** -7, rtol=2 ** -7)   # one bf16 ulp of a value <= 1.13
+        # without the saved array (an inference forward): activation only
+        act_n = torch.zeros_like(pre)
+        ops.linear_fwd(x, w, b, None, epi=epi_g, act_out=act_n, M=M, N=N, K=K, ldx=K, ldw=K, ldo=N)
+        assert torch.equal(act, act_n)
     # gate + residual
     gate = _bf(torch.randn(M // T, 3 * N, generator=g)).to(dev)
     xin = torch.randn(M, N, generator=g).to(dev)
@@ -106,6 +119,16 @@ def test_nn_dgrad(dev, M, N, K):
     p32 = pre.float().requires_grad_(True)
     _gelu(p32).backward(_bf(ref).float())
     torch.testing.assert_close(dx2.float(), p32.grad, atol=3e-2, rtol=3e-2)
+    # the one-multiply form (round 5): exact against its definition bf16(bf16(acc) * R), and — fed the rounded derivative the
+    # forward's EPI_GELU_G saves — within one bf16 rounding of the factor of the recomputing epilogue above
+    dx3 = torch.zeros_like(dx)
+    ops.linear_dgrad(dy, w, dx3, epi=ops.EPI_MUL, R=pre)
+    assert torch.equal(dx3, _bf(dx.float() * pre.float()))
+    q32 = pre.float().requires_grad_(True)
+    _gelu(q32).sum().backward()
+    der = _bf(q32.grad)
+    ops.linear_dgrad(dy, w, dx3, epi=ops.EPI_MUL, R=der)
+    torch.testing.assert_close(dx3.float(), dx2.float(), atol=2 ** -7 * dx2.float().abs().max().item(), rtol=2 ** -6)
 
 
 def test_nn_asymmetric(dev):
@@ -346,14 +369,14 @@ def test_many_tiles(dev, lay, M, N, K):
             ops.gemm(ops.NN, ops.EPI_BF16, x, wq, M, N, K, out, K, N, N, bias=b)
         return out
 
-    o128, o256, o257, o258, o129, o64 = run(128), run(256), run(257), run(258), run(129), run(64)
+    o128, o256, o257, o258, o64 = run(128), run(256), run(257), run(258), run(64)
     ops.gemm_force_tile(0)
     assert torch.isnan(o64[M]).all() and torch.equal(o64[:M], o256[:M])   # the one-wave 16 x 64 tiles (NT): the same bits
     assert torch.isnan(o128[M]).all() and torch.isnan(o256[M]).all()       # nothing written past row M-1
-    assert torch.isnan(o257[M]).all() and torch.isnan(o258[M]).all() and torch.isnan(o129[M]).all()
+    assert torch.isnan(o257[M]).all() and torch.isnan(o258[M]).all()
     # four 128x128 waves, one tile per workgroup / the persistent walk over the tile list / 128x256 tiles, two workgroups per
     # CU: the same bits
-    assert torch.equal(o257[:M], o256[:M]) and torch.equal(o258[:M], o256[:M]) and torch.equal(o129[:M], o256[:M])
+    assert torch.equal(o257[:M], o256[:M]) and torch.equal(o258[:M], o256[:M])
     ref = x.float() @ w.float().t() + b.float()
     err = (o256[:M].float() - ref).abs().max().item()
     assert err <= ref.abs().max().item() * 2 ** -7, err

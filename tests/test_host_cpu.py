@@ -612,3 +612,27 @@ def test_counted_waits_of_the_attention_forward_match_the_isa():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r4", "check_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("ok  ") >= 9 and "BAD" not in r.stdout, r.stdout
+
+
+def test_detfill_matches_the_fixture_recipe():
+    """reed_amd/detfill.py (what bench.py's loss_vs_ref leg rebuilds the C2 fixture's weights and inputs with; the product imports
+    nothing of oracle/) is the recipe the fixtures were written with (oracle/detfill.py, tools/gen_golden.py:inputs) bit for bit."""
+    import torch
+    from oracle import detfill as od
+    from reed_amd import detfill as pd
+    from tests.test_oracle_golden import inputs
+    for shape, seed in (((7,), 3), ((4, 5, 6), 12345), ((2, 256, 32), 6017)):
+        assert torch.equal(od.uniform(shape, seed, -0.3, 0.7), pd.uniform(shape, seed, -0.3, 0.7))
+        assert torch.equal(od.normal(shape, seed), pd.normal(shape, seed))
+    names = {"pos_embed": (1, 4, 8), "blocks.0.attn.qkv.weight": (24, 8), "blocks.0.attn.qkv.bias": (24,),
+             "blocks.1.adaLN_modulation.1.weight": (48, 8), "final_layer.linear.weight": (16, 8),
+             "y_embedder.embedding_table.weight": (11, 8), "blocks.0.attn.q_norm.weight": (4,), "x_embedder.proj.weight": (8, 4, 2, 2)}
+    a = od.fill_state_dict({k: torch.zeros(v) for k, v in names.items()}, base_seed=5)
+    b = pd.fill_model({k: torch.zeros(v) for k, v in names.items()}, base_seed=5)
+    for k in names:
+        assert torch.equal(a[k], b[k]), k
+    ra = inputs(3, 4, 32, 2, [(64, "i")], 256, 1000)
+    rb = pd.step_inputs(3, 2, [64])
+    for u, v in zip(ra[:5], rb[:5]):
+        assert torch.equal(u, v)
+    assert torch.equal(ra[5][0], rb[5][0])

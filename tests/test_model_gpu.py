@@ -409,6 +409,47 @@ def test_wgrad_side_stream_bit_identical(dev):
     assert torch.equal(grads[False], grads[True])
 
 
+def test_saved_activation_derivative_vs_recomputing_backward(dev):
+    """Round 5: the fc1 / t-MLP / projector forward epilogues save act'(pre) (bf16) where the pre-activation used to be saved
+    and the backward multiplies by it (gemm.h EPI_GELU_G / EPI_SILU_G / EPI_MUL) instead of recomputing the derivative from the
+    pre-activation (EPI_DGELU / EPI_DSILU).  Same forward bit for bit; the backward differs by ONE extra bf16 rounding of one
+    factor (the derivative), i.e. 2^-9 relative per element of d(pre), uncorrelated: every gradient tensor stays within
+    cosine 0.99999 / 1e-3 in norm of the recomputing form (both forms are held to the oracle bars by the tests above)."""
+    from reed_amd.loss import SILoss
+    c = TINY_CASES["xl3"]
+    cfg = c["cfg"]
+    T = (cfg["input_size"] // cfg["patch_size"]) ** 2
+    x, noise, t, y, drop_u, zs = inputs(4, 4, cfg["input_size"], 5, c["zspec"], T, cfg["num_classes"])
+    drop = drop_u < cfg["class_dropout_prob"]
+    grads, losses = {}, {}
+    for mode in (False, True):
+        m = build_hip_model(cfg, dev, 5)
+        m.train()
+        m.force_drop_mask = drop
+        m.engine().save_act_grad = mode
+        lf = SILoss(enc_names=c["enc"], loss_weights=dict(zip(c["enc"], c["co"])))
+        out = lf(m, x.to(dev), dict(y=y.to(dev)), zs=[z.to(dev) for z in zs], time_input=t, noises=noise)
+        tot = out["denoising_loss"].mean() + 0.5 * out["proj_loss"]
+        tot.backward()
+        torch.cuda.synchronize()
+        losses[mode] = tot.detach().clone()
+        grads[mode] = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.requires_grad}
+    assert torch.equal(losses[False], losses[True])
+    worst = [1.0, "", 0.0, ""]
+    for k, g0 in grads[False].items():
+        g1 = grads[True][k]
+        n0 = g0.norm().item()
+        if n0 < 5e-5:
+            continue
+        cs, dn = cos(g0, g1), abs(g1.norm().item() / n0 - 1)
+        if cs < worst[0]:
+            worst[0:2] = [cs, k]
+        if dn > worst[2]:
+            worst[2:4] = [dn, k]
+    print(f"[act-grad] worst cosine {worst[0]:.7f} ({worst[1]}), worst |norm ratio - 1| {worst[2]:.6f} ({worst[3]})")
+    assert worst[0] > 0.99999 and worst[2] < 1e-3, worst
+
+
 def test_overlapped_optimizer_bit_identical(dev):
     """FusedAdamWEMA(overlap=True): per-bucket update launches on the optimiser's own stream with the next forward
     waiting per bucket. Same arithmetic, different schedule -> master weights, EMA and the bf16 shadow after 4 steps
