@@ -49,9 +49,35 @@ def parse(argv=None):
     ap.add_argument("--no-vae-leg", action="store_true", help="skip the SD-VAE decode leg (SURVEY.md N4) the N = 1 run appends")
     ap.add_argument("--no-loss-vs-ref", action="store_true", help="skip the loss-vs-reference leg (the C2 fixture's 5 injected steps) the N = 1 run appends")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the b = 32 per-GPU leg (the 8-GPU shape) the N = 1 run appends")
-    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("REED_BENCH_LAUNCH_TIMEOUT", "2400")),
+    ap.add_argument("--launch-timeout", type=float, default=2400.0,
                     help="seconds the self-launcher lets its ranks run before it ends them (a hung collective must not hang the caller)")
+    ap.add_argument("--tuned-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the second timed region (the tuned plan) may take before the plain-plan record is printed instead")
+    ap.add_argument("--plain-file", type=str, default=None, help=argparse.SUPPRESS)        # launcher -> rank 0: where to leave the plain record
+    ap.add_argument("--test-tuner-fail", choices=["hang", "raise"], default=None, help=argparse.SUPPRESS)   # tests: a tuner that fails on first contact
     return ap.parse_args(argv)
+
+
+# Every run-time switch of the package (DESIGN.md §4 "Switches"); anything else that starts with REED_ is a typo or a switch of an
+# older round, and a bench record measured under a plan nobody asked for is worse than no record: main() refuses to run.
+KNOWN_ENV = {
+    "REED_HIP_LIB",          # _lib.py: another build of the library (same-box A/B)
+    "REED_WGRAD_W4",         # csrc/gemm256w.hip: 0 = gemm_tn.hip's grouped weight gradients everywhere, 1 = the four-wave form beside collectives too
+    "REED_WGRAD_GROUP",      # ops.py: 0 = per-GEMM split-K weight gradients (the plan the goldens pin)
+    "REED_WGRAD_STREAM",     # engine.py: 0 / 1 / auto — the weight gradients on a second stream
+    "REED_OPT_OVERLAP",      # optim.py: 0 = the optimiser pass on the main stream
+    "REED_COMM", "REED_COMM_ALGO", "REED_COMM_CUS", "REED_COMM_FORMS", "REED_ADA_GATHER", "REED_OPT_SHARD",   # the N > 1 plan (parallel.py, trainer.py)
+    "REED_FORCE_REDUCER",    # the N > 1 code path at world 1
+    "REED_BENCH_REHEARSE",   # bench.py: gloo rehearsal of an N > 1 run on fewer GPUs
+    "REED_BENCH_TUNED",      # bench.py: 0 = no second (tuned) timed region
+    "REED_ATTN_FWD_DBG", "REED_ATTN_KSP_DBG",   # diagnosis builds of csrc/attention.hip only (-DREED_ATTN_DIAG)
+}
+
+
+def check_env():
+    bad = sorted(k for k in os.environ if k.startswith("REED_") and k not in KNOWN_ENV)
+    if bad:
+        raise SystemExit(f"bench.py: unknown switch(es) in the environment: {', '.join(bad)} (known: {', '.join(sorted(KNOWN_ENV))})")
 
 
 def launcher_argv(args, argv, port):
@@ -91,8 +117,7 @@ def self_launch(args, argv):
     # be abandoned (a tuner that hangs on first contact with RCCL and takes the in-process watchdog with it), this parent —
     # which never touched the GPU — ends the group and still prints that record
     plain_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"reed_bench_plain.{os.getpid()}.json")
-    env["REED_BENCH_PLAIN_FILE"] = plain_file
-    cmd = launcher_argv(args, argv, _free_port())
+    cmd = launcher_argv(args, list(argv) + ["--plain-file", plain_file], _free_port())
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)
     timed_out = False
     try:
@@ -169,13 +194,15 @@ except Exception:
     pass
 
 
-def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
+def time_gemms(b, D=1152, Hm=4608, T=256, iters=8, act_grad=True):
     """Per-shape timing of the block GEMMs through the SAME entry points and kernel-selection logic the engine uses
     (events on the launch stream): forward NT with fused epilogues, dgrad NN on the weight shadow, wgrad TN through
     ops.plan_wgrad (wave-quantised split-K slabs + deterministic reduce, bias gradient fused as a ones-MFMA)."""
     from reed_amd import ops
     dev = torch.device("cuda")
     M = b * T
+    # the epilogues the step uses (engine.save_act_grad, round 5): fc1 saves GELU'(pre) and the fc2 dgrad multiplies by it
+    epi_gelu, epi_dgelu = (ops.EPI_GELU_G, ops.EPI_MUL) if act_grad else (ops.EPI_GELU, ops.EPI_DGELU)
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.05).to(torch.bfloat16)  # noqa: E731
     x, w_qkv, w_proj, w1, w2 = bf(M, D), bf(3 * D, D), bf(D, D), bf(Hm, D), bf(D, Hm)
     big, big2 = bf(M, Hm), bf(M, Hm)
@@ -199,9 +226,9 @@ def time_gemms(b, D=1152, Hm=4608, T=256, iters=8):
     cases = [
         ("fwd qkv  NT bias", 2.0 * M * 3 * D * D, lambda: ops.linear_fwd(x, w_qkv, bias[:3 * D], o3)),
         ("fwd proj NT gate+res", 2.0 * M * D * D, lambda: ops.linear_fwd(x, w_proj, bias[:D], xo, epi=ops.EPI_GATE_RES, R=xi, gate=gate, ldgate=6 * D, rows_per_gate=T, y_out=ybuf)),
-        ("fwd fc1  NT gelu", 2.0 * M * Hm * D, lambda: ops.linear_fwd(x, w1, bias, big, epi=ops.EPI_GELU, act_out=big2)),
+        ("fwd fc1  NT gelu", 2.0 * M * Hm * D, lambda: ops.linear_fwd(x, w1, bias, big, epi=epi_gelu, act_out=big2)),
         ("fwd fc2  NT gate+res", 2.0 * M * Hm * D, lambda: ops.linear_fwd(big, w2, bias[:D], xo, epi=ops.EPI_GATE_RES, R=xi, gate=gate, ldgate=6 * D, rows_per_gate=T, y_out=ybuf)),
-        ("dgrad fc2 NN dgelu", 2.0 * M * Hm * D, lambda: dgrad(ops.EPI_DGELU, x, w2, D, Hm, big, R=big2, ldr=Hm)),
+        ("dgrad fc2 NN dgelu", 2.0 * M * Hm * D, lambda: dgrad(epi_dgelu, x, w2, D, Hm, big, R=big2, ldr=Hm)),
         ("dgrad fc1 NN", 2.0 * M * Hm * D, lambda: dgrad(ops.EPI_BF16, big, w1, Hm, D, ybuf)),
         ("dgrad proj NN", 2.0 * M * D * D, lambda: dgrad(ops.EPI_BF16, x, w_proj, D, D, ybuf)),
         ("dgrad qkv NN", 2.0 * M * 3 * D * D, lambda: dgrad(ops.EPI_BF16, o3, w_qkv, 3 * D, D, ybuf)),
@@ -499,6 +526,7 @@ def n4_vae_leg(dev, batch=8, reps=3):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    check_env()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
     # stdout carries exactly ONE line, the JSON record: C libraries write there too (RCCL prints a version banner on stdout
@@ -584,13 +612,6 @@ def main():
             return 2.0 * tokens * sum(n * k for n, k in shapes)
         return None
 
-    # REED_MAIN_PRIO=1 (experiment): run the steps on a high-priority stream (the device has two levels; the optimiser's and the
-    # weight-gradient side streams stay at the default level)
-    if os.environ.get("REED_MAIN_PRIO", "0") == "1":
-        hp = torch.cuda.Stream(device=dev, priority=-1)
-        hp.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(hp)
-
     def timed_region(n_warm):
         """n_warm untimed steps, then EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over ranks."""
         res = None
@@ -665,6 +686,7 @@ def main():
                 rec = base_record(plain)
                 rec["plans"] = dict(plans, tuned=plans.get("tuned") or {"error": f"timeout in: {wd_state['phase']}"})
                 rec["plan_in_value"] = "plain"
+                rec["watchdog_fired"] = wd_state["phase"]
                 emit(rec)
                 wd_state["printed"] = True
             print(f"[bench.py] rank {rank}: watchdog fired in: {wd_state['phase']} - leaving", file=sys.stderr, flush=True)
@@ -672,29 +694,33 @@ def main():
 
     watchdog = None
     if use_dist:
-        if rank == 0 and os.environ.get("REED_BENCH_PLAIN_FILE"):
+        if rank == 0 and args.plain_file:
             try:
                 rec = base_record(plain)
                 rec["plans"], rec["plan_in_value"] = dict(plans), "plain"
-                with open(os.environ["REED_BENCH_PLAIN_FILE"], "w") as f:
+                with open(args.plain_file, "w") as f:
                     json.dump(rec, f)
             except OSError:
                 pass
-        watchdog = threading.Timer(float(os.environ.get("REED_BENCH_TUNED_TIMEOUT", "300")), wd_fire)
+    if want_tuned:
+        # the watchdog bounds the tuned region only: armed here, cancelled when that region has returned
+        watchdog = threading.Timer(args.tuned_timeout, wd_fire)
         watchdog.daemon = True
         watchdog.start()
-    if want_tuned:
         try:
-            fail = os.environ.get("REED_TEST_TUNER_FAIL", "")   # tests: a tuner that hangs / raises on first contact
+            fail = args.test_tuner_fail or ""   # tests: a tuner that hangs / raises on first contact
             step.plan_tuning("auto", "auto" if world > 1 else None, None)
             if fail == "hang":
                 while True:
                     time.sleep(1.0)
             if fail == "raise":
-                raise RuntimeError("REED_TEST_TUNER_FAIL=raise")
+                raise RuntimeError("--test-tuner-fail raise")
             tuned = timed_region(step.tune_steps_left() + 1)
+            watchdog.cancel()
             plans["tuned"] = plan_record(tuned, plan_of_step())
-            if tuned["dt"] < plain["dt"]:
+            # `value` is the plain region unless the tuner kept a DIFFERENT plan and that plan measured faster: two regions of one
+            # plan are two samples of it, and their maximum would bias the number upwards
+            if plans["tuned"]["plan"] != plans["plain"]["plan"] and tuned["dt"] < plain["dt"]:
                 chosen = tuned
         except Exception as e:   # the plain record stands; the ranks may no longer agree on anything: leave without collectives
             plans["tuned"] = {"error": repr(e)}
@@ -722,7 +748,7 @@ def main():
           "cu_reserve": step.cu_reserve, "cu_reserve_tuning_ms": step.cu_tuning, "comm_forms": getattr(step, "comm_forms", True), "algo_in_use": getattr(reducer, "algo", None),
           "tune_error": step.tune_error, "optimizer_sharded": bool(getattr(opt, "_shard", False)),
           "optimizer_shard_tuning": step.shard_tuning,
-          "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_COMM", "REED_ADA", "REED_GEMM_CUS", "REED_WGRAD", "NCCL_", "RCCL_"))}}
+          "env": {k: v for k, v in os.environ.items() if k.startswith(("REED_", "NCCL_", "RCCL_"))}}
     if reducer is not None:
         try:
             dp.update(dp_consistency(reducer, opt, model, world, b))
@@ -763,7 +789,7 @@ def main():
         # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region (with or without the
         # isolated kernel table, which only supplies the stand-in when the grouped launch did not run)
         n_l = sum(len(v) for v in dom.values())
-        rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm) if not args.no_kernel_table else None
+        rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm, act_grad=model.engine().save_act_grad) if not args.no_kernel_table else None
         if n_l or rows is not None:
             if n_l:
                 tot_ms = sum(sum(v) for v in dom.values())
@@ -802,7 +828,9 @@ def main():
             # the GEMM family launched in ISOLATION after the timed region (12 shapes of one block, time-weighted): an upper
             # view of the kernels, not the step — the step's efficiency is step_mfma_frac
             out["gemm_family_isolated"] = {"tflops": round(agg, 1), "frac": round(agg * 1e12 / PEAK_BF16, 4),
-                                           "ms_per_block": round(tot, 4), "table": rows}
+                                           "ms_per_block": round(tot, 4), "table": rows,
+                                           "activation_backward": "saved derivative (fc1 epilogue 14, fc2 dgrad epilogue 16)"
+                                           if model.engine().save_act_grad else "recomputed (epilogues 1 / 4)"}
         if world == 1 and not args.no_c3_leg and b != 32 and args.model == "SiT-XL/2":
             try:
                 out["c3_per_gpu_leg"] = c3_leg(step, dev, args.z_dim)

@@ -7,12 +7,20 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# REED_HIP_LIB: same-box A/B of two builds of the library (tools/); the product loads the in-tree one
+# REED_HIP_LIB=<path of another build's libreed_hip.so>: same-box A/B of two builds of the library (tools/ab_lib.sh); its
+# siblings <stem>_f16.so / <stem>_f32.so are taken where they exist.  The product loads the in-tree libraries.
 LIB_PATH = os.environ.get("REED_HIP_LIB") or os.path.join(_HERE, "libreed_hip.so")
+
+
+def _sibling(suffix):
+    alt = LIB_PATH[:-3] + suffix + ".so" if LIB_PATH.endswith(".so") else ""
+    return alt if alt and os.path.exists(alt) else os.path.join(_HERE, "libreed_hip" + suffix + ".so")
+
+
 # the same sources built with IEEE-half operands (csrc/common.hpp, -DREED_FP16): the sampling path
-LIB_PATH_F16 = os.environ.get("REED_HIP_LIB_F16") or os.path.join(_HERE, "libreed_hip_f16.so")
+LIB_PATH_F16 = _sibling("_f16")
 # the fp32-operand build (-DREED_FP32): --mixed-precision no / generate.py --no-tf32
-LIB_PATH_F32 = os.environ.get("REED_HIP_LIB_F32") or os.path.join(_HERE, "libreed_hip_f32.so")
+LIB_PATH_F32 = _sibling("_f32")
 PRECISIONS = ("bf16", "fp16", "fp32")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "reed_hip.h")
 

@@ -13,9 +13,12 @@
 // head_dim 72 is handled on chip: the third k-step (cols 64..95) uses zeroed register fragments
 // for the padded slots; the output's fifth 16-column tile is computed and only cols 64..71 stored.
 //
-// Backward recomputes P from the saved log-sum-exp and is split in two deterministic phases inside
-// one workgroup (no atomics): phase 1 gives each wave 32 query rows (dQ), phase 2 gives each wave
-// 32 key rows (dK, dV); Q, K, V, dO stay resident in LDS (147 KiB) for both.
+// Backward recomputes P from the saved log-sum-exp, key-stationary (a wave owns 32 keys: dK / dV in registers, S and dP
+// once) with dQ^T = K^T dS^T formed every 64 queries through an LDS tile of dS^T; deterministic, no atomics.  Kernels in
+// this file: attn_fwd_kernel (any T) + attn_fwd_rows_kernel (a <= 16-row tail), attn_fwd256p_kernel (T <= 256, persistent:
+// the engine's forward), attn_bwd_ks_kernel (one shot), attn_bwd_ksp_kernel (persistent, T < 256), attn_bwd_ring_kernel
+// (persistent with Q / dO rings, T = 256: the engine's backward).  Forms that were measured and removed are named where
+// they stood (round 2's three-barrier forward, round 1's two-phase backward, the half-workgroup stagger).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -152,7 +155,7 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
 
 // ------------------------------------------------------------------------------------------
 // Forward for any T (512^2 sampling: T = 1024; the CLIP tower: T = 257): 256-key tiles with online softmax, one
-// workgroup per (batch, head, 256-query block), register-staged tile loads.  T <= 256 runs attn_fwd256_kernel below.
+// workgroup per (batch, head, 256-query block), register-staged tile loads.  T <= 256 runs attn_fwd256p_kernel below.
 template <int HD>
 __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, int B, int T, int H) {
@@ -479,221 +482,10 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward for T <= 256 (training and 256^2 sampling: the whole sequence is ONE key tile).
-//
-// The one-shot kernel below (attn_fwd_kernel: load K, V, Q -> compute -> store, two workgroups per CU) spent 182 of its
-// 249 us at b = 256 in loads and stores that nothing overlapped, and its online softmax carried a rescale of O per
-// 64-key block.  This kernel is persistent — one 8-wave workgroup per CU walks (batch, head) items — and splits an item
-// in three phases whose LDS buffers are refilled by LDS-DMA while the other phases run:
-//   S  = K Q^T for all 256 keys into registers (st[2][16]: a wave's 32 queries x 256 keys = 128 VGPRs; two waves per
-//        SIMD own 256 VGPRs each)                                        reads K, Q   -> then K(n+1), Q(n+1) are issued
-//   softmax, exact and single pass (row maximum over the registers, no running rescale)   registers only
-//   O^T = V^T P^T                                                         reads V     -> then V(n+1) is issued
-// so the K / Q stream of the next item flies under softmax + PV + the output stores and the V stream under the next S
-// phase.  Every vector-memory instruction a wave issues per item is counted (5 LDS-DMA per tile, 5 + 2 buffer stores),
-// and the two waits are counted s_waitcnt vmcnt(N) behind raw barriers: nothing drains the queue.
-// LDS: K | V | Q tiles of 160-byte rows + a 32-row output staging patch per wave = 4 x 40 KiB = all 160 KiB.
-template <int HD>
-__global__ __launch_bounds__(512, 2) void attn_fwd256_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                            float* __restrict__ lse, int T, int H, int nitems) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
-  const int tid = threadIdx.x;
-  const int lane0 = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = H * HD;
-  const long tok = 3l * D;
-  const int tokb = (int)(tok * 2);
-  char* Kt = smem;
-  char* Vt = smem + TILE_F;
-  char* Qt = smem + 2 * TILE_F;
-  char* Ot = smem + 3 * TILE_F + wave * 32 * ROWF;
-  const int q0 = wave * 32;
-  const float sc2 = rsqrtf((float)HD) * LOG2E;
-  int voff[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) voff[j] = dma_voff<HD, ROWF>((wave * 5 + j) * 64 + lane0, tokb);
-  const long win = tile_window<HD>(T, tokb);
-  auto issue = [&](char* tile, const bf16* base) {
-    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(base, win);
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + (wave * 5 + j) * 1024), 16, voff[j], 0, 0, REED_ATTN_LD_AUX);
-  };
-  auto base_of = [&](int item) {
-    const int b = item / H, h = item - b * H;
-    return qkv + (long)b * T * tok + h * HD;
-  };
-  int it = xcd_contiguous(blockIdx.x, gridDim.x);   // the 16 heads of a sample run on one XCD at about the same time
-  {
-    const bf16* bs = base_of(it);
-    issue(Kt, bs + D);
-    issue(Qt, bs);
-    issue(Vt, bs + 2 * D);
-  }
-  bool first = true;
-  const int nsub = (T + 63) >> 6, ns = (T + 31) >> 5;
-  for (; it < nitems; it += gridDim.x) {
-    const int b = it / H, h = it - b * H;
-    const int nxt = it + gridDim.x;
-    // lane-derived values (fragment bases, store offsets) are re-derived per item from an opaque copy of the lane id:
-    // hoisted out of the item loop they are spilled around it, and a spill reload brings a compiler vmcnt(0) that
-    // drains the LDS-DMA queue in the middle of an item
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int i = lane & 15, g = lane >> 4;
-    // K(n), Q(n) landed: younger in this wave's queue are V(n) [5] and, after the first item, the 7 stores of item n-1
-    if (first) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    ATTN_BARRIER();
-    // ---------------- S^T = K Q^T ----------------
-    bf16x8 qf[2][KS];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (HD % 32 != 0 && ks == KS - 1) {   // columns 64..95 of a 72-wide head: 64..79 exist (72..79 = zero pad)
-          qf[qt][ks] = frag_rows_f<true>(Qt, q0 + 16 * qt, ks, lane);
-          if (g >= 2) qf[qt][ks] = zero_frag();
-        } else {
-          qf[qt][ks] = frag_rows_f<false>(Qt, q0 + 16 * qt, ks, lane);
-        }
-      }
-    f32x4 st[2][16];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int kt = 0; kt < 16; ++kt) st[qt][kt] = zero4();
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      if (sub < nsub) {
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const int kt = sub * 4 + k4;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 kf = (HD % 32 != 0 && ks == KS - 1) ? frag_rows_f<true>(Kt, 16 * kt, ks, lane)
-                                                       : frag_rows_f<false>(Kt, 16 * kt, ks, lane);
-            st[0][kt] = MFMA(kf, qf[0][ks], st[0][kt]);
-            st[1][kt] = MFMA(kf, qf[1][ks], st[1][kt]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // V(n) landed (younger: the stores of item n-1); every wave is past its K and Q reads
-    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    ATTN_BARRIER();
-    if (nxt < nitems) {
-      const bf16* bs = base_of(nxt);
-      issue(Kt, bs + D);
-      issue(Qt, bs);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the DMA issue stays in front of the softmax (the scheduler sinks it otherwise)
-    // ---------------- softmax over the 256 keys, in registers ----------------
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      if (64 * sub + 64 > T) {   // keys past T: a ragged or absent sub-block (wave-uniform)
-        int gg = g;
-        asm volatile("" : "+v"(gg));   // per-item value: keeps the 64 lane masks from being hoisted out of the item loop
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-          for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (64 * sub + 16 * k4 + 4 * gg + r >= T) st[qt][sub * 4 + k4][r] = -INFINITY;
-      }
-    }
-    float mrow[2], lrow[2];
-    bf16x8 pb[2][8];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 16; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mneg = mx * sc2;   // the scale is positive: max of the scaled scores
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 16; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sc2, -mneg));
-          st[qt][kt][r] = p;
-          sum += p;
-        }
-        if (kt & 1) pb[qt][kt >> 1] = pack2(st[qt][kt - 1], st[qt][kt]);
-      }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      mrow[qt] = mneg;
-      lrow[qt] = sum;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---------------- O^T = V^T P^T ----------------
-    f32x4 ot[2][DT];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) ot[qt][dt] = zero4();
-    {
-      const char* vb = Vt + (4 * g + (i >> 2)) * ROWF + (i & 3) * 8;
-      pv_all<ROWF, DT>(vb, ns, pb, ot);
-    }
-    ATTN_BARRIER();   // every wave is past its V reads
-    if (nxt < nitems) issue(Vt, base_of(nxt) + 2 * D);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- output: staged in this wave's patch, whole 144-byte row pieces out ----------------
-    float lsev[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const float inv = 1.f / lrow[qt];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * g;
-        if (d < HD) {
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = f2bf(ot[qt][dt][r] * inv);
-          *(bf16x4*)(Ot + (16 * qt + i) * ROWF + d * 2) = v;
-        }
-      }
-      lsev[qt] = mrow[qt] * LN2 + __logf(lrow[qt]);
-    }
-    {
-      // exactly 5 + 2 buffer stores per wave and item (counted by the waits above); rows >= T and the lanes past the
-      // 32 x NCH chunks fall outside the descriptors and are dropped by the range check
-      const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(o + (long)b * T * D + h * HD, tile_window<HD>(T, D * 2));
-      const __amdgpu_buffer_rsrc_t rsL = mk_rsrc(lse ? lse + ((long)b * H + h) * T : nullptr, (long)T * 4);
-      constexpr int NQ = 32 * NCH;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int qi = lane + 64 * k;
-        int rr = qi / NCH;
-        const int c = qi - rr * NCH;
-        const bool ok = qi < NQ;
-        rr = ok ? rr : 0;
-        const u32x4 v = *(const u32x4*)(Ot + rr * ROWF + c * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsO, ok ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
-      }
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
-                                              g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
-    }
-    first = false;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // Round 4: the T <= 256 forward with every operand at least one phase further ahead (attn_fwd256p_kernel; the engine's form).
 //
-// attn_fwd256_kernel above meets at three barriers per item and can only ask for K(n+1), Q(n+1) once every wave is past
+// Round 2's persistent kernel (three LDS tiles K | V | Q + a staging patch per wave; removed in round 5, 199-203 us at b = 256 against
+// this kernel's 174-180) met at three barriers per item and could only ask for K(n+1), Q(n+1) once every wave was past
 // S(n), and for V(n+1) once every wave is past PV(n): each tile has less than one item's time to arrive, the waves wait
 // for it at the next barrier, and the per-CU vector-memory path (the kernel's floor: 180 KiB per item at ~10 B/clk) idles
 // whenever a compute phase runs long.  Its instruction stream also carried a third of dead weight (ISA census, hd 72:
@@ -889,7 +681,7 @@ __device__ __forceinline__ unsigned pk2(float a, float b) {
 
 // DBGK: a diagnosis instantiation that takes `dbg` (bit 0: no S products, 1: no exponentials, 2: no PV products, 3: the output
 // stores dropped by the range check, 4: every tile load an empty descriptor); the product instantiations ignore it
-template <int HD, bool FULL, bool DBGK, bool STAG>
+template <int HD, bool FULL, bool DBGK>
 __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                              float* __restrict__ lse, int T, int H, int nitems, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -911,14 +703,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   const int tid = threadIdx.x;
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // STAG: the second-dispatched half of the workgroup (waves 4..7, the SIMD partners of waves 0..3) runs one phase late:
-  // after the barrier that ends PV(n) it computes S(n+1) FIRST and only then stores item n, while waves 0..3 store first.
-  // Without it all eight waves leave that barrier into the same 17 vector-memory instructions each (V(n+1), the O rows, Q(n+2))
-  // — the CU's memory path takes them one at a time, the waves sit in instruction issue (4.3 k cycles for waves 0..3, 8.1 k
-  // for waves 4..7 of a 21.3 k-cycle item: fwd_stamps.py) and the matrix pipe idles; now one wave of each SIMD multiplies
-  // while its partner is in the queue.  (O is normalised and staged in LDS before S(n+1): only the two log-sum-exp values
-  // stay in registers across it.)
-  const bool late = STAG && wave >= 4;
+  // (Round 4 measured a half-workgroup stagger — waves 4..7 form S(n+1) before storing item n, so that one wave of each SIMD
+  // multiplies while its partner sits in the vector-memory queue: 20.5 k against 21.4 k cycles per item, kernel time equal within
+  // the box noise; removed in round 5, profiles/r4_time_attn_stag_ab.txt.)
   if (DBGK && (dbg & 64) && wave >= 4) __builtin_amdgcn_s_setprio(1);    // experiment: static priority for the younger half
   if (DBGK && (dbg & 128) && wave < 4) __builtin_amdgcn_s_setprio(1);    // (control: for the older half)
   const int D = H * HD;
@@ -950,17 +737,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   const int G = gridDim.x;
   const int nsub = FULL ? 4 : (T + 63) >> 6;
   // "stores(-1)" + V of the first item: seven dropped stores, so that the counted waits hold from item 0 (distinct,
-  // non-adjacent offsets and values: identical ones are merged into one instruction — tools/r4/check_isa.py counts them)
+  // non-adjacent offsets and values: identical ones are merged into one instruction — tools/check_attn_isa.py counts them)
   auto first_v_and_stores = [&](const bf16* b0) {
     issue(Vw, plus(b0, 2 * D));
     const __amdgpu_buffer_rsrc_t none = mk_rsrc(nullptr, 0);
 #pragma unroll
     for (int k = 0; k < 7; ++k) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(k + lane0), none, DMA_OOB - 256 * k, 0, 0);
   };
-  f32x4 st[2][16];   // S^T of the item in hand: for the late half it is computed at the end of the previous iteration
+  f32x4 st[2][16];   // S^T of the item in hand
   // ---- Q(n): own patch, own wait; then S^T(n) = K(n) Q(n)^T from K buffer `kpar` (landed: the barrier that ended item n-1).
-  // with_first: the late half's first call also issues V and the seven stores of the prologue, BEHIND Q(n+1) (its issue order)
-  auto q_and_s = [&](int n, int kpar, bool with_first) {
+  auto q_and_s = [&](int n, int kpar) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));   // per-item copy of the lane id: hoisted lane-derived values are spilled around the loop
     const int i = lane & 15, g = lane >> 4;
@@ -984,7 +770,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       if (HD % 32 != 0 && g >= 2) { qf[0][KS - 1] = zero_frag(); qf[1][KS - 1] = zero_frag(); }
     }
     issue(Qw, base_of(n + G));
-    if (with_first) first_v_and_stores(base_of(n));
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(1);
     if (DBGK && (dbg & 1)) {
@@ -1024,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   };
   // ---- output of item n in two parts.  stage_item: normalise, round and write O into the wave's own rows of the V tile (dead
   // after the barrier that ends PV) — the accumulators are free afterwards; store_item: whole 144-byte row pieces read back and
-  // stored, V(n+1) into the rows just read back, in FRONT of the stores.  The late half runs S(n+1) between the two.
+  // stored, V(n+1) into the rows just read back, in FRONT of the stores.
   float lsev[2];
   auto stage_item = [&](const f32x4 (&ot)[2][DT], const float (&mrow)[2], const float (&lrow)[2]) {
     int lane = lane0;
@@ -1083,25 +868,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     issue(Qw, b0);
     issue(Kb + wave * 32 * ROWF, plus(b0, D));
     issue(Kb + TILE_F + wave * 32 * ROWF, plus(base_of(it + G), D));
-    if (late) {
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // Q, K of the first item (younger: K of the second)
-    } else {
-      first_v_and_stores(b0);
-      asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // Q, K of the first item (younger: K of the second, V, the 7 stores)
-    }
+    first_v_and_stores(b0);
+    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");   // Q, K of the first item (younger: K of the second, V, the 7 stores)
     ATTN_BARRIER();
   }
-  // Two copies of the item loop, one per half of the workgroup, selected once (a per-iteration branch on `late` made the
-  // register allocator spill: scratch traffic is vector-memory traffic and would break the counted waits).  Early half: S(n) at
-  // the top of the iteration.  Late half: the loop is rotated — S(n) is in hand at the top (st), S(n+1) is formed at the bottom
-  // between the staging and the stores of item n.  Both copies execute the same two barriers per item.
-  auto item_loop = [&](auto late_c) {
-  constexpr bool LATE = decltype(late_c)::value;
   if (DBGK && (dbg & 32)) tprev = __builtin_amdgcn_s_memtime();
-  if (LATE && it < nitems) q_and_s(it, 0, true);
   int par = 0;
   for (; it < nitems; it += G, par ^= 1) {
-    if (!LATE) q_and_s(it, par, false);
+    q_and_s(it, par);
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int i = lane & 15, g = lane >> 4;
@@ -1159,9 +933,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     }
     ATTN_STAMP(3);
     // ---------------- V(n) landed; every wave is past S(n): K(n+2) may overwrite K(n) ----------------
-    // younger than V(n): stores(n-1) 7 [+ Q(n+1) 5 for the early half, whose Q(n+1) is issued after V(n)]
-    if (LATE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    // younger than V(n): stores(n-1) 7 + Q(n+1) 5
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(4);
     if (ONES && lane < 32) *(bf16*)(Vw + lane * ROWF + HD * 2) = (bf16)1.0f;   // own rows, behind own pieces: the ones column
@@ -1203,14 +976,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     ATTN_BARRIER();
     ATTN_STAMP(8);
     stage_item(ot, mrow, lrow);
-    asm volatile("" : "+v"(lsev[0]), "+v"(lsev[1]));   // materialised here: nothing of the accumulators stays live across S(n+1)
     __builtin_amdgcn_sched_barrier(0);
-    if (LATE && it + G < nitems) q_and_s(it + G, par ^ 1, false);   // S(n+1) while the partner waves store item n
     store_item(it);
   }
-  };
-  if (late) item_loop(std::true_type{});
-  else item_loop(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills of the items past the end: LDS stays allocated until they land
   if (DBGK && (dbg & 32) && lse && lane0 == 0) {
     unsigned long long* dst = (unsigned long long*)lse + ((long)blockIdx.x * 8 + wave) * 10;
@@ -1218,279 +986,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     for (int k = 0; k < 10; ++k) dst[k] = tacc[k];
   }
 #undef ATTN_STAMP
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward, T <= 256: one workgroup per (batch, head), Q, K, V, dO resident (4 x 36 KiB), every operand read from HBM once.
-// Three other forms were built in round 2, passed every test and lost on the same box (attention;
-// profiles/r2_pmc_attention.txt): (a) four 80-KiB workgroups per item (dQ / dK,dV roles x halves, two per CU): 2.7 GB of
-// requests per launch instead of 1.2 GB, 600 us; (b) this kernel with 16 waves of 16 rows at 128 VGPRs: every fragment
-// read feeds one MFMA instead of two, LDS traffic doubles, 630 us; (c) a persistent key-stationary kernel (4 waves x 64
-// keys with the 512-register file, Q / dO / O streamed through an LDS-DMA ring across items, S and dP computed once, dQ
-// by an fp32 exchange): 631 us — 224 v_accvgpr_read per chunk and one wave per SIMD with nothing to hide its waits.
-// Two forms that give up the single read were built in round 2, passed the tests and lost (attention):
-// four 80-KiB workgroups per item with 16-row waves, two per CU (dQ / dK,dV roles; each role re-reads all operands:
-// 2.7 GB per launch against 1.2 GB, 600 us), and this kernel with 16 waves of 16 rows at 128 VGPRs (every fragment read
-// feeds one MFMA instead of two: LDS traffic doubles, 630 us).  This form: 575 us at b = 256.
-// QT = 16-row tiles per wave: 2 = eight waves of 32 rows (two per SIMD, 256 registers each); 4 = four waves of 64 rows, one per
-// SIMD with the 512-register file: a K / V (Q / dO) fragment read then feeds four MFMAs instead of two — half the LDS traffic.
-template <int HD, int QT>
-__global__ __launch_bounds__(1024 / QT, QT == 4 ? 1 : 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
-                                                       const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                       bf16* __restrict__ dqkv, int B, int T, int H) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15, g = lane >> 4;
-  const int D = H * HD;
-  const int bh = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int b = bh / H, h = bh % H;
-  const long tok = 3l * D;
-  const bf16* base = qkv + (long)b * T * tok + h * HD;
-  bf16* dbase = dqkv + (long)b * T * tok + h * HD;
-  char* Qt = smem;
-  char* Kt = smem + TILE_B;
-  char* Vt = smem + 2 * TILE_B;
-  char* Gt = smem + 3 * TILE_B;  // dO
-  float* lse2 = (float*)(smem + 4 * TILE_B + 256);
-  float* dlt = lse2 + 256;
-  if (tid < 16) *(uint4*)(smem + 4 * TILE_B + tid * 16) = make_uint4(0, 0, 0, 0);
-  const float scale = rsqrtf((float)HD);
-  const float sc2 = scale * LOG2E;
-
-  // Load phase, round 2: the four tiles arrive by LDS-DMA (nothing staged in registers) in two pairs, 9 pieces per wave
-  // and pair: K, V first — phase 1 (dQ) reads them — then this wave's own query rows straight into registers (Q and dO
-  // fragments, the O rows of its delta = rowsum(dO * O), the log-sum-exp), then Q, dO, which only phase 2 needs: they
-  // land while phase 1 computes.  The wait before phase 1 is counted (the Q / dO pieces stay in flight).
-  constexpr int NWV = 16 / QT, WR = 16 * QT;   // waves, rows per wave
-  const int r0 = wave * WR;  // this wave's rows (queries in phase 1, keys in phase 2)
-  const bf16* gbase = d_o + (long)b * T * D + h * HD;
-  auto issue_pair = [&](char* t0, const bf16* s0, int sb0, char* t1, const bf16* s1, int sb1) {
-    const __amdgpu_buffer_rsrc_t rs0 = mk_rsrc(s0, tile_window<HD>(T, sb0)), rs1 = mk_rsrc(s1, tile_window<HD>(T, sb1));
-#pragma unroll
-    for (int j = 0; j < 72 / NWV; ++j) {
-      const int pp = (72 / NWV) * wave + j;     // 72 pieces of 1 KiB: 36 per tile (256 rows x 9 chunks / 64 lanes)
-      const bool second = pp >= 36;
-      const int I = second ? pp - 36 : pp;
-      const int vo = dma_voff<HD, ROWB>(I * 64 + lane, second ? sb1 : sb0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? t1 : t0) + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
-    }
-  };
-  issue_pair(Kt, base + D, (int)(tok * 2), Vt, base + 2 * D, (int)(tok * 2));
-  bf16x8 qf[QT][KS], gf[QT][KS], of[QT][KS];
-  float lq[QT], dq_[QT];
-  // every register load of the wave's own rows is issued before anything consumes one, and the Q / dO pieces behind them:
-  // the compiler's wait for the fragments is then a counted vmcnt(9), not a drain per use
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int row = r0 + 16 * qt + i;
-    const bool ok = row < T;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[qt][ks] = load_frag_global<HD>(base + (long)row * tok, ok, ks, lane);
-      gf[qt][ks] = load_frag_global<HD>(gbase + (long)row * D, ok, ks, lane);
-      of[qt][ks] = load_frag_global<HD>(o + ((long)b * T + row) * D + h * HD, ok, ks, lane);
-    }
-    lq[qt] = lse[((long)b * H + h) * T + min(row, T - 1)];
-  }
-  issue_pair(Qt, base, (int)(tok * 2), Gt, gbase, D * 2);
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    float acc = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += bf2f(gf[qt][ks][e]) * bf2f(of[qt][ks][e]);
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
-    dq_[qt] = acc;
-    lq[qt] = (r0 + 16 * qt + i < T) ? lq[qt] * LOG2E : INFINITY;
-  }
-  if (g == 0) {   // phase 2 reads the 256 deltas and log-sum-exps from LDS: every wave contributes its 32 rows
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { dlt[r0 + 16 * qt + i] = dq_[qt]; lse2[r0 + 16 * qt + i] = lq[qt]; }
-  }
-  if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // K, V (and the register loads) landed;
-  else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                       // younger: the wave's Q / dO pieces
-  ATTN_BARRIER();
-
-  f32x4 dq[QT][DT];
-  // A wave's 32 finished rows leave through LDS: the MFMA layout gives a lane 4 consecutive columns of one row, i.e. a
-  // wave-level store of sixteen 32-byte pieces — the pattern that cost the GEMM epilogues their HBM time.
-  // Staged in the wave's OWN 32 rows of the K / V tiles (dead once phase 2 has its key fragments in registers, see the
-  // barrier below) they go out as whole 144-byte row pieces, 16 bytes per lane.
-  auto store_rows = [&](const char* tile, bf16* gbase) {
-    constexpr int NQ = WR * NCH;
-#pragma unroll
-    for (int k = 0; k < (NQ + 63) / 64; ++k) {
-      const int qi = lane + 64 * k;
-      const int rr = qi / NCH, c = qi - rr * NCH;
-      if (qi < NQ && r0 + rr < T)
-        *(uint4*)(gbase + (long)(r0 + rr) * tok + c * 8) = *(const uint4*)(tile + (r0 + rr) * ROWB + c * 16);
-    }
-  };
-  if (r0 < T) {
-    // ---------------- phase 1: dQ for queries [r0, r0+32) ----------------
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) dq[qt][dt] = zero4();
-    const int nblk = (T + 31) >> 5;
-    for (int kb = 0; kb < nblk; ++kb) {
-      const int kv0 = kb * 32;
-      f32x4 st[QT][2], dp[QT][2];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) { st[qt][kt] = zero4(); dp[qt][kt] = zero4(); }
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 kf = frag_rows(Kt, kv0 + 16 * kt, ks, lane);
-          bf16x8 vf = frag_rows(Vt, kv0 + 16 * kt, ks, lane);
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) {
-            st[qt][kt] = MFMA(kf, qf[qt][ks], st[qt][kt]);
-            dp[qt][kt] = MFMA(vf, gf[qt][ks], dp[qt][kt]);
-          }
-        }
-      bf16x8 dsb[QT];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], sc2, -lq[qt]));
-            st[qt][kt][r] = p * (dp[qt][kt][r] - dq_[qt]);
-          }
-      }
-      if (kv0 + 32 > T) {   // keys past T exist only in a ragged last key block
-        asm volatile("; ragged key block" ::);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (kv0 + 16 * kt + 4 * g + r >= T) st[qt][kt][r] = 0.f;
-      }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) dsb[qt] = pack2(st[qt][0], st[qt][1]);
-      {
-        // (asm reads: with the builtin the compiler would drain the Q / dO pieces still in flight before every read)
-        bf16x8 ktf[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) ktf[dt] = frag_trT_a<ROWB>(Kt, kv0, 16 * dt, lane);
-        ATTN_LDS_WAIT();
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) dq[qt][dt] = MFMA(ktf[dt], dsb[qt], dq[qt][dt]);
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q / dO tiles have landed
-  __syncthreads();   // phase 1 (every wave reads all of K and V) is over: rows [r0, r0+32) of Kt / Vt are this wave's alone
-  if (r0 < T) {
-    // ---------------- phase 2: dK, dV for keys [r0, r0+32) ----------------
-    bf16x8 kf[QT][KS], vf[QT][KS];
-#pragma unroll
-    for (int ct = 0; ct < QT; ++ct)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
-        vf[ct][ks] = frag_rows_z<HD>(Vt, r0 + 16 * ct, ks, lane);
-      }
-    // dQ of phase 1 leaves now, staged in the K rows whose fragments were just taken; its stores drain under phase 2
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * g;
-        if (d < HD) {
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[qt][dt][r] * scale);
-          *(bf16x4*)(Kt + (r0 + 16 * qt + i) * ROWB + d * 2) = v;
-        }
-      }
-    store_rows(Kt, dbase);
-    f32x4 dk[QT][DT], dv[QT][DT];
-#pragma unroll
-    for (int ct = 0; ct < QT; ++ct)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) { dk[ct][dt] = zero4(); dv[ct][dt] = zero4(); }
-    const int nblk = (T + 31) >> 5;
-    for (int qb = 0; qb < nblk; ++qb) {
-      const int qq0 = qb * 32;
-      f32x4 st[2][QT], dp[2][QT];  // [qt][ct]: rows q = qq0+16qt+4g+r, col kv = r0+16ct+i
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int ct = 0; ct < QT; ++ct) { st[qt][ct] = zero4(); dp[qt][ct] = zero4(); }
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 qa = frag_rows(Qt, qq0 + 16 * qt, ks, lane);
-          bf16x8 ga = frag_rows(Gt, qq0 + 16 * qt, ks, lane);
-#pragma unroll
-          for (int ct = 0; ct < QT; ++ct) {
-            st[qt][ct] = MFMA(qa, kf[ct][ks], st[qt][ct]);
-            dp[qt][ct] = MFMA(ga, vf[ct][ks], dp[qt][ct]);
-          }
-        }
-      f32x4 lq4[2], dl4[2];
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        lq4[qt] = *(const f32x4*)(lse2 + qq0 + 16 * qt + 4 * g);
-        dl4[qt] = *(const f32x4*)(dlt + qq0 + 16 * qt + 4 * g);
-      }
-      bf16x8 pb[QT], dsb[QT];
-#pragma unroll
-      for (int ct = 0; ct < QT; ++ct) {
-        f32x4 p0, p1, s0, s1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[0][ct][r], sc2, -lq4[0][r]));
-          p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[1][ct][r], sc2, -lq4[1][r]));
-          s0[r] = p0[r] * (dp[0][ct][r] - dl4[0][r]);
-          s1[r] = p1[r] * (dp[1][ct][r] - dl4[1][r]);
-        }
-        pb[ct] = pack2(p0, p1);
-        dsb[ct] = pack2(s0, s1);
-      }
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        bf16x8 gtf = frag_trT(Gt, qq0, 16 * dt, lane);
-        bf16x8 qtf = frag_trT(Qt, qq0, 16 * dt, lane);
-#pragma unroll
-        for (int ct = 0; ct < QT; ++ct) {
-          dv[ct][dt] = MFMA(gtf, pb[ct], dv[ct][dt]);
-          dk[ct][dt] = MFMA(qtf, dsb[ct], dk[ct][dt]);
-        }
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < QT; ++ct)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * g;
-        if (d < HD) {
-          bf16x4 a, c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { a[r] = f2bf(dk[ct][dt][r] * scale); c[r] = f2bf(dv[ct][dt][r]); }
-          *(bf16x4*)(Kt + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
-          *(bf16x4*)(Vt + (r0 + 16 * ct + i) * ROWB + d * 2) = c;
-        }
-      }
-    store_rows(Kt, dbase + D);
-    store_rows(Vt, dbase + 2 * D);
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2556,12 +2051,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
 #undef RING_STAMP
 }
 
-int attn_fwd_oneshot() {   // REED_ATTN_FWD=oneshot: the round-1 forward also for T <= 256 (A/B)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("REED_ATTN_FWD"); v = (e && e[0] == 'o') ? 1 : 0; }
-  return v;
-}
-
 template <typename K>
 int set_lds(K kernel, int bytes) {
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -2591,57 +2080,39 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
   REED_CHECK_ARG(hd == 64 || hd == 72 || hd == 80, "attention: head_dim %d unsupported (64, 72 or 80)", hd);
   REED_CHECK_ARG(hd != 80 || T <= 256, "attention: head_dim 80 (the I-JEPA ViT-H tower) is built for T <= 256 only (T=%d)", T);
   REED_CHECK_ARG(B > 0 && T > 0 && H > 0, "attention: bad dims B=%d T=%d H=%d", B, T, H);
-  if (T <= 256 && (hd == 80 || !attn_fwd_oneshot())) {
+  if (T <= 256) {
     const int lds = 4 * TILE_F, nitems = B * H;
     int ncu = num_cus();
     ncu -= ncu % 8;                       // whole XCD rounds: the item -> XCD map of xcd_contiguous
     const dim3 grid(nitems < ncu ? nitems : ncu);
-    // REED_ATTN_FWD=r2 keeps round 2's three-barrier kernel (same-box A/B); REED_ATTN_FWD_DBG=<bits> runs the diagnosis
-    // instantiation of the round-4 kernel (hd 72, T = 256 only: parts of the work switched off, results meaningless)
-    static const bool r2 = getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 'r';
+#ifdef REED_ATTN_DIAG   // diagnosis build: REED_ATTN_FWD_DBG=<bits> runs the instantiation with parts of the work switched off
     static const int fdbg = getenv("REED_ATTN_FWD_DBG") ? atoi(getenv("REED_ATTN_FWD_DBG")) : 0;
-    if (!r2) {
-#define LAUNCH_FWD256P(HD, FULL, DBGK, STAG)                                                                           \
+#else
+    constexpr int fdbg = 0;
+#endif
+#define LAUNCH_FWD256P(HD, FULL, DBGK)                                                                                 \
     do {                                                                                                               \
-      static int once = set_lds(attn_fwd256p_kernel<HD, FULL, DBGK, STAG>, lds);                                       \
+      static int once = set_lds(attn_fwd256p_kernel<HD, FULL, DBGK>, lds);                                             \
       if (once) return once;                                                                                           \
-      REED_KLAUNCH((attn_fwd256p_kernel<HD, FULL, DBGK, STAG>), grid, dim3(512), lds, (hipStream_t)stream,              \
+      REED_KLAUNCH((attn_fwd256p_kernel<HD, FULL, DBGK>), grid, dim3(512), lds, (hipStream_t)stream,                    \
                    (const bf16*)qkv, (bf16*)o, lse, T, H, nitems, fdbg);                                               \
     } while (0)
-      // REED_ATTN_FWD=stag: the half-workgroup stagger (measured neutral at b = 256: 180.1 / 182.9 against 185.9 / 175.8 us on
-      // one box, 20.5 k against 21.4 k cycles per item — the vector-memory issue queue is what the waves wait in either way;
-      // kept for A/B, off by default)
-      static const bool nostag = !(getenv("REED_ATTN_FWD") && getenv("REED_ATTN_FWD")[0] == 's');
-      if (fdbg && hd == 72 && T == 256) { if (nostag) LAUNCH_FWD256P(72, true, true, false); else LAUNCH_FWD256P(72, true, true, true); }
-      else if (nostag && hd == 72 && T == 256) LAUNCH_FWD256P(72, true, false, false);
-      // the stagger is instantiated where its late-half loop allocates without scratch (hd 72 at T = 256: SiT-XL; tools/r4/check_isa.py)
-      else if (hd == 64) { if (T == 256) LAUNCH_FWD256P(64, true, false, false); else LAUNCH_FWD256P(64, false, false, false); }
-      else if (hd == 72) { if (T == 256) LAUNCH_FWD256P(72, true, false, true); else LAUNCH_FWD256P(72, false, false, false); }
-      else { if (T == 256) LAUNCH_FWD256P(80, true, false, false); else LAUNCH_FWD256P(80, false, false, false); }
+#ifdef REED_ATTN_DIAG
+    if (fdbg && hd == 72 && T == 256) LAUNCH_FWD256P(72, true, true);
+    else
+#endif
+    if (hd == 64) { if (T == 256) LAUNCH_FWD256P(64, true, false); else LAUNCH_FWD256P(64, false, false); }
+    else if (hd == 72) { if (T == 256) LAUNCH_FWD256P(72, true, false); else LAUNCH_FWD256P(72, false, false); }
+    else { if (T == 256) LAUNCH_FWD256P(80, true, false); else LAUNCH_FWD256P(80, false, false); }
 #undef LAUNCH_FWD256P
-      REED_LAUNCH_CHECK();
-      return REED_OK;
-    }
-#define LAUNCH_FWD256(HD)                                                                                              \
-    do {                                                                                                               \
-      static int once = set_lds(attn_fwd256_kernel<HD>, lds);                                                          \
-      if (once) return once;                                                                                           \
-      REED_KLAUNCH(attn_fwd256_kernel<HD>, grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T,  \
-                   H, nitems);                                                                                         \
-    } while (0)
-    if (hd == 64) LAUNCH_FWD256(64);
-    else if (hd == 72) LAUNCH_FWD256(72);
-    else LAUNCH_FWD256(80);
-#undef LAUNCH_FWD256
     REED_LAUNCH_CHECK();
     return REED_OK;
   }
   const int lds = 2 * TILE_F;
   dim3 grid(B * H, (T + 255) / 256);
-  // a last query block of at most 16 rows (T = 257, 261: the ViT towers) goes to the row kernel; REED_ATTN_TAIL=0: the old form
-  static const bool tail_on = !(getenv("REED_ATTN_TAIL") && atoi(getenv("REED_ATTN_TAIL")) == 0);
+  // a last query block of at most 16 rows (T = 257, 261: the ViT towers) goes to the row kernel
   const int tail = T % 256;
-  if (tail_on && hd == 64 && T > 256 && T <= 512 && tail >= 1 && tail <= 16) {
+  if (hd == 64 && T > 256 && T <= 512 && tail >= 1 && tail <= 16) {
     grid.y = T / 256;
     const int nwaves = B * H * tail;
     REED_KLAUNCH(attn_fwd_rows_kernel, dim3(cdiv(nwaves, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, T, H,
@@ -2668,38 +2139,19 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
   REED_CHECK_ARG(T > 0 && T <= 256, "attention_bwd: T=%d unsupported (training path is T <= 256)", T);
   const int lds = 4 * TILE_B + 256 + 2048;
   dim3 grid(B * H);
-  static const bool w4 = getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1;   // experiment: 4 waves x 64 rows
-  // REED_ATTN_BWD=2p keeps the two-phase kernel (same-box A/B); default: the key-stationary kernel (S and dP once)
-  static const bool two_phase = getenv("REED_ATTN_BWD") && getenv("REED_ATTN_BWD")[0] == '2';
-  if (!two_phase && !w4) {
-    if (hd == 64) {
-      static int once = set_lds(attn_bwd_ks_kernel<64>, lds);
-      if (once) return once;
-      REED_KLAUNCH((attn_bwd_ks_kernel<64>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
-                   (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
-    } else {
-      static int once = set_lds(attn_bwd_ks_kernel<72>, lds);
-      if (once) return once;
-      REED_KLAUNCH((attn_bwd_ks_kernel<72>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
-                   (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
-    }
-    REED_LAUNCH_CHECK();
-    return REED_OK;
-  }
-  if (w4 && hd == 72) {
-    static int once = set_lds(attn_bwd_kernel<72, 4>, lds);
+  // the one-shot key-stationary kernel (S and dP once); the engine's path is reed_attention_bwd_ws / _dp below.  (Round 1's
+  // two-phase kernel — dQ by query rows, then dK / dV by key rows, S and dP twice — and a four-wave 64-row variant of it were
+  // removed in round 5: round 3 measured 595 us isolated / 586 in-step at b = 256 for the two-phase kernel against 572 for this
+  // one and 408 in-step for the persistent ring kernel, DESIGN_HISTORY.md.)
+  if (hd == 64) {
+    static int once = set_lds(attn_bwd_ks_kernel<64>, lds);
     if (once) return once;
-    REED_KLAUNCH((attn_bwd_kernel<72, 4>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
-                 (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
-  } else if (hd == 64) {
-    static int once = set_lds(attn_bwd_kernel<64, 2>, lds);
-    if (once) return once;
-    REED_KLAUNCH((attn_bwd_kernel<64, 2>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+    REED_KLAUNCH((attn_bwd_ks_kernel<64>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
                  (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   } else {
-    static int once = set_lds(attn_bwd_kernel<72, 2>, lds);
+    static int once = set_lds(attn_bwd_ks_kernel<72>, lds);
     if (once) return once;
-    REED_KLAUNCH((attn_bwd_kernel<72, 2>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
+    REED_KLAUNCH((attn_bwd_ks_kernel<72>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)o,
                  (const bf16*)d_o, lse, (bf16*)dqkv, B, T, H);
   }
   REED_LAUNCH_CHECK();
@@ -2709,8 +2161,7 @@ extern "C" int reed_attention_bwd(const void* qkv, const void* o, const void* d_
 // ------------------------------------------------------------------------------------------
 
 // Backward with a workspace (ws: reed_attention_bwd_ws_floats(B, T, H) floats, caller-owned): delta = rowsum(dO * O) by a row
-// kernel, then the persistent key-stationary kernel (attn_bwd_ksp_kernel).  REED_ATTN_BWD=2p / ks1 select the two-phase / the
-// one-shot key-stationary kernel of reed_attention_bwd instead (same-box A/B).
+// kernel, then the persistent key-stationary kernel (attn_bwd_ring_kernel at T = 256, attn_bwd_ksp_kernel below it).
 extern "C" int64_t reed_attention_bwd_ws_floats(int B, int T, int H) { return (int64_t)B * T * H; }
 
 // dpart != NULL: delta comes from the partial dot products of reed_gemm's epilogue 13 (o is not read)
@@ -2727,13 +2178,16 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
   // Beside a collective (reed_set_concurrent_comm: the data-parallel backward) RCCL's channels hold CUs, and a grid of one workgroup
   // per CU with the items in a static stride then waits for the workgroups that found no CU to run their WHOLE lists after the
   // others (+ 42 % with 8-32 CUs held: profiles/r4_kernels_under_cu_hog.txt).  Several short lists per CU instead: the dispatcher
-  // hands the next workgroup to whichever CU is free.  REED_ATTN_BWD_GRID=<m>: m workgroups per CU whatever the flag (A/B).
-  static const int gm_env = getenv("REED_ATTN_BWD_GRID") ? atoi(getenv("REED_ATTN_BWD_GRID")) : 0;
-  const int gmult = gm_env > 0 ? gm_env : reed_concurrent_comm() ? 4 : 1;
+  // hands the next workgroup to whichever CU is free.
+  const int gmult = reed_concurrent_comm() ? 4 : 1;
   const long gwant = (long)ncu * gmult;
   const dim3 pgrid((unsigned)(nitems < gwant ? nitems : gwant));
   hipStream_t s = (hipStream_t)stream;
-  static const int dbg = getenv("REED_ATTN_KSP_DBG") ? atoi(getenv("REED_ATTN_KSP_DBG")) : 0;   // diagnosis: skip parts of the work
+#ifdef REED_ATTN_DIAG
+  static const int dbg = getenv("REED_ATTN_KSP_DBG") ? atoi(getenv("REED_ATTN_KSP_DBG")) : 0;   // diagnosis build: skip parts of the work
+#else
+  constexpr int dbg = 0;
+#endif
 #define REED_DELTA(HD)                                                                                                    \
   do {                                                                                                                    \
     if (dpart)                                                                                                            \
@@ -2750,8 +2204,7 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
     REED_KLAUNCH(attn_bwd_ksp_kernel<HD>, pgrid, dim3(512), lds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
                  (bf16*)dqkv, T, H, nitems, dbg);                                                                              \
   } while (0)
-  static const bool noring = getenv("REED_ATTN_RING") && atoi(getenv("REED_ATTN_RING")) == 0;   // A/B: the tile form at T = 256 too
-  if (T == 256 && !noring) {
+  if (T == 256) {
     const int rlds = 4 * 64 * ROWF + 3 * TILE_B + 4096;
 #define REED_BWD_RING(HD)                                                                                                 \
   do {                                                                                                                    \
@@ -2762,6 +2215,7 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
     REED_KLAUNCH(attn_bwd_ring_kernel<HD>, pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
                  (bf16*)dqkv, H, nitems, dbg);                                                                            \
   } while (0)
+#ifdef REED_ATTN_DIAG
     if (hd == 72 && (dbg & 4)) {   // the stamped instantiation (diagnosis)
       static int once = set_lds(attn_bwd_ring_kernel<72, true>, rlds);
       if (once) return once;
@@ -2769,7 +2223,9 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
       REED_LAUNCH_CHECK();
       REED_KLAUNCH((attn_bwd_ring_kernel<72, true>), pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws,
                    (bf16*)dqkv, H, nitems, dbg);
-    } else if (hd == 64) REED_BWD_RING(64);
+    } else
+#endif
+    if (hd == 64) REED_BWD_RING(64);
     else REED_BWD_RING(72);
 #undef REED_BWD_RING
     REED_LAUNCH_CHECK();
@@ -2785,8 +2241,7 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
 
 extern "C" int reed_attention_bwd_ws(const void* qkv, const void* o, const void* d_o, const float* lse, void* dqkv, float* ws,
                                      int B, int T, int H, int hd, void* stream) {
-  static const bool other = getenv("REED_ATTN_BWD") != nullptr || (getenv("REED_ATTN_BWD_W4") && atoi(getenv("REED_ATTN_BWD_W4")) == 1);
-  if (other || !ws) return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
+  if (!ws) return reed_attention_bwd(qkv, o, d_o, lse, dqkv, B, T, H, hd, stream);
   return attention_bwd_persistent(qkv, o, d_o, lse, dqkv, ws, nullptr, B, T, H, hd, stream);
 }
 

@@ -525,12 +525,6 @@ __global__ __launch_bounds__(256) void final_bwd_rows_lds_kernel(const float* __
 
 }  // namespace
 
-// REED_EMBED_OLD=1: the first forms of the patch-embed / final-layer forward (tests compare the two bit for bit; A/B timing)
-static bool embed_old_forms() {
-  const char* e = getenv("REED_EMBED_OLD");
-  return e && atoi(e) == 1;
-}
-
 extern "C" int reed_patchify_bf16(const float* x, void* out, int B, int C, int HW, int P, int order, void* stream) {
   REED_CHECK_ARG(HW % P == 0, "patchify: HW=%d not divisible by P=%d", HW, P);
   long n = (long)B * C * HW * HW;
@@ -545,7 +539,7 @@ extern "C" int reed_patch_embed_fwd(const float* x, const void* w, const void* b
   REED_CHECK_ARG(HW % P == 0 && (C * P * P) % 8 == 0, "patch_embed: HW=%d P=%d C=%d unsupported", HW, P, C);
   const int T = (HW / P) * (HW / P), K = C * P * P;
   if (K == PK && D % 4 == 0 && D <= 4 * PNT && ((uintptr_t)w % 16) == 0 && ((uintptr_t)pos % 16) == 0 &&
-      ((uintptr_t)tokens % 16) == 0 && !embed_old_forms()) {   // patch 2 on 4 channels (every SiT-*/2 preset)
+      ((uintptr_t)tokens % 16) == 0) {   // patch 2 on 4 channels (every SiT-*/2 preset)
     REED_KLAUNCH(patch_embed_fwd16_kernel, dim3(cdiv((long)B * T, PT)), dim3(PNT), 0, (hipStream_t)stream, x, (const bf16*)w,
                  (const bf16*)bias, pos, tokens, B, C, HW, P, D);
     REED_LAUNCH_CHECK();
@@ -619,7 +613,7 @@ extern "C" int reed_final_layer_fwd(const float* x, const void* shift, const voi
   int G = (int)(sqrtf((float)T) + 0.5f);
   REED_CHECK_ARG(G * G == T, "final_layer: T=%d is not a square grid", T);
   const long wbytes = (long)P * P * C * D * sizeof(bf16);
-  if (wbytes <= 64 * 1024 && (P * P * C * D) % 8 == 0 && ((uintptr_t)w % 16) == 0 && !embed_old_forms()) {   // the weight fits a block's LDS
+  if (wbytes <= 64 * 1024 && (P * P * C * D) % 8 == 0 && ((uintptr_t)w % 16) == 0) {   // the weight fits a block's LDS
     REED_KLAUNCH(final_fwd_lds_kernel, dim3(cdiv((long)B * T, FR)), dim3(256), (size_t)wbytes, (hipStream_t)stream, x,
                  (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w, (const bf16*)bias, out, mean, rstd, B, T, D, C, P,
                  eps);
@@ -641,7 +635,7 @@ extern "C" int reed_final_layer_bwd_rows(const float* dout, const float* x, cons
   REED_CHECK_ARG(D % 4 == 0 && D <= 256 * MAXV, "final_layer: D=%d unsupported", D);
   const int NO = P * P * C;
   const long wb = (long)NO * D * sizeof(bf16);
-  if (wb + 4 * NO * (long)sizeof(float) <= 64 * 1024 && (NO * D) % 8 == 0 && ((uintptr_t)w % 16) == 0 && !embed_old_forms()) {
+  if (wb + 4 * NO * (long)sizeof(float) <= 64 * 1024 && (NO * D) % 8 == 0 && ((uintptr_t)w % 16) == 0) {
     REED_KLAUNCH(final_bwd_rows_lds_kernel, dim3(cdiv((long)B * T, FR)), dim3(256), (size_t)(wb + 4 * NO * sizeof(float)),
                  (hipStream_t)stream, dout, x, mean, rstd, (const bf16*)shift, (const bf16*)scale, (long)ldmod, (const bf16*)w,
                  (bf16*)hbuf, (bf16*)dlin, (bf16*)dh, B, T, D, C, P);

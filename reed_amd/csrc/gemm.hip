@@ -286,15 +286,13 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
   // 5 rounds of 256 CUs where 64 x 16 = 1024 are exactly 4 (qkv 4 -> 3, proj and fc2 2 -> 1).  Where dropping the ragged row
   // tile saves a round, the full rows go out as one launch and the <= 128 tail rows as a second, small one (the same kernels
   // on offset pointers: bit-identical results; epilogues whose row index carries meaning — the per-sample gate, the head-dot
-  // slots — are left alone).  REED_GEMM_SPLIT_M=0 switches it off (A/B).
+  // slots — are left alone).
   {
-    static int split_on = -1;
-    if (split_on < 0) { const char* e = getenv("REED_GEMM_SPLIT_M"); split_on = e ? atoi(e) : 1; }
     const bool epi_rows_free = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_QGELU || epi == EPI_GELU_ERF ||
                                epi == EPI_RES_BF16 || epi == EPI_LS_RES || epi == EPI_DGELU || epi == EPI_DSILU ||
                                epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_MUL;
     const int r = a.M % 256, mfull = a.M - r;
-    if (split_on && g_force_tile == 0 && want != EPI_BF16_DOT && epi_rows_free && splits <= 1 && (layout == LAY_NT || layout == LAY_NN) &&
+    if (g_force_tile == 0 && want != EPI_BF16_DOT && epi_rows_free && splits <= 1 && (layout == LAY_NT || layout == LAY_NN) &&
         r > 0 && r <= 128 && mfull >= 2048) {
       const int ncu = reed_num_cus(), ntn = cdiv(a.N, 256), rows = mfull / 256;
       if (cdiv((long)rows * ntn, ncu) < cdiv((long)(rows + 1) * ntn, ncu)) {
@@ -309,10 +307,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
         const int rc = reed_gemm_launch(layout, epi, m, splits, stream);
         if (rc != REED_OK) return rc;
         // the tail: a few rows against the whole weight matrix — bound by how many CUs stream it (gemm_skinny.hip: 16 x 64 tiles,
-        // one wave each; REED_GEMM_SKINNY=0: the 128^2 kernel as before, A/B)
-        static int skinny_on = -1;
-        if (skinny_on < 0) { const char* e = getenv("REED_GEMM_SKINNY"); skinny_on = e ? atoi(e) : 1; }
-        if (skinny_on && reed_gemm_skinny_eligible(layout, epi, t, splits)) return reed_gemm_skinny_launch(epi, t, stream);
+        // one wave each)
+        if (reed_gemm_skinny_eligible(layout, epi, t, splits)) return reed_gemm_skinny_launch(epi, t, stream);
         return reed_gemm_launch(layout, epi, t, splits, stream);
       }
     }
@@ -330,9 +326,8 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
   if (g_force_tile != 128 && (g_force_tile == 256 || reed_gemm256_preferred(layout, epi, a, splits)) &&
       !(layout == LAY_TN && a.dbias)) {
     // the 256^2 tile: four waves of 128x128 (gemm256w.hip) where that kernel is built, else eight of 128x64 (gemm256.hip);
-    // REED_GEMM_W4=0 or force_tile 256 keep the 8-wave kernel (A/B timing)
-    static const bool w4 = !(getenv("REED_GEMM_W4") && atoi(getenv("REED_GEMM_W4")) == 0);
-    if (w4 && g_force_tile != 256 && reed_gemm256w_eligible(layout, epi, a, splits))
+    // force_tile 256 keeps the 8-wave kernel (tests, A/B timing)
+    if (g_force_tile != 256 && reed_gemm256w_eligible(layout, epi, a, splits))
       return reed_gemm256w_launch(layout, want, a, stream);
     REED_ONLY_PLAIN();
     return reed_gemm256_launch(layout, epi, a, splits, stream);

@@ -407,11 +407,7 @@ __global__ __launch_bounds__(LW ? 768 : 512) void gemm144_kernel(GemmArgs a) {
   if (wc == 0) strip_epilogue<EPI>(a, accx, m0 + wr * 64, n0 + 64, lane);   // columns 64 .. 79 of the tile
 }
 
-static bool use_loader_waves() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("REED_GEMM144_LW"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
+static bool use_loader_waves() { return true; }   // (the 8-wave form without them: the epilogues that have no loader-wave instantiation)
 
 template <int LAY, int EPI>
 int launch144(const GemmArgs& a, hipStream_t stream) {
@@ -479,7 +475,7 @@ double reed_gemm256_rate();
 // 1.18).  A 256x144 tile is 0.5625 of a 256^2 tile; with the loader waves its main loop runs at the chip's dense-MFMA
 // ceiling when all 256 CUs are busy, but per round it exposes the same epilogue as the 256^2 kernel on 0.56 of the work,
 // so over the block shapes it is worth ~0.92 of the 256^2 kernel per flop (tools/tile_ab.py and, in-step,
-// tools/eta_sweep.sh, b = 32 .. 256): cost = rounds x 2.25 / 0.92.  The 256^2 side: below two rounds in WHOLE rounds
+// a sweep of the threshold inside the step, b = 32 .. 256, round 2): cost = rounds x 2.25 / 0.92.  The 256^2 side: below two rounds in WHOLE rounds
 // (ragged column tiles as workgroups: at 1.25 rounds — b = 64, N = 1152 — the second, quarter-full round costs a full
 // tile time), from two rounds on gemm256.hip's own half-round model.  Outcome on SiT-XL/2: the five 1152-wide outputs
 // (proj / fc2 forward, dgrads of qkv / proj / fc1) at b <= 64 per GPU and the two 4608-wide ones (fc1 forward, fc2
@@ -487,7 +483,7 @@ double reed_gemm256_rate();
 bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits) {
   if (!reed_gemm144_eligible(layout, epi, a, splits) || a.K < 256) return false;
   const int ncu = reed_num_cus();
-  static const double eta = getenv("REED_GEMM144_ETA") ? atof(getenv("REED_GEMM144_ETA")) : 0.92;   // experiments
+  constexpr double eta = 0.92;
   const long tm = cdiv(a.M, 256), tn = cdiv(a.N, 256);
   const long t144 = (long)cdiv(a.M, BM4) * (a.N / BN4);
   const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);

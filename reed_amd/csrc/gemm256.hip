@@ -327,13 +327,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 }
 
 // Tile rows per group of the XCD-local tile walk (kernel: groups of GM tile rows x all tile columns, rows fastest).
-// REED_GEMM256_GM overrides (A/B timing).
-int tile_group_rows(const GemmArgs& a) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("REED_GEMM256_GM"); forced = e ? atoi(e) : 0; }
-  if (forced > 0) return forced;
-  return 4;
-}
+int tile_group_rows(const GemmArgs& a) { return 4; }
 
 template <int LAY, int EPI>
 int launch256(const GemmArgs& a, int splits, hipStream_t stream) {
@@ -397,13 +391,9 @@ extern "C" int reed_set_cu_reserve(int n) { g_cu_reserve = n > 0 ? n : 0; return
 int reed_num_cus() {
   static int n = 0;
   if (!n) {
-    const char* e = getenv("REED_GEMM_CUS");
-    if (e && atoi(e) > 0) n = atoi(e);
-    if (!n) {
-      int dev = 0;
-      hipDeviceProp_t p;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    }
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
     if (n <= 0) n = 256;
   }
   return n - g_cu_reserve > 32 ? n - g_cu_reserve : 32;
@@ -423,11 +413,8 @@ int reed_concurrent_comm() { return g_concurrent_comm; }
 //   t256 = ceil(tiles256 / CUs) * 4 / 1.18        t128 = ceil(tiles128 / (2 CUs)) * 2
 // TN (wgrad) stays on the 128^2 kernel with wave-quantised split-K (ops.plan_wgrad); its 256^2 variant is reachable
 // through reed_gemm_force_tile only.
-// speed of the 256^2 kernel per flop relative to the 128^2 one in the round-count models (REED_GEMM256_RATE: experiments)
-double reed_gemm256_rate() {
-  static const double r = getenv("REED_GEMM256_RATE") ? atof(getenv("REED_GEMM256_RATE")) : 1.18;
-  return r;
-}
+// speed of the 256^2 kernel per flop relative to the 128^2 one in the round-count models
+double reed_gemm256_rate() { return 1.18; }
 
 bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits) {
   if (layout == LAY_TN || splits > 1 || a.K < 256) return false;

@@ -681,12 +681,6 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
   // (Measured and dropped in round 4: starting every other workgroup of an XCD 6 / 12 / 18 us late, so that half the chip is in
   // its K loops while the other half is in its epilogues — every shape of the block slower by about the delay itself, none
   // faster: fwd proj 0.241 -> 0.246, fc1 0.678 -> 0.694, dgrad fc2 0.709 -> 0.727 ms at 12 us; gpurun_out/r4a/stagger.txt)
-#ifdef REED_STAGGER_TICKS   // diagnostic build (tools/r4/epi_phase.py): every other workgroup of an XCD starts this many 10 ns ticks late
-  if (s & 1) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < REED_STAGGER_TICKS) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
   int tm, tn;
   w_tile_of(run0 + p, ntm, ntn, a.tile_gm, tm, tn);
   int pmode = -1;   // MODE of the previous tile of this workgroup (-1: none)
@@ -872,14 +866,11 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
 }
 
-// Tile rows per XCD-local group of the workgroup -> tile map (as gemm256.hip; REED_GEMM256_GM overrides for A/B timing).
+// Tile rows per XCD-local group of the workgroup -> tile map (as gemm256.hip).
 // Measured at b = 256 (tools/_ab/gm_w4.sh): the 1152-wide outputs (4.5 column tiles) prefer groups of 2 rows — fc2 forward
 // 0.637 -> 0.618 ms, fc1 / qkv dgrads 0.564 -> 0.546 / 0.430 -> 0.417 —, the 3456- / 4608-wide ones groups of 4 (fc1 forward
 // 0.684 vs 0.720 with 2).
 int w_tile_group_rows(const GemmArgs& a) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("REED_GEMM256_GM"); forced = e ? atoi(e) : 0; }
-  if (forced > 0) return forced;
   if (cdiv(a.M, WBM) < 192) return 4;   // b = 128: 1157 (4 everywhere) vs 1151 images/s with the per-shape choice
   const int ntn = cdiv(a.N, WBN);
   return ntn <= 6 ? 2 : ntn >= 16 ? 5 : 4;   // (4608-wide: fc1 forward 0.688 -> 0.675, fc2 dgrad 0.727 -> 0.721 with 5)
@@ -906,13 +897,12 @@ double w_static_max_load(int ntm, int ntn, bool rag, int GM, int wpx) {
   return worst;
 }
 
-// REED_GEMM_PERSIST: 0 never, 1 where the static deal is balanced (default), 2 wherever the form applies (A/B)
+// mode 0: never (beside a collective; forced tile 257), 1: where the static deal is balanced (the default), 2: wherever the
+// form applies (forced tile 258: tests)
 template <int LAY, int EPI>
 int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
-  static int env_mode = -1;
-  if (env_mode < 0) { const char* e = getenv("REED_GEMM_PERSIST"); env_mode = e ? atoi(e) : 1; }
   const int forced = reed_gemm_forced_tile();   // tests: 257 = the one-shot kernel, 258 = this form wherever it applies
-  const int mode = forced == 257 ? 0 : forced == 258 ? 2 : reed_concurrent_comm() ? 0 : env_mode;
+  const int mode = forced == 257 ? 0 : forced == 258 ? 2 : reed_concurrent_comm() ? 0 : 1;
   *used = false;
   const int nt = cdiv(a.K, WBK), ntm = cdiv(a.M, WBM), ntn = cdiv(a.N, WBN);
   const int wpx = reed_num_cus() / 8;
@@ -1009,10 +999,8 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) {
   // (QuickGELU / exact-GELU epilogues stay on the 8-wave kernel: their VALU work — erff, two roundings per element — needs two
   // waves per SIMD to hide its own latency; measured 0.93 vs 0.64 ms on the ViT-L fc1 shape)
-  // round 4: each of the two is now its own instantiation (gemm_common.hpp); REED_QGELU_W4=1 sends them to this kernel (A/B)
-  static const bool qw4 = getenv("REED_QGELU_W4") && atoi(getenv("REED_QGELU_W4")) == 1;
   const bool epi_ok = layout == LAY_NT ? (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES ||
-                                          epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_RES_BF16 || epi == EPI_LS_RES || (qw4 && (epi == EPI_QGELU || epi == EPI_GELU_ERF)))
+                                          epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_RES_BF16 || epi == EPI_LS_RES)
                                        : (epi == EPI_BF16 || epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL);
   return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 && epi_ok;
 }
@@ -1056,7 +1044,7 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
   }
   const int ncu = reed_num_cus();
   // one round: every full tile gets a CU at once and the short tiles fill the rest; and the CUs should be mostly busy
-  static const double minfill = getenv("REED_WGRAD_W4_MINFILL") ? atof(getenv("REED_WGRAD_W4_MINFILL")) : 0.7;   // experiments
+  constexpr double minfill = 0.7;
   if (g.nfull > ncu || equiv > ncu || equiv < minfill * ncu) return REED_OK;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1064,9 +1052,17 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
     if (e != hipSuccess) { reed_set_error("gemm256w: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  // the static form with the ragged tiles cut along K (see TnGroupW); REED_WGRAD_W4_SPLIT=0: the dynamic form (A/B)
-  static const bool split_on = !(getenv("REED_WGRAD_W4_SPLIT") && atoi(getenv("REED_WGRAD_W4_SPLIT")) == 0);
+  // the static form with the ragged tiles cut along K (see TnGroupW).  Its partial-tile slab is ONE allocation of the process,
+  // made on the device of the first call; launches are ordered by the caller's stream (the engine issues every grouped launch of
+  // a process on one stream) and a call made with another device current falls back to gemm_tn.hip's launch
   static float* slab = nullptr;
+  static int slab_dev = -1;
+  {
+    int dev_now = -1;
+    if (hipGetDevice(&dev_now) != hipSuccess) dev_now = -1;
+    if (slab && dev_now != slab_dev) return REED_OK;
+    if (!slab) slab_dev = dev_now;
+  }
   bool k_ok = true;
   for (int i = 0; i < n; ++i)
     k_ok = k_ok && (probs[i].K % WBK) == 0 && probs[i].K >= 16 * WBK && probs[i].K / WBK < 65536 && probs[i].slab_stride == 0 &&
@@ -1074,7 +1070,7 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
   SplitReduceArgs rd;
   memset(&rd, 0, sizeof(rd));
   const int nw = ncu - g.nfull;
-  if (split_on && k_ok && g.nfull + g.nrag > ncu && nw >= 1 && nw <= 64 && (ncu & 7) == 0 && g.nrag <= 64) {
+  if (k_ok && g.nfull + g.nrag > ncu && nw >= 1 && nw <= 64 && (ncu & 7) == 0 && g.nrag <= 64) {
     if (!slab) {
       hipError_t e = hipMalloc(&slab, (size_t)SPLIT_SLOTS * SPLIT_TILE * sizeof(float));
       if (e != hipSuccess) { reed_set_error("gemm256w: cannot allocate the split slab: %s", hipGetErrorString(e)); return (int)e; }
@@ -1087,8 +1083,8 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
     const int nk = probs[0].K / WBK;
     // two vertically adjacent 256 x 128 tiles of a ragged column = one tall tile, two 128 x 256 tiles of a ragged row = one wide
     // tile (MODE 4 / 5: two half tiles' work at 1.1-1.2 of a full tile's time instead of 1.44); the bias-gradient tile of a ragged
-    // row stays a whole tile of its own; everything else is tape.  REED_WGRAD_W4_PAIRS=0: no pairs (A/B)
-    static const bool pairs_on = !(getenv("REED_WGRAD_W4_PAIRS") && atoi(getenv("REED_WGRAD_W4_PAIRS")) == 0);
+    // row stays a whole tile of its own; everything else is tape
+    constexpr bool pairs_on = true;
     auto add_cut = [&](unsigned desc, int mode, float* out, long ldc, int cols) {
       if (rd.n >= 64) return false;
       rd.out[rd.n] = out;

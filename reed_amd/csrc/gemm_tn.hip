@@ -267,222 +267,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroupArgs g) {
   else gemm_tn_body<false>(a, smem, tm, tn, 0, 1);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Round 3: the grouped weight gradients on a 128x192 tile with THREE workgroups per CU (gemm_tn3_group_kernel) — built, correct,
-// bit-identical, and 5-8 % SLOWER than the kernel above: kept as an opt-in (REED_WGRAD_TN3=1) with the measurement beside it.
-//
-// What bounds the 256x128 / 128x256 kernel above is not a pipe but the per-wave serial time of a K-tile — wait for the DMA,
-// barrier, issue 6 LDS-DMAs, 24 transposing reads, wait, 32 MFMAs: ~1540 cycles against 512 of matrix pipe — so a
-// SIMD with two waves keeps the pipe busy 1024 / 1540 whatever the order inside a wave.  A third wave per SIMD needs <= 168
-// registers per lane; the 128x64 wave tile has 128 accumulators + 48 fragment registers + the fused bias gradient's 36.  Here a
-// wave owns 64x96 (4 x 6 MFMA tiles: 96 accumulators, 10 fragments, 16 bias accumulators: ~150 registers), a workgroup of four
-// waves 128 x 192, and SiT-XL/2's shapes tile EXACTLY, in one orientation: 1152 = 9 x 128 = 6 x 192, 3456 = 27 x 128,
-// 4608 = 36 x 128 = 24 x 192 -> fc1 216 + fc2 216 + qkv 162 + proj 54 = 648 full tiles on the 768 slots of three workgroups per
-// CU, no ragged tile, no padding.  Per K-tile of 32 a wave issues 24 MFMAs for 6 LDS-DMAs (the Q operand's tile is 1.5 of the
-// [32][128] sub-tiles: the second one is half filled, its other lanes carry an offset outside the descriptor) and 20
-// transposing reads; the same LDS formats, fragment reads and accumulation order (K-tiles in sequence, one accumulator per
-// output) as the kernel above, so the results are bit-identical to it.  48 KiB of LDS per workgroup: 144 KiB per CU.
-// one transposing fragment (two ds_read_b64_tr_b16) at LDS byte address `a` + OFF / + OFF + 1024 ^ 16 (see the address algebra below)
-template <int OFF>
-__device__ __forceinline__ bf16x8 tn3_frag(unsigned a0, unsigned a1) {
-  bf16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(OFF));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <int DUMMY>
-__device__ __forceinline__ void gemm_tn3_body(const GemmArgs& a, char* smem, const int tm, const int tn) {
-  constexpr int TM = 4, TNN = 6;                 // 16x16 MFMA tiles per wave along M (64 rows) / N (96 columns)
-  constexpr int BMT = 128, BNT = 192;
-  constexpr int STAGE = 3 * SUB_BYTES;           // P [32][128] | Q [32][128] | Q [32][64 of 128]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = tm * BMT, n0 = tn * BNT;
-  const int kend = a.K;
-  const int nt = (kend + TBK - 1) / TBK;
-  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.P + m0, ((long)kend * a.ldp - m0) * 2);
-  // the Q descriptor ends with the tile's last column of the last row
-  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(a.Q + n0, ((long)(kend - 1) * a.ldq + BNT) * 2);
-  // LDS-DMA: six pieces per wave and K-tile; the lane part of the offset is loop-invariant, the K-tile's row offset goes in the
-  // instruction's scalar offset (k0 * ld * 2 bytes): six registers, no per-tile address arithmetic on the vector ALU
-  int vo[3][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int L = i * 256 + tid;
-    const int r = L >> 4, chp = L & 15;
-    const int ch = chp ^ tr_sw(r);
-    vo[0][i] = (int)(((long)r * a.ldp + ch * 8) * 2);
-    vo[1][i] = (int)(((long)r * a.ldq + ch * 8) * 2);
-    // columns 128..191: chunks 8..15 of a row are the next tile's columns — asked for out of range (the DMA writes zeros)
-    vo[2][i] = ch < 8 ? (int)(((long)r * a.ldq + 128 + ch * 8) * 2) : 0x7FFFFFF0;
-  }
-  const int sP = (int)(a.ldp * 2 * TBK), sQ = (int)(a.ldq * 2 * TBK);   // byte step of a K-tile (ld < 2^24: checked by the launcher)
-  auto stage = [&](int t, int buf) {
-    char* tp = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      char* dst = tp + (i * 256 + wave * 64) * 16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)dst, 16, vo[0][i], t * sP, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(dst + SUB_BYTES), 16, vo[1][i], t * sQ, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(dst + 2 * SUB_BYTES), 16, vo[2][i], t * sQ, 0, 0);
-    }
-  };
-  f32x4 acc[TM][TNN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TNN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 accb[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_dbias = a.dbias != nullptr && tn == 0 && wn == 0;
-  const int prow = wm * (TM * 16), pcol = wn * (TNN * 16);   // the wave's rows of the P tile, columns of the Q tile
-  // Fragment addresses without a register per read.  gemm_common.hpp's frag_tr reads element (k-row r, column c) of a [32][128]
-  // sub-tile at  r * 256 + ((c >> 3) ^ tr_sw(r)) * 16 + (c & 7) * 2  with r = 8 g + q (+ 4 for the second read) and, for the
-  // 16-column fragment at column base cb (a multiple of 16), c = cb + 4 p: chunk = (cb >> 3) + (p >> 1).  cb >> 3 is even, so the
-  // chunk is (cb >> 3) | (p >> 1) and  (chunk ^ sw) * 16 = ((cb >> 3) * 16) ^ (((p >> 1) ^ sw) * 16):  address = lane base ^ const,
-  // with ONE lane base per read row (lb0, lb1 = lb0 + 1024 with chunk bit 0 flipped: tr_sw(r + 4) = tr_sw(r) ^ 1) and the
-  // constant (cb >> 3) * 16 wave-uniform.  Sub-tile and buffer go into the DS offset field.
-  const int i16 = lane & 15, g = lane >> 4, q = i16 >> 2, pp = i16 & 3;
-  const int r0 = 8 * g + q;
-  const unsigned lds0 = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)smem;
-  const unsigned lb0 = lds0 + r0 * 256 + ((((pp >> 1) ^ tr_sw(r0)) & 15) << 4) + ((pp & 1) << 3);
-  const unsigned lb1 = lds0 + (r0 + 4) * 256 + ((((pp >> 1) ^ tr_sw(r0 + 4)) & 15) << 4) + ((pp & 1) << 3);
-  const unsigned xp = (unsigned)(prow >> 3) << 4;          // P: column base prow + 16 i  ->  const = xp ^ (i << 5)  (prow / 8 is a multiple of 8)
-  // Q: column base pcol + 16 j inside the 192-column tile; columns >= 128 live in the second Q sub-tile
-  //   wn = 0: j = 0..5 -> columns 0..95, sub-tile 0, chunk 2 j;  wn = 1: j = 0, 1 -> columns 96, 112 (chunks 12, 14), j = 2..5 -> sub-tile 1, chunks 0, 2, 4, 6
-
-  if (nt > 0) stage(0, 0);
-  __syncthreads();
-  auto ktile = [&](auto BUFC, int t) {
-    constexpr int BUF = decltype(BUFC)::value;
-    if (t + 1 < nt) stage(t + 1, BUF ^ 1);
-    constexpr int OP = BUF * STAGE, OQ0 = BUF * STAGE + SUB_BYTES, OQ1 = BUF * STAGE + 2 * SUB_BYTES;
-    bf16x8 pf[TM], qf[3];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) pf[i] = tn3_frag<OP>(lb0 ^ (xp ^ (i << 5)), lb1 ^ (xp ^ (i << 5)));
-    // first half of the wave's columns
-    if (wn == 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) qf[j] = tn3_frag<OQ0>(lb0 ^ (j << 5), lb1 ^ (j << 5));
-    } else {
-      qf[0] = tn3_frag<OQ0>(lb0 ^ (12 << 4), lb1 ^ (12 << 4));
-      qf[1] = tn3_frag<OQ0>(lb0 ^ (14 << 4), lb1 ^ (14 << 4));
-      qf[2] = tn3_frag<OQ1>(lb0, lb1);
-    }
-    REED_LDS_WAIT();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[i][j] = REED_MFMA_16x16x32(qf[j], pf[i], acc[i][j]);
-    if (do_dbias) {
-      bf16x8 ones;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) accb[i] = REED_MFMA_16x16x32(ones, pf[i], accb[i]);
-    }
-    // second half: the same three registers
-    if (wn == 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) qf[j] = tn3_frag<OQ0>(lb0 ^ ((j + 3) << 5), lb1 ^ ((j + 3) << 5));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) qf[j] = tn3_frag<OQ1>(lb0 ^ ((j + 1) << 5), lb1 ^ ((j + 1) << 5));
-    }
-    REED_LDS_WAIT();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[i][3 + j] = REED_MFMA_16x16x32(qf[j], pf[i], acc[i][3 + j]);
-    __syncthreads();
-  };
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    ktile(std::integral_constant<int, 0>{}, t);
-    ktile(std::integral_constant<int, 1>{}, t + 1);
-  }
-  if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
-  // fp32 output: pointer-path epilogue, 64 columns at a time (32 of the second group's 64 exist: N guards the rest)
-  GemmArgs e = a;
-  e.N = min(a.N, n0 + pcol + TNN * 16);      // this wave's 96 columns end here
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    f32x4 part[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) part[i][j] = (h * 4 + j < TNN) ? acc[i][h * 4 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
-    tile_epilogue_ptr<EPI_F32, TM>(e, part, m0 + prow, n0 + pcol + 64 * h, lane, 0);
-  }
-  if (do_dbias && (lane >> 4) == 0) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + prow + i * 16 + (lane & 15);
-      if (m < a.M) {
-        if (a.accumulate) a.dbias[m] += accb[i][0];
-        else a.dbias[m] = accb[i][0];
-      }
-    }
-  }
-}
-
-struct Tn3GroupArgs {
-  GemmArgs a[4];
-  int first[5];   // first tile of each problem in the sequence
-  int n;
-};
-__global__ __launch_bounds__(256, 3) void gemm_tn3_group_kernel(Tn3GroupArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // the tiles of all problems form ONE sequence (each problem column by column: the 192-column Q block is shared by consecutive
-  // workgroups) and XCD x (workgroups x, x + 8, ...) takes a contiguous eighth of it, as in the kernel above
-  const int seq = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (seq >= g.first[g.n]) return;
-  int p = 0;
-#pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < g.n && seq >= g.first[i]) p = i;
-  const int l = seq - g.first[p];
-  const GemmArgs& a = g.a[p];
-  const int ntm = a.M / 128;
-  const int tn = l / ntm, tm = l - tn * ntm;
-  gemm_tn3_body<0>(a, smem, tm, tn);
-}
-
-// the 128x192 grouped launch when every problem tiles exactly and one round of three workgroups per CU holds them
-static int launch_tn3_group(int n, const GemmArgs* probs, hipStream_t stream, int* launched) {
-  *launched = 0;
-  // measured (round 3, same box, b = 256 / 128 / 32): 2.00 / 1.07 / 0.266 ms against 1.91 / 1.00 / 0.247 for the two-per-CU kernel
-  // above — a third wave per SIMD does not buy what its smaller tile costs (and what the chip's clock gives back): off by
-  // default, REED_WGRAD_TN3=1 runs it (bit-identical results: tests/test_gemm_gpu.py::test_wgrad_group_tn3)
-  static const int on = getenv("REED_WGRAD_TN3") ? atoi(getenv("REED_WGRAD_TN3")) : 0;
-  if (!on) return REED_OK;
-  Tn3GroupArgs g;
-  memset(&g, 0, sizeof(g));
-  g.n = n;
-  int at = 0;
-  for (int i = 0; i < n; ++i) {
-    const GemmArgs& a = probs[i];
-    if (a.M % 128 || a.N % 192 || a.K != probs[0].K || a.K <= 0 || a.ldq >= (1 << 24) || a.ldp >= (1 << 24)) return REED_OK;
-    g.a[i] = a;
-    g.first[i] = at;
-    at += (a.M / 128) * (a.N / 192);
-  }
-  g.first[n] = at;
-  if (at > 3 * reed_num_cus() || at < 2 * reed_num_cus()) return REED_OK;   // more than one round / too few to fill three per CU
-  constexpr int LDS = 2 * 3 * SUB_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn3_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
-  REED_KLAUNCH(gemm_tn3_group_kernel, dim3(8 * cdiv(at, 8)), dim3(256), LDS, stream, g);
-  REED_LAUNCH_CHECK();
-  *launched = 1;
-  return REED_OK;
-}
+// (Round 3 also built the grouped weight gradients on a 128x192 tile with THREE workgroups per CU — bit-identical, and 5-8 %
+// slower than the kernel above at every batch: 2.00 / 1.07 / 0.266 ms against 1.91 / 1.00 / 0.247 at b = 256 / 128 / 32 — a third wave
+// per SIMD does not buy what its smaller tile costs; removed in round 5, DESIGN_HISTORY.md.)
 
 template <bool WIDE>
 int launch_tn(const GemmArgs& a, int splits, hipStream_t stream) {
@@ -513,16 +300,10 @@ int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) 
     const int rc = reed_gemm256w_tn_group_launch(n, probs, stream, &launched);
     if (rc != REED_OK || launched) return rc;
   }
-  {   // 128x192 tiles, three workgroups per CU, when every problem tiles exactly (SiT-XL/2 does) and one round holds them
-    int launched = 0;
-    const int rc = launch_tn3_group(n, probs, stream, &launched);
-    if (rc != REED_OK || launched) return rc;
-  }
   TnGroupArgs g;
   memset(&g, 0, sizeof(g));
   g.n = n;
-  static const int compact = getenv("REED_WGRAD_MAP") ? atoi(getenv("REED_WGRAD_MAP")) : 1;   // 0: per-problem runs (A/B)
-  g.compact = compact;
+  g.compact = 1;   // (0: per-problem runs — the A/B of round 3)
   int at = 0, padded = 0;
   for (int i = 0; i < n; ++i) {
     const GemmArgs& a = probs[i];
@@ -534,7 +315,7 @@ int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) 
     g.a[i].ksplit_len = cdiv(a.K, TBK) * TBK;
     g.wide[i] = wid < tall;
     g.first[i] = at;
-    at += compact ? min(tall, wid) : (min(tall, wid) + 7) & ~7;
+    at += g.compact ? min(tall, wid) : (min(tall, wid) + 7) & ~7;
     padded += (min(tall, wid) + 7) & ~7;
   }
   g.first[n] = at;
@@ -542,7 +323,7 @@ int reed_gemm_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream) 
     reed_set_error("wgrad_group: %d workgroups do not fit one round of %d slots", padded, 2 * reed_num_cus());
     return REED_ERR_UNSUPPORTED;
   }
-  if (compact) at = 8 * cdiv(at, 8);
+  if (g.compact) at = 8 * cdiv(at, 8);
   constexpr int LDS = 2 * 3 * SUB_BYTES;
   static bool attr_set = false;
   if (!attr_set) {

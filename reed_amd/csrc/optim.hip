@@ -184,7 +184,7 @@ extern "C" int reed_adamw_ema(float* p, const float* g, float* m, float* v, floa
   AdamArgs a{lr, beta1, beta2, eps, weight_decay, bc1, bc2, ema_decay};
   long n4 = n_total >> 2;
   int blocks = (int)((n4 + 255) / 256);
-  static const int cap = getenv("REED_ADAM_BLOCKS") && atoi(getenv("REED_ADAM_BLOCKS")) > 0 ? atoi(getenv("REED_ADAM_BLOCKS")) : 8192;
+  constexpr int cap = 8192;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   REED_KLAUNCH(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema,

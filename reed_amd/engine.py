@@ -54,7 +54,7 @@ class Engine:
         # True / False / None = auto: on when the local batch is small enough that one-round GEMM grids leave CUs idle
         # (measured on MI355X, SiT-XL/2: +3.7 % at b = 32, -1 % at 64, -5 % at 128 and 256)
         self.wgrad_stream = {"0": False, "1": True}.get(os.environ.get("REED_WGRAD_STREAM", "auto"))
-        self.wgrad_stream_max_tokens = int(os.environ.get("REED_WGRAD_STREAM_MAXTOK", "12288"))
+        self.wgrad_stream_max_tokens = 12288
         self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
         self.table_rows = model.num_classes + (1 if model.class_dropout_prob > 0 else 0)
         self._hb = 2             # bytes per element of the current build's operand arrays (set per forward / backward)
@@ -62,7 +62,11 @@ class Engine:
         # pre-activation (in the array that used to hold the pre-activation: nothing but the backward's dGELU / dSiLU epilogue
         # read it), so that backward epilogue is one multiply per element.  False: the pre-activation and the recomputing
         # epilogues (the form the round-1..4 records were measured with; tests compare the two).
-        self.save_act_grad = os.environ.get("REED_SAVE_ACT_GRAD", "1") != "0"
+        # (same-box A/B at b = 256: dgrad fc2 0.729 -> 0.659 ms, fc1 forward 0.681 -> 0.708, step 199.1 -> 197.5 ms: profiles/r5_actgrad.txt)
+        self.save_act_grad = True
+        # the attention backward's delta = rowsum(dO * O) from the epilogue of the GEMM that produces dO (False: the row kernel;
+        # tests/test_model_gpu.py::test_bench_plan_matches_the_golden_pinned_plan_at_b256 compares the two)
+        self.fused_delta = True
         self._err = None         # sticky device flag: a label outside the embedding table was seen (see check_errors)
 
     def _check_dims(self, prec):
@@ -389,18 +393,15 @@ class Engine:
         # the answer of the library ("this shape's dO GEMM has the head-dot epilogue") depends on which kernel the GEMM runs on:
         # the token count, the operand type, whether gradient buckets are being reduced beside this backward (the library then
         # keeps off the persistent kernels) and a forced tile — all in the key (a 1002 seen once under one of
-        # them was remembered for the rest of the run under the token count alone).  With REED_ATTN_BWD / REED_ATTN_BWD_W4 set
-        # (the A/B switches of the other backward kernels, honoured by reed_attention_bwd_ws only) the fused path is skipped.
+        # them was remembered for the rest of the run under the token count alone).
         # (and the CU reserve and the forms-beside-collectives switch, which the tuner cycles under one token count)
         dkey = (M, str(hdt), self.reducer is not None and self.reducer.active(), ops.gemm_forced_tile(), ops.cu_reserve(),
                 ops.comm_forms())
-        ab = os.environ.get("REED_ATTN_BWD") is not None or os.environ.get("REED_ATTN_BWD_W4", "0") == "1"
-        dot_delta = (self._dot_delta if os.environ.get("REED_ATTN_DP", "1") != "0" and hdt != torch.float32 and not ab
-                     else {dkey: False})
+        dot_delta = self._dot_delta if self.fused_delta and hdt != torch.float32 else {dkey: False}
         side = None
         if self.wgrad_stream or (self.wgrad_stream is None and M <= self.wgrad_stream_max_tokens):
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("REED_WGRAD_PRIO", "0")))
+                self._side = torch.cuda.Stream(device=dev)
             side = self._side
         dout = dout.contiguous().float()
         # -- final layer

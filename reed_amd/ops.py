@@ -219,7 +219,7 @@ def wgrad_slots():
     if torch.cuda.is_available():
         return 2 * int(_lib.load().reed_planning_cus())
     return WGRAD_SLOTS - 2 * _CU_RESERVE
-WGRAD_SPLIT_MAX = int(__import__("os").environ.get("REED_WGRAD_SPLIT_MAX", "8"))  # experiments: cap the split count
+WGRAD_SPLIT_MAX = 8
 
 
 WGRAD_TILES = ((TN, 128, 128, 1.0), (TN_TALL, 256, 128, 1.10), (TN_WIDE, 128, 256, 1.10))   # layout, rows, cols, rate

@@ -52,6 +52,9 @@ def sample_posterior(moments, latents_scale=0.18215, latents_bias=0.0, noise=Non
 
 
 class TrainStep:
+    CU_CANDIDATES = (0, 16, 32)   # CU reserves measured by REED_COMM_CUS=auto
+    TUNE_STEPS = 3                # event-timed steps per candidate (after one settling step)
+
     def __init__(self, model, loss_fn, optimizer, reducer=None, proj_coeff=0.5, repa_decay="constant",
                  repa_steps=400000, start_diffusion_steps=0, diffusion_warm_up_steps=50000,
                  diffusion_decay="constant", max_train_steps=400000, latents_scale=0.18215, latents_bias=0.0,
@@ -73,8 +76,8 @@ class TrainStep:
         # 512 workgroup slots, so the grouped weight-gradient launch gives way to the split-K path):
         #   REED_COMM_CUS unset / off   reserve 0, nothing measured (the default; bit-reproducible run to run)
         #   REED_COMM_CUS=<n>           reserve n
-        #   REED_COMM_CUS=auto          the first optimiser steps run with each candidate of REED_COMM_CUS_CANDIDATES (0,16,32):
-        #                               one settling step + REED_COMM_TUNE_STEPS (3) event-timed steps; per candidate the MEDIAN,
+        #   REED_COMM_CUS=auto          the first optimiser steps run with each candidate of CU_CANDIDATES (0, 16, 32):
+        #                               one settling step + TUNE_STEPS (3) event-timed steps; per candidate the MEDIAN,
         #                               MAX over ranks; the fastest is kept and logged on rank 0.  bench.py asks for this.
         #                               Then, at that reserve, one more candidate ("static"): the backward WITHOUT the kernel forms
         #                               ops.set_concurrent_comm selects beside a collective (ops.set_comm_forms) — they cost ~ 3 % of
@@ -105,6 +108,11 @@ class TrainStep:
         optimiser pass — so that a measurement that fails on first contact with the real interconnect cannot lose that number."""
         reducer, optimizer = self.reducer, self.opt
         mode = mode or "off"
+        if self.cu_tuning is not None or self.shard_tuning is not None or self._tune:
+            # (ADVICE round 4) a second pass would compare against the first one's records: the keep-the-fastest block is keyed on
+            # cu_tuning being unset, the "static" and "rsag" verdicts on their absence from it — refuse instead of mis-measuring
+            raise RuntimeError("TrainStep.plan_tuning: this step has already measured (or is measuring) its plan; build a new "
+                               "TrainStep to measure again")
         self._tune_shard = (shard == "auto" and reducer is not None and reducer.active()
                             and hasattr(optimizer, "set_sharded") and getattr(optimizer, "overlap", False))
         if reducer is not None and reducer.active() and (mode != "off" or self._tune_shard):
@@ -112,9 +120,9 @@ class TrainStep:
                 self.cu_reserve = int(mode)
                 ops.set_cu_reserve(self.cu_reserve)
             if mode == "auto" or self._tune_shard:
-                cands = ([int(v) for v in os.environ.get("REED_COMM_CUS_CANDIDATES", "0,16,32").split(",")] if mode == "auto"
+                cands = (list(self.CU_CANDIDATES) if mode == "auto"
                          else [self.cu_reserve])          # (only the sharded pass is measured: its replicated baseline)
-                nt = max(1, int(os.environ.get("REED_COMM_TUNE_STEPS", "3")))
+                nt = max(1, int(self.TUNE_STEPS))
                 self._tune = [(c, k) for c in cands for k in range(nt + 1)]   # k = 0: settling step, k >= 1: timed
                 self._tune_times = {}
                 if mode == "auto" and self.comm_forms:   # (REED_COMM_FORMS=0: already off, nothing to compare)

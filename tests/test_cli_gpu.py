@@ -444,7 +444,7 @@ assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, o
 # timed step each) and keeps the faster; whatever it keeps, five steps end with the parameters of five replicated steps
 def five(mode):
     os.environ["REED_OPT_SHARD"] = mode
-    os.environ["REED_COMM_TUNE_STEPS"] = "1"
+    TrainStep.TUNE_STEPS = 1
     m3, ema3, opt3 = make()
     red3 = GradReducer(m3, rank=rank, world=world)
     red3.broadcast_params(0)
@@ -664,19 +664,20 @@ def test_bench_two_ranks_rehearsal(dev):
     assert "c3_per_gpu_leg" not in d and d["scaling"] == "strong"
 
 
-def _rehearse(extra_env, timeout=900):
+def _rehearse(extra_env, timeout=900, extra_args=()):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["REED_BENCH_REHEARSE"] = "gloo"
     env.update(extra_env)
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "SiT-S/2",
-                           "--global-batch", "16", "--no-cpu-baseline", "--no-kernel-table"], env=env, capture_output=True, text=True,
-                          timeout=timeout)
+                           "--global-batch", "16", "--no-cpu-baseline", "--no-kernel-table"] + list(extra_args), env=env,
+                          capture_output=True, text=True, timeout=timeout)
 
 
 def test_bench_two_ranks_times_the_plain_plan_first(dev):
     """At N > 1 the bench times the plain plan (torch binding, all-reduce buckets, no CU reserve, replicated optimiser pass, no
     run-time measurement) through warm-up and the timed region BEFORE the tuned plan is even scheduled; both are reported, `value`
-    is the better of the two."""
+    is the plain region's unless the tuner kept a DIFFERENT plan that measured faster (two regions of one plan are two samples
+    of it: their maximum would bias the number)."""
     r = _rehearse({})
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -685,21 +686,24 @@ def test_bench_two_ranks_times_the_plain_plan_first(dev):
     pl = d["plans"]
     assert "CU reserve 0" in pl["plain"]["plan"] and "replicated" in pl["plain"]["plan"] and "allreduce" in pl["plain"]["plan"]
     assert pl["plain"]["images_per_sec"] > 0 and pl["tuned"].get("images_per_sec", 0) > 0, pl
-    best = max(pl["plain"]["images_per_sec"], pl["tuned"]["images_per_sec"])
-    assert d["value"] == best and d["plan_in_value"] in ("plain", "tuned")
+    same_plan = pl["plain"]["plan"] == pl["tuned"]["plan"]
+    best = pl["plain"]["images_per_sec"] if same_plan else max(pl["plain"]["images_per_sec"], pl["tuned"]["images_per_sec"])
+    assert d["value"] == best and d["plan_in_value"] in ("plain", "tuned") and (d["plan_in_value"] == "plain" or not same_plan)
     assert d["data_parallel"]["cu_reserve_tuning_ms"] is not None     # the tuned region did measure something
 
 
 @pytest.mark.parametrize("fail", ["raise", "hang"])
 def test_bench_keeps_the_plain_record_when_the_tuner_fails(dev, fail):
-    """A tuner that raises, or hangs (REED_TEST_TUNER_FAIL), after the plain plan was timed: rc 0, exactly one JSON line, the
+    """A tuner that raises, or hangs (bench.py --test-tuner-fail), after the plain plan was timed: rc 0, exactly one JSON line, the
     plain plan's number in it, the failure named under plans.tuned.  The hang is ended by the in-process watchdog (a timer
     thread: rank 0 prints the held record, every rank leaves with os._exit — no exec, no teardown of a wedged communicator)."""
-    r = _rehearse({"REED_TEST_TUNER_FAIL": fail, "REED_BENCH_TUNED_TIMEOUT": "25"})
+    r = _rehearse({}, extra_args=["--test-tuner-fail", fail, "--tuned-timeout", "25"])
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["plan_in_value"] == "plain" and d["value"] == d["plans"]["plain"]["images_per_sec"] > 0
     err = d["plans"]["tuned"]["error"]
-    assert ("timeout" in err) if fail == "hang" else ("REED_TEST_TUNER_FAIL" in err), err
+    assert ("timeout" in err) if fail == "hang" else ("--test-tuner-fail" in err), err
+    assert ("watchdog_fired" in d) == (fail == "hang")
+

@@ -518,41 +518,6 @@ def test_persistent_form_with_cu_reserve(dev, force_tile, reserve):
     assert torch.equal(outs[258][:M], outs[256][:M])
 
 
-def test_wgrad_group_tn3(dev):
-    """The 128x192 / three-workgroups-per-CU form of the grouped weight gradients (csrc/gemm_tn.hip:gemm_tn3_group_kernel, opt-in
-    with REED_WGRAD_TN3=1; measured slower than the default and kept for the record): run in a child process with the switch on,
-    it must reproduce the default kernel's weight and bias gradients bit for bit on the SiT-XL/2 block (648 exact tiles)."""
-    import subprocess
-    import sys
-    code = r'''
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from reed_amd import ops
-dev = torch.device("cuda")
-g = torch.Generator().manual_seed(17)
-tokens, shapes = 1024, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]
-probs = []
-for n_out, k_in in shapes:
-    dy = torch.randn(tokens, n_out, generator=g).to(torch.bfloat16).to(dev)
-    x = torch.randn(tokens, k_in, generator=g).to(torch.bfloat16).to(dev)
-    out = torch.full((n_out * k_in + n_out,), float("nan"), device=dev)
-    probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:], n_out, k_in))
-assert ops.wgrad_group(probs, tokens)
-torch.cuda.synchronize()
-torch.save([(q[2].cpu(), q[3].cpu()) for q in probs], sys.argv[2])
-'''
-    outs = []
-    for flag in ("0", "1"):
-        path = f"/tmp/reed_tn3_{os.getpid()}_{flag}.pt"
-        r = subprocess.run([sys.executable, "-c", code, os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path],
-                           env=dict(os.environ, REED_WGRAD_TN3=flag), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(torch.load(path))
-        os.remove(path)
-    for (w0, b0), (w1, b1) in zip(*outs):
-        assert torch.isfinite(w0).all() and torch.equal(w0, w1) and torch.equal(b0, b1)
-
-
 @pytest.mark.parametrize("N,K", [(1024, 1024), (4096, 1024), (1024, 4096)])
 def test_ragged_m_split_is_bit_invisible(dev, N, K, force_tile):
     """M = 64 x 257 (a ViT tower at batch 64): the dispatcher sends the 64 full tile rows and the 64 tail rows out as two

@@ -604,14 +604,14 @@ def test_bench_launcher_argv(monkeypatch):
 def test_counted_waits_of_the_attention_forward_match_the_isa():
     """attn_fwd256p_kernel waits with s_waitcnt vmcnt(N) for immediates derived from how many vector-memory instructions a wave
     issues per item: compile csrc/attention.hip to gfx950 ISA (hipcc cross-compiles here) and count them in every instantiation —
-    20 + 7 before the item loop, 15 + 7 per item, the waits in the expected order, no scratch traffic (tools/r4/check_isa.py; the
+    20 + 7 before the item loop, 15 + 7 per item, the waits in the expected order, no scratch traffic (tools/check_attn_isa.py; the
     compiler once merged seven identical prologue stores into one, which left the first item's waits six operations short)."""
     import subprocess
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r4", "check_isa.py")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_attn_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok  ") >= 9 and "BAD" not in r.stdout, r.stdout
+    assert r.stdout.count("ok  ") == 6 and "BAD" not in r.stdout, r.stdout   # hd 64 / 72 / 80 x (T = 256, T < 256)
 
 
 def test_detfill_matches_the_fixture_recipe():
@@ -636,3 +636,10 @@ def test_detfill_matches_the_fixture_recipe():
     for u, v in zip(ra[:5], rb[:5]):
         assert torch.equal(u, v)
     assert torch.equal(ra[5][0], rb[5][0])
+
+
+def test_bench_refuses_unknown_switches():
+    """A REED_* variable bench.py does not know (a typo, a switch of an older round) must stop the run before anything is timed."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=dict(os.environ, REED_GEMM_W4="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "REED_GEMM_W4" in r.stderr and not r.stdout.strip()

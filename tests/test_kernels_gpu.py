@@ -537,9 +537,10 @@ def test_fp16_library_gemm_and_attention(dev):
 
 
 @pytest.mark.parametrize("B,D,HW", [(40, 1152, 32), (3, 384, 32), (7, 1024, 32), (3, 384, 8), (5, 1152, 16), (1, 384, 8)])
-def test_embed_and_final_layer_second_forms_bit_identical(dev, monkeypatch, B, D, HW):
+def test_embed_and_final_layer_second_forms_bit_identical(dev, B, D, HW):
     """The patch-embed forward with the weight rows in registers (16-byte stores) and the final-layer forward / backward rows with
-    the weight staged in LDS per 64 rows (csrc/embed.hip) against the first forms (REED_EMBED_OLD=1): the same per-lane accumulation
+    the weight staged in LDS per 64 rows (csrc/embed.hip) against the first forms (the library's fallback for weights that are
+    not 16-byte aligned: the second run passes the same weights at an 8-byte offset): the same per-lane accumulation
     order and the same wave reductions, so every output is bit-identical.  HW = 32: B * 256 rows, always whole 64-row groups;
     HW = 8 / 16 (T = 16 / 64 tokens per image) with odd B: 48, 320 and 16 rows — the kernels' tail guards (a last group with fewer
     than 64 rows, the second half of a row pair missing)."""
@@ -557,7 +558,15 @@ def test_embed_and_final_layer_second_forms_bit_identical(dev, monkeypatch, B, D
     bf = torch.randn(16, generator=g).to(torch.bfloat16).to(dev)
     dout = torch.randn(B, C, HW, HW, generator=g).to(dev)
 
-    def run():
+    def off8(t):   # the same values at an address that is 8 (mod 16)
+        buf = torch.empty(t.numel() + 12, dtype=t.dtype, device=dev)
+        k = 4 if buf.data_ptr() % 16 == 0 else 0
+        v = buf[k:k + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 8
+        return v
+
+    def run(w, wf):
         tok = torch.full((B * T, D), float("nan"), device=dev)
         out = torch.full((B, C, HW, HW), float("nan"), device=dev)
         mean, rstd = torch.empty(B * T, device=dev), torch.empty(B * T, device=dev)
@@ -569,8 +578,7 @@ def test_embed_and_final_layer_second_forms_bit_identical(dev, monkeypatch, B, D
         torch.cuda.synchronize()
         return tok, out, mean, rstd, hbuf, dh, dlin
 
-    new = run()
-    monkeypatch.setenv("REED_EMBED_OLD", "1")
-    old = run()
+    new = run(w, wf)
+    old = run(off8(w), off8(wf))
     for a, b in zip(new, old):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)

@@ -571,7 +571,7 @@ def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
     grouped weight gradients without split-K, the ring backward with delta from the dO GEMM's epilogue), at the bench's own size:
     ONE step of SiT-XL/2 + 1024-d projector at local batch 256, four ways —
       bench   the heuristic plan (what bench.py times)
-      A       the same with the row-kernel delta (REED_ATTN_DP=0)
+      A       the same with the row-kernel delta (engine.fused_delta = False)
       B       A with every GEMM forced onto the 128^2 kernel            -> loss bit-identical; gradients too, except the K-cut ragged
                                                                             tiles of the four-wave weight gradients (<= 1e-5)
       C       B with the per-GEMM split-K weight gradients (REED_WGRAD_GROUP=0) = the plan the goldens pin
@@ -599,7 +599,7 @@ def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
     lf = SILoss(enc_names=["dinov2-vit-l"], loss_weights={"dinov2-vit-l": 1.0})
 
     def step(tile, dp, group):
-        monkeypatch.setenv("REED_ATTN_DP", dp)
+        m.engine().fused_delta = dp != "0"
         monkeypatch.setenv("REED_WGRAD_GROUP", group)
         ops.gemm_force_tile(tile)
         try:

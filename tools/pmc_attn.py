@@ -11,7 +11,7 @@ M = b * T
 bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 qkv, o, do = bf(M, 3 * D), torch.empty(M, D, dtype=torch.bfloat16, device=dev), bf(M, D)
 dqkv, lse = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev), torch.empty(b, H, T, device=dev)
-ws = None if os.environ.get("REED_ATTN_BWD") else torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
+ws = torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
 for _ in range(3):
     ops.attention_fwd(qkv, o, lse, b, T, H, hd)
     ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd, ws=ws)

@@ -32,7 +32,7 @@ for b in [int(a) for a in sys.argv[1:]] or [32, 256]:
     dqkv = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(b, H, T, device=dev)
     import os
-    ws = None if os.environ.get("REED_ATTN_BWD") else torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
+    ws = torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
     tf = timeit(lambda: ops.attention_fwd(qkv, o, lse, b, T, H, hd))
     tb = timeit(lambda: ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd, ws=ws))
     # the form the engine runs where the dO GEMM is on the four-wave 256^2 kernel: delta from that GEMM's epilogue 13 (the GEMM
