@@ -125,10 +125,10 @@ __device__ __forceinline__ bf16x8 load_frag_global(const bf16* rowptr, bool row_
   if (row_ok && col < HD) z = *(const bf16x8*)(rowptr + col);
   return z;
 }
-template <int HD>
+template <int HD, int RB = ROWB>
 __device__ __forceinline__ bf16x8 frag_rows_z(const char* tile, int row0, int ks, int lane) {
   // register-resident operand: padded k-slots (col >= HD) must be exact zeros
-  bf16x8 f = frag_rows(tile, row0, ks, lane);
+  bf16x8 f = *(const bf16x8*)(tile + (row0 + (lane & 15)) * RB + (ks * 32 + 8 * (lane >> 4)) * 2);
   if (HD % 32 != 0 && ks * 32 + 8 * (lane >> 4) >= HD) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (bf16)0.f;
@@ -1725,9 +1725,9 @@ struct RingB {
   template <int KS>
   static __device__ __forceinline__ void load(unsigned sb, unsigned kb, bf16x8& dsf, bf16x8 (&ktf)[NK]) {
     dsf = frag_trT_u<ROWB, KS * 32 * ROWB>(sb);
-    ktf[0] = frag_trT_u<ROWB, KS * 32 * ROWB>(kb);
-    if constexpr (NK > 1) ktf[1] = frag_trT_u<ROWB, KS * 32 * ROWB + 32>(kb);
-    if constexpr (NK > 2) ktf[2] = frag_trT_u<ROWB, KS * 32 * ROWB + 64>(kb);
+    ktf[0] = frag_trT_u<ROWF, KS * 32 * ROWF>(kb);
+    if constexpr (NK > 1) ktf[1] = frag_trT_u<ROWF, KS * 32 * ROWF + 32>(kb);
+    if constexpr (NK > 2) ktf[2] = frag_trT_u<ROWF, KS * 32 * ROWF + 64>(kb);
   }
   template <int KS>
   static __device__ __forceinline__ void step(unsigned sb, unsigned kb, f32x4 (&dq)[NK], bf16x8& dsc, bf16x8 (&kc)[NK], bf16x8& dsn,
@@ -1737,12 +1737,12 @@ struct RingB {
     for (int k = 0; k < NK; ++k) dq[k] = (KS == 0) ? MFMA(kc[k], dsc, zero4()) : MFMA(kc[k], dsc, dq[k]);
     ATTN_LDS_WAIT();
   }
-  // St / Kt: the dS^T and K tiles (144-byte rows); qrow0: dqkv row of the tile's first query (q part); returns after the stores
+  // St / Kt: the dS^T tile (144-byte rows) and the K tile (160-byte rows since round 5); qrow0: dqkv row of the tile's first query (q part); returns after the stores
   static __device__ __forceinline__ void run(const char* St, const char* Kt, int qtile, int lane, float scale, bf16* qrow0, long tok,
                                              bool skip) {
     const int i = lane & 15, g = lane >> 4;
     const unsigned sb = lds_addr(St + (4 * g + (i >> 2)) * ROWB + (16 * qtile + 4 * (i & 3)) * 2);
-    const unsigned kb = lds_addr(Kt + (4 * g + (i >> 2)) * ROWB + (16 * D0 + 4 * (i & 3)) * 2);
+    const unsigned kb = lds_addr(Kt + (4 * g + (i >> 2)) * ROWF + (16 * D0 + 4 * (i & 3)) * 2);
     f32x4 dq[NK];
     if (skip) {   // diagnosis: no products
 #pragma unroll
@@ -1802,8 +1802,10 @@ struct RingB {
 //   NQ + 2 NI younger) covers X2, X3 and K(n+1).  (Round 3 hard-coded the hd-72 counts 14 / 12, 9 / 8 and 3 + 2 NI for both
 //   head sizes: with hd 64's two dQ stores per chunk its waits allowed two operations too many — fixed with the counts computed.)
 // The ring slots use 160-byte rows (ROWF: conflict-free ds_read_b128 and transposing reads; with 144-byte rows 7 of the 8 rows
-// a ds_read_b128 lane group takes at g = 1 share banks with its g = 0 rows), the K and dS^T tiles keep 144 (LDS budget).
-// LDS: Q ring 20 | dO ring 20 | K x 2 72 | dS^T 36 | lse, delta x 2 4 = 152 KiB.
+// a ds_read_b128 lane group takes at g = 1 share banks with its g = 0 rows).  Round 5: the two K tiles too (the 8 KiB the
+// kernel had left: 40 pieces per tile, five per wave — the transposing reads of phase B's K^T operand and the waves' own K row
+// fragments no longer wrap a row onto the first row's banks); the dS^T tile keeps 144-byte rows: 160 would need 4 KiB the CU
+// does not have.  LDS: Q ring 20 | dO ring 20 | K x 2 80 | dS^T 36 | lse, delta x 2 4 = 160 KiB.
 template <int HD, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
@@ -1822,7 +1824,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
   char* Qr = smem;
   char* Gr = smem + 2 * CHB;
   char* Kb = smem + 4 * CHB;                        // two K tiles
-  char* St = Kb + 2 * TILE_B;
+  char* St = Kb + 2 * TILE_F;
   float* ld2 = (float*)(St + TILE_B);               // [2 items][lse2[256] | dlt[256]]
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
@@ -1859,14 +1861,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       if (pp < 20) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rs1 : rs0, (lds_ptr_t)((second ? g2 : q) + I * 1024), 16, v2, 0, 0, REED_ATTN_LD_AUX);
     }
   };
-  // a whole K tile: 36 pieces, waves 0..3 issue 5, waves 4..7 issue 4
+  // a whole K tile (160-byte rows): 40 pieces, every wave issues 5
   auto issue_k = [&](const bf16* kb, char* dst, int ln) {
     const __amdgpu_buffer_rsrc_t rs = mk_rsrc(kb, tile_window<HD>(T, tokb));
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int I = wave + 8 * j;
-      const int vo = dma_voff<HD, ROWB>(I * 64 + ln, tokb);   // (not inside the builtin's argument list: clang's host pass then drops the kernel)
-      if (I < 36) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
+      const int vo = dma_voff<HD, ROWF>(I * 64 + ln, tokb);   // (not inside the builtin's argument list: clang's host pass then drops the kernel)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
   };
   auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {
@@ -1928,7 +1930,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
     int lane = lane0;
     asm volatile("" : "+v"(lane));   // per-item copy: lane-derived addresses are not hoisted out of the item loop (and spilled)
     const int i = lane & 15, g = lane >> 4;
-    const char* Kt = Kb + par * TILE_B;
+    const char* Kt = Kb + par * TILE_F;
     const float* lse2 = ld2 + par * 512;
     const float* dlt = lse2 + 256;
     if (STAMPS && (dbg & 4)) tprev = __builtin_amdgcn_s_memtime();
@@ -1937,7 +1939,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ct][ks] = frag_rows_z<HD>(Kt, r0 + 16 * ct, ks, lane);
+      for (int ks = 0; ks < KS; ++ks) kf[ct][ks] = frag_rows_z<HD, ROWF>(Kt, r0 + 16 * ct, ks, lane);
     f32x4 dk[2][DT], dv[2][DT];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -1969,7 +1971,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
         asm volatile("" : "+v"(ln));   // fresh copy: piece offsets and row addresses are computed here, not kept in registers
         if (ch < 2) issue_chunk(base, gbase, ch + 2, ln);
         else issue_chunk(nbase, ngbase, ch - 2, ln);
-        if (has_next && ch == 0) issue_k(nbase + D, Kb + (par ^ 1) * TILE_B, ln);
+        if (has_next && ch == 0) issue_k(nbase + D, Kb + (par ^ 1) * TILE_F, ln);
         if (has_next && ch == 3) own_rows(nbase, nlbase, ndlbase, ln);   // vf of this item is dead: phase A is over
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1983,8 +1985,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       __builtin_amdgcn_sched_barrier(0);
       RING_STAMP(3);
       if (has_next) {
-        // X = this wave's pieces of a chunk (3 | 2 by half), Kp = of a K tile (5 | 4), NQ = its dQ stores per chunk (by parity)
-        const int X = wave < 4 ? 3 : 2, Kp = wave < 4 ? 5 : 4;
+        // X = this wave's pieces of a chunk (3 | 2 by half), Kp = of a K tile (5), NQ = its dQ stores per chunk (by parity)
+        const int X = wave < 4 ? 3 : 2, Kp = 5;
         const int NQ = (wave & 1) ? RingB<HD, true>::NST : RingB<HD, false>::NST;
         if (ch == 1) vmcnt_wait(Kp + X + 2 * NQ);      // chunk 2 (X0) landed; younger: K(n+1), dQ, X1, dQ
         else if (ch == 2) vmcnt_wait(X + 2 * NQ);      // chunk 3 (X1) landed; younger: dQ, X2, dQ
@@ -2205,7 +2207,7 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
                  (bf16*)dqkv, T, H, nitems, dbg);                                                                              \
   } while (0)
   if (T == 256) {
-    const int rlds = 4 * 64 * ROWF + 3 * TILE_B + 4096;
+    const int rlds = 4 * 64 * ROWF + 2 * TILE_F + TILE_B + 4096;   // 160 KiB: the whole CU
 #define REED_BWD_RING(HD)                                                                                                 \
   do {                                                                                                                    \
     static int once = set_lds(attn_bwd_ring_kernel<HD>, rlds);                                                            \

@@ -1,8 +1,8 @@
 import ctypes, os, statistics, sys, time
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reed_amd import _lib, ops
-b = 256
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda")
 D, Hm, T = 1152, 4608, 256
 shapes = [(D, Hm), (Hm, D), (D, D), (3 * D, D)]
