@@ -407,6 +407,12 @@ __global__ __launch_bounds__(LW ? 768 : 512) void gemm144_kernel(GemmArgs a) {
   if (wc == 0) strip_epilogue<EPI>(a, accx, m0 + wr * 64, n0 + 64, lane);   // columns 64 .. 79 of the tile
 }
 
+// (Round 5 built a persistent form of this kernel — one workgroup per CU walking its tiles as ONE stream of K-tiles through the ring,
+// the next tile's first two K-tiles landing under the current tile's last two and its epilogue, bit-identical in 35 test cases —
+// for the four-round launches of b = 32 per GPU (the 4608-wide outputs: 1024 tiles).  fc1 forward 0.106-0.107 -> 0.104-0.105 ms: the
+// K loop of a 256x144 tile is not waiting for its prologue but for the L2 -> LDS operand stream (50 KiB per K-tile and CU = 12.8 MB
+// per step chip-wide, 1.07 us at the ~12 TB/s that path delivers, against 0.6 us of MFMA work), and the NN instantiations need more
+// than the 168 registers three waves per SIMD leave (0.100 -> 0.156 ms with the spills).  Removed; profiles/r5_gemm144_persistent_form.txt.)
 static bool use_loader_waves() { return true; }   // (the 8-wave form without them: the epilogues that have no loader-wave instantiation)
 
 template <int LAY, int EPI>
