@@ -498,6 +498,7 @@ def loss_vs_ref_leg(dev, steps=5, B=8):
     m = SiT_models["SiT-XL/2"](z_dims=[1024], z_types=["i"], encoder_depth=8)
     detfill.fill_model(m.state_dict(), base_seed=0)
     m = m.to(dev).train()
+    m.engine().save_act_grad = True   # the activation backward of the timed b = 256 step (the engine's choice above 12288 tokens), not B = 8's
     ema = copy.deepcopy(m).requires_grad_(False).eval()
     opt = FusedAdamWEMA(m, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
     lf = SILoss(enc_names=["dinov2"], loss_weights={"dinov2": 1.0})
@@ -520,6 +521,7 @@ def loss_vs_ref_leg(dev, steps=5, B=8):
             "abs_delta_per_step_bf16": [float(round(v, 7)) for v in d_b],
             "max_abs_delta_vs_fp32_reference": float(round(d_f.max(), 7)),
             "reference_own_bf16_vs_fp32_gap": float(round(np.abs(ref_b - ref_f).max(), 7)),
+            "activation_backward": "saved derivative (the timed step's form)",
             "fixture": "tests/golden/xl2_c2.npz (tools/gen_golden.py, the imported reference; image/train.py:396-398)"}
 
 
@@ -812,7 +814,9 @@ def main():
         # roofline = the ONE kernel with the largest share of the step, timed live inside the timed region (with or without the
         # isolated kernel table, which only supplies the stand-in when the grouped launch did not run)
         n_l = sum(len(v) for v in dom.values())
-        rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm, act_grad=model.engine().save_act_grad) if not args.no_kernel_table else None
+        sag = model.engine().save_act_grad
+        sag = b * T_TOK > 12288 if sag is None else sag     # the engine's rule (engine.py)
+        rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm, act_grad=sag) if not args.no_kernel_table else None
         if n_l or rows is not None:
             if n_l:
                 tot_ms = sum(sum(v) for v in dom.values())
@@ -853,7 +857,7 @@ def main():
             out["gemm_family_isolated"] = {"tflops": round(agg, 1), "frac": round(agg * 1e12 / PEAK_BF16, 4),
                                            "ms_per_block": round(tot, 4), "table": rows,
                                            "activation_backward": "saved derivative (fc1 epilogue 14, fc2 dgrad epilogue 16)"
-                                           if model.engine().save_act_grad else "recomputed (epilogues 1 / 4)"}
+                                           if sag else "recomputed (epilogues 1 / 4)"}
         if world == 1 and not args.no_c3_leg and b != 32 and args.model == "SiT-XL/2":
             try:
                 out["c3_per_gpu_leg"] = c3_leg(step, dev, args.z_dim)

@@ -63,7 +63,11 @@ class Engine:
         # read it), so that backward epilogue is one multiply per element.  False: the pre-activation and the recomputing
         # epilogues (the form the round-1..4 records were measured with; tests compare the two).
         # (same-box A/B at b = 256: dgrad fc2 0.729 -> 0.659 ms, fc1 forward 0.681 -> 0.708, step 199.1 -> 197.5 ms: profiles/r5_actgrad.txt)
-        self.save_act_grad = True
+        # None = by the token count: on above 12288 tokens (b > 48 per GPU), where the block's GEMMs run on the four-wave 256^2
+        # kernels — one wave per SIMD, the dGELU epilogue's vector work exposed.  Below, the 256x144 kernel's two waves per SIMD
+        # hide that work already and the derivative only costs the forward: b = 32, in-step, fc1 forward 123.8 -> 136.5 us per launch
+        # against 118.1 -> 116.4 for the fc2 dgrad (profiles/r4_b32_timeline.txt, r5_b32_timeline_first.txt).
+        self.save_act_grad = None
         # the attention backward's delta = rowsum(dO * O) from the epilogue of the GEMM that produces dO (False: the row kernel;
         # tests/test_model_gpu.py::test_bench_plan_matches_the_golden_pinned_plan_at_b256 compares the two)
         self.fused_delta = True
@@ -153,10 +157,12 @@ class Engine:
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
 
-        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x, prec=prec, act_grad=self.save_act_grad) if need_grad else None
+        sag = self.save_act_grad if self.save_act_grad is not None else M > 12288
+        self._sag = sag   # (the projector forward of this call follows it)
+        tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x, prec=prec, act_grad=sag) if need_grad else None
         # epilogues of a layer whose saved array feeds the backward (gemm.h): derivative-saving forms when there is a backward
-        epi_silu = EPI_SILU_G if need_grad and self.save_act_grad else EPI_SILU
-        epi_gelu = EPI_GELU_G if need_grad and self.save_act_grad else EPI_GELU
+        epi_silu = EPI_SILU_G if need_grad and sag else EPI_SILU
+        epi_gelu = EPI_GELU_G if need_grad and sag else EPI_GELU
         # -- embedders
         tok = f32(M, D)
         ops.patch_embed_fwd(x, self.W("x_embedder.proj.weight"), self.W("x_embedder.proj.bias"), self.Wf("pos_embed"),
@@ -291,7 +297,7 @@ class Engine:
         else:
             ops.token_mean_fwd(x, xin, B, T, D)
         pre = f"projectors.{j}."
-        epi_silu = EPI_SILU_G if need_grad and self.save_act_grad else EPI_SILU
+        epi_silu = EPI_SILU_G if need_grad and self._sag else EPI_SILU
         p1p, p1 = (bf(R, Pd) if need_grad else None), bf(R, Pd)
         ops.gemm(NT, epi_silu, xin, self.W(pre + "0.weight"), R, Pd, D, p1p, D, D, Pd, C2=p1, ldc2=Pd,
                  bias=self.W(pre + "0.bias"))
