@@ -810,6 +810,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   // ---- output of item n in two parts.  stage_item: normalise, round and write O into the wave's own rows of the V tile (dead
   // after the barrier that ends PV) — the accumulators are free afterwards; store_item: whole 144-byte row pieces read back and
   // stored, V(n+1) into the rows just read back, in FRONT of the stores.
+  // (round 5) the staging image inside the wave's 32 V rows uses 144-byte rows where the head fits them: the 16 rows of an 8-byte
+  // write then share the write banks two by two instead of four by four (160-byte rows: 160 i mod 128 has four values), and the
+  // read-back of hd 72's nine 16-byte chunks per row is one contiguous run
+  constexpr int RST = HD <= 72 ? ROWB : ROWF;
   float lsev[2];
   auto stage_item = [&](const f32x4 (&ot)[2][DT], const float (&mrow)[2], const float (&lrow)[2]) {
     int lane = lane0;
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       for (int dt = 0; dt < DT; ++dt) {
         const int d = 16 * dt + 4 * g;
         const u32x2 v = {pk2(ot[qt][dt][0] * inv, ot[qt][dt][1] * inv), pk2(ot[qt][dt][2] * inv, ot[qt][dt][3] * inv)};
-        if (16 * dt + 16 <= HD || d < HD) *(u32x2*)(Vw + (16 * qt + i) * ROWF + d * 2) = v;   // (only hd 72's fifth tile is partial)
+        if (16 * dt + 16 <= HD || d < HD) *(u32x2*)(Vw + (16 * qt + i) * RST + d * 2) = v;   // (only hd 72's fifth tile is partial)
       }
       lsev[qt] = mrow[qt] * LN2 + __logf(l);
     }
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     for (int k = 0; k < 5; ++k) {
       const int qi = min(lane + 64 * k, NQ - 1);
       const int rr = qi / NCH, c = qi - rr * NCH;
-      piece[k] = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vw + rr * ROWF + c * 16)));
+      piece[k] = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vw + rr * RST + c * 16)));
     }
     ATTN_LDS_WAIT();
     issue(Vw, plus(base_of(n + G), 2 * D));
@@ -1669,9 +1673,15 @@ __device__ __forceinline__ void ring_a_half(unsigned qb, unsigned qbw, unsigned 
     }
     pb[ct] = pack2(p0, p1);
     dsb[ct] = pack2(s0, s1);
-    char* sp = St + (r0 + 16 * ct + i) * ROWB + (ql + 4 * g) * 2;
-    *(bf16x4*)sp = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
-    *(bf16x4*)(sp + 32) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
+    // dS^T tile (round 5): 128-byte rows (64 queries).  Logical (row r, 32-byte segment s, 8-byte slot p) lives at segment
+    // s ^ ((r >> 1) & 3), slot p ^ ((r & 1) | ((r >> 3) & 1) << 1): the 8 rows a half-wave of a transposing read touches (banks
+    // mod 64) lie on 8 disjoint 8-bank ranges, and the 16 rows a 16-lane group of this 8-byte write touches (banks mod 32:
+    // MI355X_MICROARCH.md, LDS) on 16 distinct slots of the 128-byte bank space.  (144-byte rows: a read's eighth row wrapped onto
+    // its first row's banks and a write's rows i, i + 8 shared a slot; profiles/r5_attn_bwd_lds.txt)
+    const int f = (i >> 1) & 3, hsl = (i & 1) | (((i >> 3) & 1) << 1);   // (r0 + 16 ct is a multiple of 16)
+    char* srow = St + (r0 + 16 * ct + i) * 128 + ((g ^ hsl) << 3);
+    *(bf16x4*)(srow + (((2 * QH) ^ f) << 5)) = __builtin_shufflevector(dsb[ct], dsb[ct], 0, 1, 2, 3);
+    *(bf16x4*)(srow + (((2 * QH + 1) ^ f) << 5)) = __builtin_shufflevector(dsb[ct], dsb[ct], 4, 5, 6, 7);
   }
   // dO^T / Q^T fragments of the half (transposed reads), then — for the first half — the next half's first tile, all in flight
   // under the MFMAs of the previous group
@@ -1724,7 +1734,7 @@ struct RingB {
   static constexpr int NST = (NK + 1) / 2;             // store instructions per chunk: pairs as dwordx4, a last odd tile as dwordx2
   template <int KS>
   static __device__ __forceinline__ void load(unsigned sb, unsigned kb, bf16x8& dsf, bf16x8 (&ktf)[NK]) {
-    dsf = frag_trT_u<ROWB, KS * 32 * ROWB>(sb);
+    dsf = frag_trT_u<128, KS * 32 * 128>(sb);
     ktf[0] = frag_trT_u<ROWF, KS * 32 * ROWF>(kb);
     if constexpr (NK > 1) ktf[1] = frag_trT_u<ROWF, KS * 32 * ROWF + 32>(kb);
     if constexpr (NK > 2) ktf[2] = frag_trT_u<ROWF, KS * 32 * ROWF + 64>(kb);
@@ -1737,11 +1747,12 @@ struct RingB {
     for (int k = 0; k < NK; ++k) dq[k] = (KS == 0) ? MFMA(kc[k], dsc, zero4()) : MFMA(kc[k], dsc, dq[k]);
     ATTN_LDS_WAIT();
   }
-  // St / Kt: the dS^T tile (144-byte rows) and the K tile (160-byte rows since round 5); qrow0: dqkv row of the tile's first query (q part); returns after the stores
+  // St / Kt: the dS^T tile (128-byte rows, swizzled 32-byte segments) and the K tile (160-byte rows); qrow0: dqkv row of the tile's first query (q part); returns after the stores
   static __device__ __forceinline__ void run(const char* St, const char* Kt, int qtile, int lane, float scale, bf16* qrow0, long tok,
                                              bool skip) {
     const int i = lane & 15, g = lane >> 4;
-    const unsigned sb = lds_addr(St + (4 * g + (i >> 2)) * ROWB + (16 * qtile + 4 * (i & 3)) * 2);
+    const unsigned sb = lds_addr(St + (4 * g + (i >> 2)) * 128 + ((qtile ^ ((2 * g + (i >> 3)) & 3)) << 5) +
+                                 (((i & 3) ^ (((i >> 2) & 1) | ((g >> 1) << 1))) << 3));
     const unsigned kb = lds_addr(Kt + (4 * g + (i >> 2)) * ROWF + (16 * D0 + 4 * (i & 3)) * 2);
     f32x4 dq[NK];
     if (skip) {   // diagnosis: no products
@@ -1805,7 +1816,8 @@ struct RingB {
 // a ds_read_b128 lane group takes at g = 1 share banks with its g = 0 rows).  Round 5: the two K tiles too (the 8 KiB the
 // kernel had left: 40 pieces per tile, five per wave — the transposing reads of phase B's K^T operand and the waves' own K row
 // fragments no longer wrap a row onto the first row's banks); the dS^T tile keeps 144-byte rows: 160 would need 4 KiB the CU
-// does not have.  LDS: Q ring 20 | dO ring 20 | K x 2 80 | dS^T 36 | lse, delta x 2 4 = 160 KiB.
+// does not have — so it went the other way: 128-byte rows (its payload: 64 queries) with the 32-byte segments XOR-swizzled by the
+// row pair, and the dK / dV staging moved to the item's dead K tile.  LDS: Q ring 20 | dO ring 20 | K x 2 80 | dS^T 32 | lse, delta x 2 4 = 156 KiB.
 template <int HD, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
@@ -1825,7 +1837,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
   char* Gr = smem + 2 * CHB;
   char* Kb = smem + 4 * CHB;                        // two K tiles
   char* St = Kb + 2 * TILE_F;
-  float* ld2 = (float*)(St + TILE_B);               // [2 items][lse2[256] | dlt[256]]
+  float* ld2 = (float*)(St + 256 * 128);            // [2 items][lse2[256] | dlt[256]]
   const float scale = rsqrtf((float)HD);
   const float sc2 = scale * LOG2E;
   const int r0 = wave * 32;
@@ -1997,7 +2009,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       ATTN_BARRIER();   // dS^T is free for the next chunk; the next chunk's ring slot is complete
       RING_STAMP(5);
     }
-    // ---------------- dK, then dV, of the wave's keys through its own rows of the dS^T tile ----------------
+    // ---------------- dK, then dV, of the wave's keys through its own rows of this item's K tile ----------------
+    // (dead since the barrier that ended the last chunk's phase B; K(n+2) is issued into it behind the next item-boundary barrier.
+    // Until round 5 the dS^T tile served here, which kept its rows at 144 bytes: a head's 72 columns.  The staging image keeps
+    // 144-byte rows inside the 40 KiB buffer: with 160 the 16 rows of an 8-byte write share four slots of the write banks)
+    char* Ks = Kb + par * TILE_F;
     int le = lane0;
     asm volatile("" : "+v"(le));
     auto stage_store = [&](const f32x4 (&acc)[2][DT], float mul, bf16* gb) {
@@ -2010,7 +2026,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
             bf16x4 a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = f2bf(acc[ct][dt][r] * mul);
-            *(bf16x4*)(St + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
+            *(bf16x4*)(Ks + (r0 + 16 * ct + i) * ROWB + d * 2) = a;
           }
         }
       constexpr int NQ = 32 * NCH;
@@ -2019,7 +2035,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       for (int k = 0; k < NI; ++k) {
         const int qi = min(le + 64 * k, NQ - 1);
         const int rr = qi / NCH, c = qi - rr * NCH;
-        const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)(St + (r0 + rr) * ROWB + c * 16);
+        const unsigned a = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)(Ks + (r0 + rr) * ROWB + c * 16);
         asm volatile("ds_read_b128 %0, %1" : "=v"(piece[k]) : "v"(a) : "memory");
       }
       ATTN_LDS_WAIT();
@@ -2207,7 +2223,7 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
                  (bf16*)dqkv, T, H, nitems, dbg);                                                                              \
   } while (0)
   if (T == 256) {
-    const int rlds = 4 * 64 * ROWF + 2 * TILE_F + TILE_B + 4096;   // 160 KiB: the whole CU
+    const int rlds = 4 * 64 * ROWF + 2 * TILE_F + 256 * 128 + 4096;   // 156 KiB
 #define REED_BWD_RING(HD)                                                                                                 \
   do {                                                                                                                    \
     static int once = set_lds(attn_bwd_ring_kernel<HD>, rlds);                                                            \
