@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
   constexpr bool PVX = FULL && HD != 80;   // exponentials inside the PV product (pvx_all); hd 80's allocation spills with it
   if (!DBGK) dbg = 0;
   // dbg bit 5 (DBGK only): shader-clock time per phase, summed over the wave's items in registers and written over the start
-  // of `lse` when the wave is done ([workgroup][wave][10] x u64; tools/r4/fwd_stamps.py) — no memory instruction inside the loop
+  // of `lse` when the wave is done ([workgroup][wave][10] x u64; tools/attn_fwd_stamps.py) — no memory instruction inside the loop
   unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define ATTN_STAMP(k)                                               \
   do {                                                              \
@@ -1844,7 +1844,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
   if ((dbg & 8) && wave >= 4) __builtin_amdgcn_s_setprio(1);    // experiment (REED_ATTN_KSP_DBG bit 3): static priority for waves 4..7
   if ((dbg & 16) && wave < 4) __builtin_amdgcn_s_setprio(1);    // (bit 4: for waves 0..3)
   // STAMPS (diagnosis instantiation, dbg bit 2): shader-clock time per phase summed over the wave's items in registers, written over
-  // the start of dqkv when the wave is done ([workgroup][wave][8] x u64; tools/r4/bwd_stamps.py); no memory instruction in the loops
+  // the start of dqkv when the wave is done ([workgroup][wave][8] x u64; tools/attn_bwd_stamps.py); no memory instruction in the loops
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define RING_STAMP(k)                                               \
   do {                                                              \

@@ -3,7 +3,7 @@
 stamped build: python tools/_ab/build_variant.py clk -DREED_CLK_PROBE).  Every tile records its
 K loop's end and the moment its last store is issued on the 100 MHz clock; the epilogue of a tile is that interval, its
 concurrency the number of tiles chip-wide whose interval contains its midpoint.
-usage: REED_HIP_LIB=tools/_ab/libreed_clk.so python tools/r4/epi_phase.py [b]"""
+usage: REED_HIP_LIB=tools/_ab/libreed_clk.so python tools/epi_phase.py [b]"""
 import ctypes
 import os
 import statistics
