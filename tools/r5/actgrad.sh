@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5, item 1: the derivative-saving epilogues (EPI_GELU_G / EPI_SILU_G / EPI_MUL) — tests, then a same-box A/B of the step
 # against the recomputing form (REED_SAVE_ACT_GRAD=0), alternating.  Output: gpurun_out/r5_actgrad.txt
+# (Ran at commit 0a480b8, where that switch existed; it is now engine.save_act_grad — None = by token count — and bench.py refuses
+# unknown REED_* variables: to repeat the A/B, check that commit out.)
 set -o pipefail
 O=gpurun_out/r5_actgrad.txt
 mkdir -p gpurun_out
