@@ -60,6 +60,14 @@ int reed_gemm(int layout, int epilogue, const void* P, int64_t ldp, const void* 
  * 128x256 tiles do not fit one round of 2 x CUs workgroups (use reed_gemm layout 3 / 4 with split_k then). */
 int reed_wgrad_group(int n, const void* const* dy, const void* const* x, float* const* dw, float* const* dbias,
                      const int* n_out, const int* k_in, int tokens, int accumulate, void* stream);
+/* Planning side of reed_wgrad_group (host arithmetic, no device call): how the 16-bit builds' one-workgroup-per-CU form of the
+ * grouped launch (csrc/gemm256w.hip: TnGroupW) deals the problems over `cus` CUs.  items[256]: entry x * (cus / 8) + j = the item of
+ * workgroup j of XCD x, 0xFFFFFFFF = none; an item = problem | mode << 2 | row unit << 6 | column unit << 14 | (valid row units - 1)
+ * << 22 | (valid column units - 1) << 24 | bias gradient << 26 in units of 128 rows / columns of dw: mode 0 = a 256 x 256 tile,
+ * 6 = 384 x 128 (+ the bias gradient of its rows), 7 = 128 x 384, 8 = the bias gradient of up to 512 rows, no output.  Returns the
+ * number of items; 0 = the form does not apply to these problems (or this build: fp32 operands) and reed_wgrad_group uses the
+ * two-workgroups-per-CU kernel (csrc/gemm_tn.hip). */
+int reed_wgrad_group_deal(int n, const int* n_out, const int* k_in, const int* has_bias, int cus, unsigned* items);
 
 /* CUs the GEMM tile heuristics plan for: the device's count (or REED_GEMM_CUS) minus a reserve for kernels that hold CUs
  * beside the GEMMs (RCCL channels during a gradient bucket).  reed_set_cu_reserve(n): n >= 0; reed_planning_cus(): the result. */

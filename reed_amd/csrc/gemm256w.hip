@@ -58,18 +58,13 @@ extern "C" int reed_clk_probe_read(unsigned long long* out, int n) {
 #ifndef REED_DB_DEAL
 #define REED_DB_DEAL 0
 #endif
-// 1: the static form's full tiles dealt so that the bias-gradient tiles run on the even XCDs (see the launcher); 0: compact runs in
-// problem order (A/B)
-#ifndef REED_W4_DB_EVEN
-#define REED_W4_DB_EVEN 1
-#endif
 namespace {
 using namespace gemm_detail;
 
 constexpr int WBM = 256, WBN = 256, WBK = 64;
 constexpr int HTW = 16384;                                  // half-tile bytes
 constexpr int LDS_W = 8 * HTW + 4 * EPI_STAGE_BYTES;        // 144 KiB
-constexpr int LDS_TN = 10 * HTW;                            // 160 KiB: the grouped weight gradients (tall / wide tiles: ten slots)
+constexpr int LDS_TN = 8 * HTW;                             // 128 KiB: the grouped weight gradients (four half-tiles x two K-tile buffers)
 __device__ __forceinline__ constexpr int wslotA(int h, int cur) { return (h * 2 + cur) * HTW; }
 __device__ __forceinline__ constexpr int wslotB(int h, int cur) { return (4 + h * 2 + cur) * HTW; }
 
@@ -113,30 +108,39 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
                                               const int prev_mode = -1, const int nx_mode = -1, const int nx_tm = 0,
                                               const int nx_tn = 0) {
   const bool first = prev_mode < 0;
-  // MODE 4 / 5 (TN, one-shot only; round 4): a TALL tile of 512 rows x 128 columns = two vertically adjacent MODE-1 tiles, wave w on
-  // A half-tile w x B half-tile 0, and a WIDE one of 128 x 512 = two MODE-2 tiles, A half-tile 0 x B half-tile w: 128 x 128 per wave
-  // like a full tile (the same reads per MFMA), five half-tiles per K-tile buffer = all ten 16 KiB slots of the LDS
-  static_assert(MODE <= 3 || (LAY == LAY_TN && PM == 0), "tall / wide tiles: weight gradients only");
+  // (MODE 4 / 5, round 4: 512 x 128 / 128 x 512 tiles on five half-tiles per K-tile, 1.13 of a full tile's time per K-tile — gone with
+  // the K-cut form of the grouped weight gradients, DESIGN_HISTORY.md)
+  // MODE 6 / 7 / 8 (TN, one-shot only; round 6: the grouped weight gradients' ragged work as WHOLE-K items that keep a full tile's
+  // pace, so that they walk the tokens in step with the full tiles of their rows and take those tiles' operand panels from the
+  // XCD's L2 — see TnGroupW): 6 = 384 rows x 128 columns, waves 0..2 on A half-tile w x B half-tile 0 (128 x 128 each, the full
+  // tile's instruction stream; four half-tiles per K-tile like a full tile), 7 = 128 x 384, A half-tile 0 x B half-tile w; wave 3
+  // owns no output: it stages its share of the K-tiles, keeps the barriers, and forms the BIAS GRADIENT of the item's rows (one
+  // MFMA per row tile and k-step against a fragment of ones: 24 / 8 per k-step where a computing wave issues 64).  8 = no output at
+  // all: four A half-tiles (512 rows of dY), every wave the bias gradient of one.  tm / tn of these modes count 128-row / -column
+  // units; rows / columns past a.M / a.N are computed and not stored.
+  static_assert(MODE <= 3 || (MODE >= 6 && MODE <= 8 && LAY == LAY_TN && PM == 0), "three-unit / bias-only items: weight gradients only");
   constexpr bool RN = MODE <= 3 && (MODE & 1) != 0, RM = MODE <= 3 && (MODE & 2) != 0;
   constexpr int NA = RN ? 4 : 8;              // 16-row tiles per wave
   constexpr int NB = RM ? 4 : 8;              // 16-column tiles per wave
   constexpr int NCH = NA * NB / 4;            // chunks of 4 MFMAs per phase
   constexpr int NF = NA + NB;                 // fragment reads per k-step
-  constexpr int NAH = MODE == 4 ? 4 : (MODE == 5 || RM) ? 1 : 2;   // A / B half-tiles staged per K-tile
-  constexpr int NBH = MODE == 5 ? 4 : (MODE == 4 || RN) ? 1 : 2;
+  constexpr int NAH = MODE == 8 ? 4 : MODE == 6 ? 3 : (MODE == 7 || RM) ? 1 : 2;   // A / B half-tiles staged per K-tile
+  constexpr int NBH = MODE == 7 ? 3 : MODE == 8 ? 0 : (MODE == 6 || RN) ? 1 : 2;
   constexpr int ND = 4 * (NAH + NBH);         // DMA instructions per K-tile per wave
   constexpr bool A_TR = LAY == LAY_TN, B_TR = LAY != LAY_NT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int aHalf = MODE == 4 ? wave : (MODE == 0 || MODE == 1) ? (wave >> 1) : 0;
+  // the waves that form a bias gradient instead of a piece of the output (MODE 6 / 7: wave 3, MODE 8: all)
+  const bool brole = MODE == 8 || ((MODE == 6 || MODE == 7) && wave == 3);
+  const int aHalf = (MODE == 6 || MODE == 8) ? wave : (MODE == 0 || MODE == 1) ? (wave >> 1) : 0;
   const int aQuart = MODE == 1 ? (wave & 1) : MODE == 3 ? (wave >> 1) : 0;
-  const int bHalf = MODE == 5 ? wave : MODE == 0 ? (wave & 1) : MODE == 2 ? (wave >> 1) : 0;
+  const int bHalf = MODE == 7 ? wave : MODE == 0 ? (wave & 1) : MODE == 2 ? (wave >> 1) : 0;
   const int bQuart = (MODE == 2 || MODE == 3) ? (wave & 1) : 0;
-  // LDS slot of half-tile h of buffer cur (modes 0-3: A 0..3, B 4..7; tall: A 0..7, B 8..9; wide: B 0..7, A 8..9)
-  auto slotA = [](int h, int cur) constexpr { return MODE == 5 ? (8 + cur) * HTW : wslotA(h, cur); };
-  auto slotB = [](int h, int cur) constexpr { return MODE == 4 ? (8 + cur) * HTW : MODE == 5 ? (h * 2 + cur) * HTW : wslotB(h, cur); };
+  // LDS slot of half-tile h of buffer cur (modes 0-3: A 0..3, B 4..7; 6: A 0..5, B 6..7; 7: B 0..5, A 6..7; 8: A 0..7)
+  auto slotA = [](int h, int cur) constexpr { return MODE == 7 ? (6 + cur) * HTW : wslotA(h, cur); };
+  auto slotB = [](int h, int cur) constexpr { return MODE == 6 ? (6 + cur) * HTW : MODE == 7 ? (h * 2 + cur) * HTW : wslotB(h, cur); };
   const int mrow = aHalf * 128 + aQuart * 64, ncol = bHalf * 128 + bQuart * 64;
-  const int m0 = tm * WBM, n0 = tn * WBN;
+  const int m0 = MODE >= 6 ? tm * 128 : tm * WBM, n0 = MODE >= 6 ? tn * 128 : tn * WBN;
   const int nt = (a.K + WBK - 1) / WBK;
 
   __amdgpu_buffer_rsrc_t rsP, rsQ;
@@ -219,6 +223,17 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   // no bit in 5..7, where the slot swizzle and the tile index live — one vector instruction per read instead of add / xor / add
   const unsigned lds0 = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)smem;   // a multiple of 256 at least
   unsigned uA0 = lds0 + tA0 + tSA, uA1 = lds0 + ((tA0 + 1024) ^ 16) + tSA, uB0 = lds0 + tB0 + tSB, uB1 = lds0 + ((tB0 + 1024) ^ 16) + tSB;
+  // the bias role's read bases: the A half-tiles whose column sums it forms (MODE 6: 0..2, MODE 7: 0, MODE 8: the wave's own)
+  constexpr int NBR = MODE == 6 ? 3 : 1;
+  unsigned ubA0[NBR], ubA1[NBR];
+  if constexpr (MODE >= 6) {
+#pragma unroll
+    for (int h = 0; h < NBR; ++h) {
+      const int sb = slotA(MODE == 6 ? h : MODE == 8 ? wave : 0, 0) + trow;
+      ubA0[h] = lds0 + sb + (xe << 5);
+      ubA1[h] = lds0 + ((sb + 1024) ^ 16) + (xe << 5);
+    }
+  }
 
   bf16x8 Af[2][NA], Bf[2][NB];
   auto ldA = [&](int cur, int ks, int i) {
@@ -299,7 +314,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   int db_par = -1;
   bf16x8 ones;
   if constexpr (LAY == LAY_TN) {
-    do_dbias = a.dbias != nullptr && tn == 0 && ncol == 0;
+    do_dbias = MODE < 6 && a.dbias != nullptr && tn == 0 && ncol == 0;   // (MODE >= 6: the bias role's waves, not the computing ones)
     if (MODE == 0 && PM == 0 && REED_TN_RING && REED_DB_DEAL && a.dbias != nullptr && a.N / WBN >= 4) {
       // a matrix with at least four full tile columns: the bias gradient of a tile row's 16 row tiles is dealt over its first
       // four tiles — tile tn takes row tiles 2 tn, 2 tn + 1 of each A half-tile, in the wave that owns the tile's first columns:
@@ -314,6 +329,12 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     for (int i = 0; i < NA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+  }
+  f32x4 accB[MODE >= 6 ? NBR * 8 : 1];   // the bias role's sums (VGPRs): row tile i of its half-tile h in accB[8 h + i]
+  const bool bias_on = MODE >= 6 && a.dbias != nullptr;
+  if constexpr (MODE >= 6) {
+#pragma unroll
+    for (int i = 0; i < NBR * 8; ++i) accB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   // chunk c = 4 MFMAs: row tile CI(c), column tiles CJ(c) .. + 3
@@ -397,6 +418,30 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     WSTAMP(2);                                                                             \
   } while (0)
 
+  // bias role (MODE >= 6): the column sums of slice (cur, ks) of its A half-tiles — read, waited for and added within the phase
+  // (the computing waves read a slice one phase before its MFMAs; this wave has no MFMA stream to hide a read behind and a
+  // tenth of their work)
+  auto bias_step = [&](int cur, int ks, bool on) {
+    if constexpr (MODE >= 6) {
+      if (!bias_on) return;
+#pragma unroll
+      for (int h = 0; h < NBR; ++h) {
+        bf16x8 f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned q0 = ubA0[h] ^ (unsigned)(i << 5), q1 = ubA1[h] ^ (unsigned)(i << 5);
+          if (cur == 0) f[i] = ks ? wtr2u<8192>(q0, q1) : wtr2u<0>(q0, q1);
+          else f[i] = ks ? wtr2u<HTW + 8192>(q0, q1) : wtr2u<HTW>(q0, q1);
+        }
+        WLGKM0();
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) REED_MFMA_ACC_V(accB[h * 8 + i], ones, f[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   // PM: the previous tile staged this tile's K-tiles 0 and 1 beside its last two K-tiles; its epilogue's loads and stores are
   // YOUNGER than those DMAs in the same vmcnt: everything is drained here and at K-tile 0.
   if (PM != 0 && !first) {
@@ -418,8 +463,11 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     WBARRIER();
+    if (MODE >= 6 && brole) bias_step(0, 0, true);
+    else {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
+      for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
+    }
   }
 #ifdef REED_CLK_PROBE
   unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
@@ -502,7 +550,30 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       }
       if (t < nt) { WRING(t, 0); ++t; }
     };
-    if (!do_dbias) ring(std::integral_constant<int, 0>{});
+    // the bias role's walk: the same waits, barriers and DMA pieces per phase; its reads and MFMAs are bias_step's
+#define WRINGB(T, CUR)                                                                       \
+  do {                                                                                       \
+    const int t_ = (T);                                                                      \
+    ring_wait(false);                                                                        \
+    WBARRIER();                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) dmas32(t_ + 2, (CUR), 0, c);             \
+    bias_step((CUR), 1, true);                                                               \
+    ring_wait(t_ == 0);                                                                      \
+    WBARRIER();                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) dmas32(t_ + 2, (CUR), 1, c);             \
+    bias_step(1 - (CUR), 0, t_ + 1 < nt);                                                    \
+  } while (0)
+    auto ring_bias = [&]() {
+      for (; t + 1 < nt; t += 2) {
+        WRINGB(t, 0);
+        WRINGB(t + 1, 1);
+      }
+      if (t < nt) { WRINGB(t, 0); ++t; }
+    };
+#undef WRINGB
+    if constexpr (MODE == 8) ring_bias();
+    else if (MODE >= 6 && brole) ring_bias();
+    else if (!do_dbias) ring(std::integral_constant<int, 0>{});
     else if (db_par < 0) ring(std::integral_constant<int, 1>{});
     else if constexpr (MODE == 0) {
       if (db_par == 0) ring(std::integral_constant<int, 2>{});
@@ -575,6 +646,23 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     }
   }
 #endif
+  if constexpr (MODE >= 6) {   // the bias role owns no output: its column sums, one row per lane of the first 16
+    if (brole) {
+      if (bias_on && (lane >> 4) == 0) {
+#pragma unroll
+        for (int h = 0; h < NBR; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int m = m0 + (MODE == 6 ? h : MODE == 8 ? wave : 0) * 128 + i * 16 + (lane & 15);
+            if (m < a.M) {
+              if (a.accumulate) a.dbias[m] += accB[h * 8 + i][0];
+              else a.dbias[m] = accB[h * 8 + i][0];
+            }
+          }
+      }
+      return;
+    }
+  }
   // epilogue: the wave's piece in 64-column groups through gemm_common.hpp's tile_epilogue (fp32 outputs: its pointer path)
   char* stage = smem + 8 * HTW + wave * EPI_STAGE_BYTES;
 #pragma unroll
@@ -718,152 +806,55 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
   }
 }
 
-// ---- the weight gradients of one transformer block in one launch: 256^2 tiles of all (<= 4) problems, one per CU ----------
-// SiT-XL/2: fc1 4608x1152, fc2 1152x4608, qkv 3456x1152, proj 1152x1152 = 212 full tiles + 63 ragged ones (half / quarter
-// tiles: 243 tile equivalents for 256 CUs).  Workgroup order: every XCD gets a contiguous run of the full tiles (shared
-// operand column blocks stay in its L2), then a run of the ragged ones — the hardware dispatches in blockIdx order, so the
-// 275 - 256 workgroups that do not fit at once are short ones and start when the first short ones finish, at half time.
-// Round 4: the census.  A block's four weight matrices are 212 full + 61 half + 2 quarter tiles: 275 workgroups for 256 CUs — 34-35
-// per XCD of 32 CUs, and the hardware hands workgroup b to XCD b % 8: in every XCD three ragged tiles wait for the first ragged ones
-// to finish and the launch takes two ragged-tile times (1.8 ms) with the full tiles done at 1.45 (stamps: profiles/r4_wgrad_w4_ring.txt).
-// So the half tiles (MODE 1 / 2, except a bias-gradient tile) are cut in two along K: 0.45 ms pieces that fill the 5-6 CUs an XCD
-// has left beside its full tiles in three rounds.  The two pieces of a tile write fp32 partial tiles into a slab (plain stores,
-// local coordinates) and wgrad_split_reduce_kernel adds them in a fixed order (+ the old value when accumulating): deterministic;
-// the summation order of those tiles differs from the unsplit kernel's (two partial sums: 1e-7 relative).  Handing the pieces out as
-// workgroups of their own did not do it (the dispatcher places workgroups in order, each on XCD b % 8: 1.93 ms, the last piece
-// starting at 1.48 ms), so the form is STATIC: one workgroup per CU; in every XCD the first cf take one full tile each, the others walk
-// lists of ragged items the host has balanced (longest first: bias-gradient half tiles 2, quarter tiles 1.3, pieces 1 unit).
+// ---- the weight gradients of one transformer block in one launch: one item per CU, dealt around tile rows per XCD -----------
+// SiT-XL/2: fc1 4608x1152, fc2 1152x4608, qkv 3456x1152, proj 1152x1152 — every matrix has a 128-wide ragged edge (1152 = 4.5 x 256,
+// 3456 = 13.5 x 256): 212 full 256^2 tiles + 124 units of 128^2 along the edges, 243 tile equivalents for 256 CUs.
+// History (DESIGN_HISTORY.md): round 4 ran the edges as 256x128 / 128x256 / 512x128 / 128x512 tiles CUT ALONG K into lists that
+// filled the 44 CUs beside the full tiles, partial tiles through a slab + a reduce kernel: 1.58 ms per launch at b = 256, with 7.4 GB
+// through the L2s' memory side for 2.48 GB of operands — 3.2 GB of it the K-range pieces, which run at other token offsets than
+// anything else on their XCD and share no operand panel — at 1.64-1.77 GHz, and the launch ending with the bias-gradient full
+// tiles (one more MFMA per row tile and k-step: 1.0625 of a tile).
+// Round 6: NO cut.  Every edge is covered by items of THREE units — 384x128 along a ragged column (MODE 6), 128x384 along a ragged
+// row (MODE 7) — whose three computing waves run a full tile's instruction stream on four half-tiles per K-tile, i.e. at a full
+// tile's pace over the whole K: 42 items (12 + 12 + 9 + 3 + 3 + 3) + 212 full tiles = 254 CUs.  The items of a matrix are dealt
+// in the order of the tile rows they touch (a 384-row item right behind the full-tile rows whose dY panels it shares) and each
+// XCD takes a contiguous 1/8 of that sequence: an item walks the tokens in step with the full tiles of its rows and finds their
+// panels in the XCD's L2.  The fourth wave of an item forms the BIAS GRADIENT of its rows (the 384-row items of a matrix cover all
+// its rows), fc2 — ragged row, no ragged column — gets two bias-only items (MODE 8) for its 1024 full-tile rows: no full tile carries
+// a bias gradient any more.  No slab, no reduce kernel, and every tile is ONE K sequence: bit-identical to gemm_tn.hip's grouped
+// kernel (the K-cut form differed in fp32 summation order).
 struct TnGroupW {
   GemmArgs a[4];
   int n;
-  int fm[4], fn[4], rm[4], rn[4];   // full tile rows / columns, ragged (128-wide) last row / column present
-  int nfull, nrag;
-  int nitem;                        // > 0: static form — exactly one workgroup per CU, the ragged work is item[] dealt by the host
-  int wpx;                          // workgroups (= CUs) per XCD in that form
-  unsigned short wstart[66];        // ragged workgroup id -> its first item (wstart[id + 1]: one past its last)
-  unsigned item[176];               // p | mode << 2 | tm << 5 | tn << 13 | split << 21 | slab slot << 22 (mode 4 / 5: tall / wide pair)
-  unsigned krange[176];             // first K-tile (of 64 tokens) | K-tiles << 16 of the item
-  unsigned short fstart[9];         // static form: XCD x takes the full tiles ftab[fstart[x] .. fstart[x + 1])
-  unsigned ftab[256];               // p | tm << 2 | tn << 10
-  float* slab;                      // [slots][256 * 128] partial tiles
+  int wpx;                // workgroups (= CUs) per XCD: workgroup b is item[(b & 7) * wpx + (b >> 3)]
+  unsigned item[256];     // p | mode << 2 | row unit << 6 | column unit << 14 | (valid units - 1) of the row range << 22, of the column
+                          // range << 24 | bias gradient << 26 (units of 128; mode 0 / 6 / 7 / 8); 0xFFFFFFFF: none
 };
-constexpr int SPLIT_TILE = 512 * 128;   // a tall / wide pair; a single half tile uses the first half of its slot
-constexpr int SPLIT_SLOTS = 176;
-struct SplitReduceArgs {
-  float* out[64];      // the tile's first element in its weight-gradient matrix
-  int ldc[64];
-  short cols[64];      // 128 (a 256 x 128 or 512 x 128 tile), 256 (128 x 256) or 512 (128 x 512)
-  int nel[64];         // elements of the tile: 32768 or 65536
-  short first[64], cnt[64];   // its partial tiles: slab slots first .. first + cnt - 1, added in that order
-  int n, accumulate;
-  const float* slab;
-};
-__global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(SplitReduceArgs r) {
-  const int q = blockIdx.y, i4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // 4 consecutive columns of one row of the tile
-  if (i4 >= r.nel[q]) return;
-  const int cols = r.cols[q], row = i4 / cols, col = i4 - row * cols;
-  const float* sp = r.slab + (long)r.first[q] * SPLIT_TILE + i4;
-  f32x4 v = *(const f32x4*)sp;
-  for (int k = 1; k < r.cnt[q]; ++k) v += *(const f32x4*)(sp + (long)k * SPLIT_TILE);
-  float* o = r.out[q] + (long)row * r.ldc[q] + col;
-  if (r.accumulate) v += *(const f32x4*)o;
-  *(f32x4*)o = v;
-}
 __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int qf = g.nfull >> 3, rf = g.nfull & 7, qr = g.nrag >> 3, rr = g.nrag & 7;
-  const int cf = qf + (xcd < rf), sf = xcd * qf + min(xcd, rf);
-  const int cr = qr + (xcd < rr), sr = xcd * qr + min(xcd, rr);
-  int p = 0, tm, tn, mode;
-  int piece = -1;   // >= 0: the item is a K range of a split tile and writes slab slot `piece` (static form)
-  if (g.nitem > 0) {   // static form: the host's deal of the full tiles (see reed_gemm256w_tn_group_launch)
-    const int f0 = g.fstart[xcd], nf = g.fstart[xcd + 1] - f0;
-    if (j < nf) {
-      const unsigned e = g.ftab[f0 + j];
-      p = e & 3;
-#ifdef REED_CLK_PROBE
-      GemmArgs a = g.a[p];
-      a.act_variant = 2000 + (int)blockIdx.x;
-#else
-      const GemmArgs a = g.a[p];
-#endif
-      gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, (e >> 2) & 255, (e >> 10) & 255);
-      return;
-    }
-    const int id = g.wpx * xcd - f0 + (j - nf);   // this workgroup walks its list of ragged items
-    for (int r = g.wstart[id]; r < g.wstart[id + 1]; ++r) {
-      const unsigned it = g.item[r], kr = g.krange[r];
-      p = it & 3; mode = (it >> 2) & 7; tm = (it >> 5) & 255; tn = (it >> 13) & 255;
-      piece = ((it >> 21) & 1) ? (int)(it >> 22) : -1;
-      GemmArgs a = g.a[p];
-#ifdef REED_CLK_PROBE
-      a.act_variant = 1000 + r;
-#endif
-      if (piece >= 0) {   // a sub-problem in local coordinates: the tile's rows x columns of C from the item's range of tokens
-        const long k0 = (long)(kr & 0xFFFF) * WBK;
-        a.P += k0 * a.ldp + tm * WBM;
-        a.Q += k0 * a.ldq + tn * WBN;
-        a.K = (int)(kr >> 16) * WBK;
-        a.M = mode == 1 ? WBM : mode == 4 ? 2 * WBM : 128;
-        a.N = mode == 2 ? WBN : mode == 5 ? 2 * WBN : 128;
-        a.C = g.slab + (long)piece * SPLIT_TILE;
-        a.ldc = a.N;
-        a.dbias = nullptr;
-        a.accumulate = 0;
-        tm = 0;
-        tn = 0;
-      }
-      if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
-      else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);
-      else if (mode == 4) gemm256w_body<LAY_TN, EPI_F32, 4>(a, smem, tm, tn);
-      else if (mode == 5) gemm256w_body<LAY_TN, EPI_F32, 5>(a, smem, tm, tn);
-      else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
-      __syncthreads();   // every wave is out of the item's last K-tile before the next item's first DMA
-    }
-    return;
-  } else if (j < cf) {
-    int F = sf + j;
-    while (p < g.n - 1 && F >= g.fm[p] * g.fn[p]) { F -= g.fm[p] * g.fn[p]; ++p; }
-    // the shorter side of the tile grid runs fastest: an XCD's run of 26-27 consecutive tiles is then a compact block (fc2's 4 x 18
-    // grid: 7 columns x 4 rows = 11 operand panels of 33 MB instead of 2 rows + 18 columns = 20; PMC: 8.7 GB fetched per launch
-    // in row-major order, 5 TB/s of HBM)
-    if (g.fm[p] < g.fn[p]) {
-      tn = F / g.fm[p];
-      tm = F - tn * g.fm[p];
-    } else {
-      tm = F / g.fn[p];
-      tn = F - tm * g.fn[p];
-    }
-    mode = 0;
-  } else {
-    if (g.nitem > 0 || j - cf >= cr) return;
-    int R = sr + (j - cf);
-    for (;;) {
-      const int nr = g.rn[p] * g.fm[p] + g.rm[p] * g.fn[p] + g.rm[p] * g.rn[p];
-      if (p == g.n - 1 || R < nr) break;
-      R -= nr;
-      ++p;
-    }
-    if (R < g.rn[p] * g.fm[p]) { tm = R; tn = g.fn[p]; mode = 1; }
-    else {
-      R -= g.rn[p] * g.fm[p];
-      if (R < g.rm[p] * g.fn[p]) { tm = g.fm[p]; tn = R; mode = 2; }
-      else { tm = g.fm[p]; tn = g.fn[p]; mode = 3; }
-    }
-  }
+  const unsigned it = g.item[(blockIdx.x & 7) * g.wpx + (blockIdx.x >> 3)];
+  if (it == 0xFFFFFFFFu) return;
+  const int p = it & 3, mode = (it >> 2) & 15, mu = (it >> 6) & 255, nu = (it >> 14) & 255;
+  const int vm = ((it >> 22) & 3) + 1, vn = ((it >> 24) & 3) + 1;
   // by value: through a reference into the kernel-argument array the compiler re-loads M, N, ldc (s_load + lgkmcnt(0)) in the
   // middle of the hand-placed K loop, where the SIMD's only wave then stands still (tools/isa_sload_scan.py)
-#ifdef REED_CLK_PROBE
   GemmArgs a = g.a[p];
+  if (((it >> 26) & 1) == 0) a.dbias = nullptr;
+#ifdef REED_CLK_PROBE
   a.act_variant = 2000 + (int)blockIdx.x;
-#else
-  const GemmArgs a = g.a[p];
 #endif
-  if (mode == 0) gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, tm, tn);
-  else if (mode == 1) gemm256w_body<LAY_TN, EPI_F32, 1>(a, smem, tm, tn);
-  else if (mode == 2) gemm256w_body<LAY_TN, EPI_F32, 2>(a, smem, tm, tn);
-  else gemm256w_body<LAY_TN, EPI_F32, 3>(a, smem, tm, tn);
+  if (mode == 0) {
+    gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, mu >> 1, nu >> 1);
+  } else if (mode == 6) {
+    a.M = min(a.M, (mu + vm) * 128);
+    gemm256w_body<LAY_TN, EPI_F32, 6>(a, smem, mu, nu);
+  } else if (mode == 7) {
+    a.N = min(a.N, (nu + vn) * 128);
+    gemm256w_body<LAY_TN, EPI_F32, 7>(a, smem, mu, nu);
+  } else {
+    a.M = min(a.M, (mu + vm) * 128);
+    gemm256w_body<LAY_TN, EPI_F32, 8>(a, smem, mu, 0);
+  }
 }
 
 // Tile rows per XCD-local group of the workgroup -> tile map (as gemm256.hip).
@@ -1012,218 +1003,106 @@ int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream) {
 
 int reed_gemm_forced_tile();  // gemm.hip
 
+// The deal of the grouped weight gradients (TnGroupW): n problems dw_i [M_i, N_i] with or without a bias gradient on `ncu` CUs.
+// Fills item[256] in the kernel's layout (XCD x, workgroup j of it -> item[x * (ncu / 8) + j]; 0xFFFFFFFF = none) and returns the
+// number of items, 0 where the form does not apply (the items do not fit one round of CUs, or fill it too thinly).  Host arithmetic
+// only: reed_wgrad_group_deal exposes it to the planning side and to the CPU tests.
+static int w4_deal(int n, const int* M, const int* N, const int* has_db, int ncu, unsigned* item) {
+  if (n < 1 || n > 4 || ncu < 8 || (ncu & 7) != 0 || ncu > 256) return 0;
+  const int wpx = ncu / 8;
+  auto pack = [](int p, int mode, int mu, int nu, int vm, int vn, int db) {
+    return (unsigned)(p | mode << 2 | mu << 6 | nu << 14 | (vm - 1) << 22 | (vn - 1) << 24 | db << 26);
+  };
+  // pass 1: the census — items without the bias-only ones, and how many of those the matrices without a ragged column would take
+  int count = 0, bias_only = 0;
+  double equiv = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (M[i] <= 0 || N[i] <= 0 || M[i] % 128 || N[i] % 128 || M[i] / 128 > 255 || N[i] / 128 > 255) return 0;
+    const int Mu = M[i] / 128, Nu = N[i] / 128, fm = Mu / 2, fn = Nu / 2, rm = Mu & 1, rn = Nu & 1;
+    count += fm * fn + (rn ? cdiv(Mu, 3) : 0) + (rm ? cdiv(2 * fn, 3) : 0);
+    if (has_db[i] && !rn) bias_only += cdiv(2 * fm, 4);
+    equiv += 0.25 * Mu * Nu;
+  }
+  // one round: every item gets a CU at once, and the CUs should be mostly busy
+  constexpr double minfill = 0.7;
+  if (count > ncu || equiv < minfill * ncu) return 0;
+  const bool use_bias_only = count + bias_only <= ncu;   // otherwise those matrices' first tile column carries the extra MFMA
+  // pass 2: every matrix's items in the order of the tile rows (columns) they touch, the matrices one after the other
+  std::vector<unsigned> seq;
+  for (int i = 0; i < n; ++i) {
+    const int Mu = M[i] / 128, Nu = N[i] / 128, fm = Mu / 2, fn = Nu / 2, rm = Mu & 1, rn = Nu & 1;
+    const bool colmajor = fm < fn;      // the shorter side of the tile grid runs fastest: an XCD's run is a compact block of panels
+    const int db = has_db[i] ? 1 : 0;
+    std::vector<std::pair<double, unsigned>> its;
+    for (int u = 0; u < (colmajor ? fn : fm); ++u)
+      for (int v = 0; v < (colmajor ? fm : fn); ++v) {
+        const int tm = colmajor ? v : u, tn = colmajor ? u : v;
+        its.push_back({u + 0.5, pack(i, 0, 2 * tm, 2 * tn, 2, 2, (db && !rn && !use_bias_only && tn == 0) ? 1 : 0)});
+      }
+    if (rn)   // the ragged column, corner included: 384-row items; their fourth waves form the whole matrix's bias gradient
+      for (int c = 0; 3 * c < Mu; ++c)
+        its.push_back({colmajor ? fn + 0.51 : (3 * c + 1.5) / 2.0, pack(i, 6, 3 * c, 2 * fn, std::min(3, Mu - 3 * c), 1, db)});
+    if (rm)   // the ragged row (without the corner if a ragged column took it): 384-column items
+      for (int c = 0; 3 * c < 2 * fn; ++c)
+        its.push_back({colmajor ? (3 * c + 1.5) / 2.0 : fm + 0.51,
+                       pack(i, 7, 2 * fm, 3 * c, 1, std::min(3, 2 * fn - 3 * c), (db && !rn && c == 0) ? 1 : 0)});
+    if (db && !rn && use_bias_only)
+      for (int c = 0; 4 * c < 2 * fm; ++c)
+        its.push_back({(colmajor ? fn : fm) + 1.0, pack(i, 8, 4 * c, 0, std::min(4, 2 * fm - 4 * c), 1, 1)});
+    std::stable_sort(its.begin(), its.end(),
+                     [](const std::pair<double, unsigned>& x, const std::pair<double, unsigned>& y) { return x.first < y.first; });
+    for (auto& e : its) seq.push_back(e.second);
+  }
+  const int T = (int)seq.size();
+  if (T > ncu) return 0;
+  for (int q = 0; q < 256; ++q) item[q] = 0xFFFFFFFFu;
+  for (int x = 0; x < 8; ++x) {
+    const int b = (int)((long)x * T / 8), e = (int)((long)(x + 1) * T / 8);
+    for (int q = b; q < e; ++q) item[x * wpx + (q - b)] = seq[q];
+  }
+  return T;
+}
+
+extern "C" int reed_wgrad_group_deal(int n, const int* n_out, const int* k_in, const int* has_bias, int cus, unsigned* items) {
+  if (!n_out || !k_in || !has_bias || !items) return 0;
+  return w4_deal(n, n_out, k_in, has_bias, cus, items);
+}
+
 // 1 = launched; 0 = the problems do not suit this kernel (the caller falls back to gemm_tn.hip's grouped launch)
 int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stream, int* launched) {
   *launched = 0;
-  // Round 4: the default where its static form applies (one workgroup per CU, ragged tiles cut along K: see TnGroupW) — with the
-  // K-tile buffers walked as a ring and one vector instruction per transposing read it measures 0.254-0.271 / 0.454 / 0.896 / 1.81 ms
-  // at b = 32 / 64 / 128 / 256 against 0.282-0.294 / 0.476 / 0.942 / 1.85 for gemm_tn.hip's grouped launch, and 1.72 against 1.82 ms
-  // inside the step (profiles/r4_wgrad_w4_ring.txt).  (Round 3's form of it: 2.70 ms.)  REED_WGRAD_W4=0: off; =1: also where only
-  // the dynamic form (one workgroup per tile, slower than gemm_tn.hip's) applies — A/B.
+  // The default where the items fill one round of CUs (see TnGroupW).  REED_WGRAD_W4=0: off (gemm_tn.hip's grouped launch
+  // everywhere); =1: also beside a collective — A/B.
   static const int w4mode = getenv("REED_WGRAD_W4") ? atoi(getenv("REED_WGRAD_W4")) : -1;   // -1 = auto
   if (w4mode == 0 || reed_gemm_forced_tile() == 128) return REED_OK;   // force_tile 128: gemm_tn.hip's grouped kernel (tests, A/B)
   // Beside a collective (reed_set_concurrent_comm: the data-parallel backward) the static form is the wrong shape: its workgroups
-  // take a whole CU's LDS each and every one of them carries 1 / 256 of the launch, so the ones that find their CU held by an RCCL
-  // channel start when another workgroup has finished its ENTIRE list — the launch takes twice as long (measured with a stand-in
-  // that holds 16 CUs: profiles/r4_wgrad_under_cu_hog.txt).  gemm_tn.hip's launch has half-size tiles in dynamic order: it loses
-  // what the missing CUs carried.  REED_WGRAD_W4=1 forces this kernel there too (A/B on a multi-GPU node).
+  // take a whole CU each and every one of them carries 1 / 256 of the launch, so the ones that find their CU held by an RCCL
+  // channel start when another workgroup has finished — the launch takes twice as long (measured with a stand-in that holds
+  // 16 CUs: profiles/r4_wgrad_under_cu_hog.txt).  gemm_tn.hip's launch has half-size tiles in dynamic order: it loses what the
+  // missing CUs carried.  REED_WGRAD_W4=1 forces this kernel there too (A/B on a multi-GPU node).
   if (reed_concurrent_comm() && w4mode != 1) return REED_OK;
+  if (n < 1 || n > 4) return REED_OK;
+  const int ncu = reed_num_cus();
   TnGroupW g;
   memset(&g, 0, sizeof(g));
-  g.n = n;
-  double equiv = 0.0;
+  int M[4], N[4], db[4];
   for (int i = 0; i < n; ++i) {
     const GemmArgs& a = probs[i];
-    if (a.M % 128 || a.N % 128 || a.K < 2 * WBK) return REED_OK;
+    if (a.K < 2 * WBK || a.slab_stride != 0 || a.K != probs[0].K) return REED_OK;
+    M[i] = a.M; N[i] = a.N; db[i] = a.dbias != nullptr;
     g.a[i] = a;
-    g.fm[i] = a.M / 256; g.fn[i] = a.N / 256;
-    g.rm[i] = (a.M % 256) != 0; g.rn[i] = (a.N % 256) != 0;
-    g.nfull += g.fm[i] * g.fn[i];
-    g.nrag += g.rn[i] * g.fm[i] + g.rm[i] * g.fn[i] + g.rm[i] * g.rn[i];
-    equiv += g.fm[i] * g.fn[i] + 0.5 * (g.rn[i] * g.fm[i] + g.rm[i] * g.fn[i]) + 0.25 * g.rm[i] * g.rn[i];
   }
-  const int ncu = reed_num_cus();
-  // one round: every full tile gets a CU at once and the short tiles fill the rest; and the CUs should be mostly busy
-  constexpr double minfill = 0.7;
-  if (g.nfull > ncu || equiv > ncu || equiv < minfill * ncu) return REED_OK;
+  if (w4_deal(n, M, N, db, ncu, g.item) == 0) return REED_OK;
+  g.n = n;
+  g.wpx = ncu / 8;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
     if (e != hipSuccess) { reed_set_error("gemm256w: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  // the static form with the ragged tiles cut along K (see TnGroupW).  Its partial-tile slab is ONE allocation of the process,
-  // made on the device of the first call; launches are ordered by the caller's stream (the engine issues every grouped launch of
-  // a process on one stream) and a call made with another device current falls back to gemm_tn.hip's launch
-  static float* slab = nullptr;
-  static int slab_dev = -1;
-  {
-    int dev_now = -1;
-    if (hipGetDevice(&dev_now) != hipSuccess) dev_now = -1;
-    if (slab && dev_now != slab_dev) return REED_OK;
-    if (!slab) slab_dev = dev_now;
-  }
-  bool k_ok = true;
-  for (int i = 0; i < n; ++i)
-    k_ok = k_ok && (probs[i].K % WBK) == 0 && probs[i].K >= 16 * WBK && probs[i].K / WBK < 65536 && probs[i].slab_stride == 0 &&
-           probs[i].K == probs[0].K;
-  SplitReduceArgs rd;
-  memset(&rd, 0, sizeof(rd));
-  const int nw = ncu - g.nfull;
-  if (k_ok && g.nfull + g.nrag > ncu && nw >= 1 && nw <= 64 && (ncu & 7) == 0 && g.nrag <= 64) {
-    if (!slab) {
-      hipError_t e = hipMalloc(&slab, (size_t)SPLIT_SLOTS * SPLIT_TILE * sizeof(float));
-      if (e != hipSuccess) { reed_set_error("gemm256w: cannot allocate the split slab: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    // cost of a K-tile of a ragged tile relative to a 256 x 128 one (stamps: 1978 / 1853 / 1323 cycles)
-    const double wmode[6] = {0.0, 1.0, 0.94, 0.67, 1.6, 1.6};   // (a tall / wide pair: 1.1-1.2 of a full tile's 2688 cycles)
-    struct Tile { unsigned desc; int mode; bool whole; int entry; };
-    std::vector<Tile> whole, cut;
-    auto pack = [](int p, int mode, int tm, int tn) { return (unsigned)(p | mode << 2 | tm << 5 | tn << 13); };
-    const int nk = probs[0].K / WBK;
-    // two vertically adjacent 256 x 128 tiles of a ragged column = one tall tile, two 128 x 256 tiles of a ragged row = one wide
-    // tile (MODE 4 / 5: two half tiles' work at 1.1-1.2 of a full tile's time instead of 1.44); the bias-gradient tile of a ragged
-    // row stays a whole tile of its own; everything else is tape
-    constexpr bool pairs_on = true;
-    auto add_cut = [&](unsigned desc, int mode, float* out, long ldc, int cols) {
-      if (rd.n >= 64) return false;
-      rd.out[rd.n] = out;
-      rd.ldc[rd.n] = (int)ldc;
-      rd.cols[rd.n] = (short)cols;
-      rd.nel[rd.n] = (mode >= 4 ? 2 : 1) * 32768;
-      cut.push_back({desc, mode, false, rd.n++});
-      return true;
-    };
-    bool room = true;
-    for (int i = 0; i < n && room; ++i) {
-      float* C = (float*)probs[i].C;
-      const long ldc = probs[i].ldc;
-      if (g.rn[i]) {   // the ragged column: tiles (tm, fn), 256 rows x 128 columns
-        int tm = 0;
-        if (pairs_on)
-          for (; tm + 1 < g.fm[i] && room; tm += 2) room = add_cut(pack(i, 4, tm, g.fn[i]), 4, C + (long)tm * WBM * ldc + (long)g.fn[i] * WBN, ldc, 128);
-        for (; tm < g.fm[i] && room; ++tm) room = add_cut(pack(i, 1, tm, g.fn[i]), 1, C + (long)tm * WBM * ldc + (long)g.fn[i] * WBN, ldc, 128);
-      }
-      if (g.rm[i]) {   // the ragged row: tiles (fm, tn), 128 rows x 256 columns
-        int tn = 0;
-        if (probs[i].dbias) { whole.push_back({pack(i, 2, g.fm[i], 0), 2, true, -1}); tn = 1; }
-        if (pairs_on)
-          for (; tn + 1 < g.fn[i] && room; tn += 2) room = add_cut(pack(i, 5, g.fm[i], tn), 5, C + (long)g.fm[i] * WBM * ldc + (long)tn * WBN, ldc, 512);
-        for (; tn < g.fn[i] && room; ++tn) room = add_cut(pack(i, 2, g.fm[i], tn), 2, C + (long)g.fm[i] * WBM * ldc + (long)tn * WBN, ldc, 256);
-      }
-      if (g.rm[i] && g.rn[i]) whole.push_back({pack(i, 3, g.fm[i], g.fn[i]), 3, true, -1});
-    }
-    double total = 0.0;
-    for (const Tile& t : whole) total += wmode[t.mode] * nk;
-    for (const Tile& t : cut) total += wmode[t.mode] * nk;
-    const double target = total / nw;
-    std::vector<std::vector<std::pair<unsigned, unsigned>>> lists(nw);
-    std::vector<double> load(nw, 0.0);
-    // the tiles that stay whole (bias-gradient half tiles, quarter tiles) open a workgroup's list each
-    std::stable_sort(whole.begin(), whole.end(), [&](const Tile& x, const Tile& y) { return wmode[x.mode] > wmode[y.mode]; });
-    int kw = 0;
-    for (const Tile& t : whole) {
-      lists[kw % nw].push_back({t.desc, (unsigned)nk << 16});
-      load[kw % nw] += wmode[t.mode] * nk;
-      ++kw;
-    }
-    // the rest as one tape of K-tiles, cut where a workgroup's share is full (pieces of at least 8 K-tiles)
-    int slot = 0, k = 0;
-    bool fits = true;
-    for (const Tile& t : cut) {
-      int k0 = 0, pieces = 0;
-      rd.first[t.entry] = (short)slot;
-      while (k0 < nk) {
-        while (k < nw - 1 && (target - load[k]) / wmode[t.mode] < 8.0) ++k;
-        int take = k == nw - 1 ? nk - k0 : std::min(nk - k0, (int)((target - load[k]) / wmode[t.mode] + 0.5));
-        if (nk - k0 - take < 8) take = nk - k0;
-        if (slot >= SPLIT_SLOTS) { fits = false; break; }
-        lists[k].push_back({t.desc | 1u << 21 | (unsigned)slot << 22, (unsigned)k0 | (unsigned)take << 16});
-        load[k] += wmode[t.mode] * take;
-        k0 += take;
-        ++slot;
-        ++pieces;
-      }
-      rd.cnt[t.entry] = (short)pieces;
-    }
-    g.nitem = 0;
-    for (int w = 0; w < nw && fits; ++w) {
-      g.wstart[w] = (unsigned short)g.nitem;
-      for (auto& it : lists[w]) {
-        if (g.nitem >= 176) { fits = false; break; }
-        g.item[g.nitem] = it.first;
-        g.krange[g.nitem++] = it.second;
-      }
-    }
-    fits = fits && room && (int)whole.size() <= nw;
-    if (fits) {
-      // Full tiles: in every stamp the odd XCCs' full tiles run 4-5 % behind the even ones', and the tiles that carry a bias gradient
-      // (the first tile column of a matrix) 5 % behind their XCD's others — so the even XCDs take all of those and the odd ones only
-      // tiles without: [the other tiles in compact order | the bias-gradient tiles], odd XCDs the first runs of it.
-      std::vector<unsigned> rest, dbt, natural;
-      for (int i = 0; i < n; ++i) {
-        const bool colmajor = g.fm[i] < g.fn[i];
-        const int n1 = colmajor ? g.fn[i] : g.fm[i], n2 = colmajor ? g.fm[i] : g.fn[i];
-        for (int u = 0; u < n1; ++u)
-          for (int v = 0; v < n2; ++v) {
-            const int tm = colmajor ? v : u, tn = colmajor ? u : v;
-            ((tn == 0 && probs[i].dbias) ? dbt : rest).push_back((unsigned)(i | tm << 2 | tn << 10));
-            natural.push_back((unsigned)(i | tm << 2 | tn << 10));
-          }
-      }
-      const int per = ncu / 8, nwx = nw / 8, nwr = nw % 8;   // CUs per XCD; ragged workgroups per XCD (the first nwr XCDs one more)
-      int cnt[8], need_even = 0, need_odd = 0;
-      // (the odd XCDs first take the nw % 8 extra ragged workgroups: one full tile fewer there)
-      for (int x = 0; x < 8; ++x) cnt[x] = per - nwx - (((x & 1) ? (x >> 1) : 4 + (x >> 1)) < nwr ? 1 : 0);
-      // the counts as they are (sum = nfull); if the odd XCDs can be filled from `rest` alone, deal it that way
-      for (int x = 0; x < 8; ++x) (x & 1 ? need_odd : need_even) += cnt[x];
-      std::vector<unsigned> seq;
-      int pos[9];
-      if (REED_W4_DB_EVEN && need_odd <= (int)rest.size()) {
-        size_t r = 0;
-        std::vector<std::vector<unsigned>> px(8);
-        for (int x = 1; x < 8; x += 2) for (int c = 0; c < cnt[x]; ++c) px[x].push_back(rest[r++]);
-        // the even XCDs share the bias-gradient tiles evenly (an XCD of nothing but those runs at their pace: 1747 us against
-        // 1623-1651 for the other even ones in the stamps) and fill up with the other tiles
-        size_t d = 0;
-        for (int k = 0; k < 4; ++k) {
-          const int x = 2 * k;
-          const size_t nd = dbt.size() / 4 + ((size_t)k < dbt.size() % 4 ? 1 : 0);
-          for (int c = 0; c < cnt[x]; ++c) {
-            if ((size_t)c < (size_t)cnt[x] - std::min(nd, (size_t)cnt[x]) && r < rest.size()) px[x].push_back(rest[r++]);
-            else if (d < dbt.size()) px[x].push_back(dbt[d++]);
-            else px[x].push_back(rest[r++]);
-          }
-        }
-        for (int x = 0; x < 8; ++x) { pos[x] = (int)seq.size(); seq.insert(seq.end(), px[x].begin(), px[x].end()); }
-      } else {
-        seq = natural;
-        int acc0 = 0;
-        for (int x = 0; x < 8; ++x) { pos[x] = acc0; acc0 += cnt[x]; }
-      }
-      pos[8] = (int)seq.size();
-      for (int x = 0; x <= 8; ++x) g.fstart[x] = (unsigned short)pos[x];
-      for (size_t q = 0; q < seq.size() && q < 256; ++q) g.ftab[q] = seq[q];
-      g.wstart[nw] = (unsigned short)g.nitem;
-      g.wpx = ncu / 8;
-      g.slab = slab;
-      rd.accumulate = probs[0].accumulate;
-      rd.slab = slab;
-    } else {
-      g.nitem = 0;
-      rd.n = 0;
-    }
-  } else {
-    rd.n = 0;
-  }
-  if (g.nitem == 0 && w4mode != 1) return REED_OK;   // only the dynamic form applies: gemm_tn.hip's grouped launch is the faster one
-  const int grid = g.nitem > 0 ? ncu : 8 * (cdiv(g.nfull, 8) + cdiv(g.nrag, 8));
-  REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(grid), dim3(256), LDS_TN, stream, g);
+  REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(ncu), dim3(256), LDS_TN, stream, g);
   REED_LAUNCH_CHECK();
-  if (rd.n > 0) {
-    REED_KLAUNCH(wgrad_split_reduce_kernel, dim3(SPLIT_TILE / 4 / 256, rd.n), dim3(256), 0, stream, rd);
-    REED_LAUNCH_CHECK();
-  }
   *launched = 1;
   return REED_OK;
 }

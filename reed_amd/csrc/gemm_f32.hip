@@ -328,6 +328,8 @@ int reed_gemm_tn_group_launch(int, const GemmArgs*, hipStream_t) {
   return REED_ERR_UNSUPPORTED;
 }
 
+extern "C" int reed_wgrad_group_deal(int, const int*, const int*, const int*, int, unsigned*) { return 0; }   // (16-bit builds only)
+
 // 3x3 convolution, padding 1, optional nearest x2 upsampling of the input, as an implicit GEMM on the fp32 MFMA kernel above (the
 // 16-bit builds have their own: conv.hip): out f32 [B*Ho*Wo, ldc] (+)= conv(a f32 NHWC [B, Hi, Wi, C]; w f32 [N, 9 C]) + bias.
 extern "C" int reed_conv3x3(const void* act, const void* w, const float* bias, float* out, int64_t ldc, int B, int Hi, int Wi, int C,

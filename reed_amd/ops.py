@@ -250,6 +250,38 @@ def wgrad_group_fits(shapes, min_fill=0.85):
     return n is not None and len(shapes) <= 4 and min_fill * slots <= n <= slots
 
 
+def wgrad_group_deal(shapes, cus=256, precision="bf16"):
+    """How the one-workgroup-per-CU form of the grouped weight gradients deals [(n_out, k_in, has_bias), ...] over `cus` CUs
+    (reed_wgrad_group_deal: host arithmetic, runs without a GPU).  Returns None where the form does not apply, else a list of 8
+    lists (one per XCD) of items {p, mode, row, col, rows, cols, bias}: row / col / rows / cols in elements of dw; mode 0 = a
+    256 x 256 tile, 6 = 384 x 128 with the bias gradient of its rows, 7 = 128 x 384, 8 = the bias gradient of `rows` rows only."""
+    n = len(shapes)
+    ip = ctypes.c_int * n
+    items = (ctypes.c_uint * 256)()
+    L = _lib.load(precision)
+    T = L.reed_wgrad_group_deal(n, ctypes.cast(ip(*[int(q[0]) for q in shapes]), ctypes.c_void_p),
+                                ctypes.cast(ip(*[int(q[1]) for q in shapes]), ctypes.c_void_p),
+                                ctypes.cast(ip(*[int(bool(q[2])) for q in shapes]), ctypes.c_void_p), int(cus),
+                                ctypes.cast(items, ctypes.c_void_p))
+    if T <= 0:
+        return None
+    wpx, out = cus // 8, []
+    for x in range(8):
+        run = []
+        for j in range(wpx):
+            it = items[x * wpx + j]
+            if it == 0xFFFFFFFF:
+                continue
+            mode, mu, nu = (it >> 2) & 15, (it >> 6) & 255, (it >> 14) & 255
+            vm, vn = ((it >> 22) & 3) + 1, ((it >> 24) & 3) + 1
+            rows = {0: 256, 6: 128 * vm, 7: 128, 8: 128 * vm}[mode]
+            cols = {0: 256, 6: 128, 7: 128 * vn, 8: 0}[mode]
+            run.append(dict(p=it & 3, mode=mode, row=128 * mu, col=128 * nu, rows=rows, cols=cols, bias=(it >> 26) & 1))
+        out.append(run)
+    assert sum(len(r) for r in out) == T
+    return out
+
+
 def wgrad_group(problems, tokens, accumulate=False):
     """problems: [(dy [tokens, n_out], x [tokens, k_in], dw f32 [n_out, k_in], dbias f32 [n_out] | None, n_out, k_in), ...]
     (tensors or raw device addresses) -> one launch of the 256x128 / 128x256 TN tiles, no split-K (reed_wgrad_group).

@@ -215,8 +215,8 @@ def test_tn_wgrad_tall_wide_tiles(dev, lay, Mtok, N, K, split, force_tile):
 @pytest.mark.parametrize("tokens,shapes", [
     (512, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),     # the SiT-XL/2 block: 162 + 162 + 45 + 126 tiles
     (1000, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),    # ragged token count
-    (2048, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),    # long enough for the four-wave form's static deal (force_tile 0):
-                                                                         # tall / wide tile pairs, K-cut leftovers, the slab reduce
+    (2048, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]),    # (force_tile 0: gemm256w.hip's one-item-per-CU form at every
+                                                                         # token count since round 6)
     (256, [(384, 256), (640, 128)]),                                     # ragged last tile rows (1.5 and 2.5 tiles of 256)
     (300, [(128, 128)]),
 ])
@@ -224,8 +224,8 @@ def test_wgrad_group(dev, tokens, shapes, force_tile):
     """reed_wgrad_group (csrc/gemm_tn.hip): the weight + bias gradients of up to four linears in one launch without
     split-K, against fp32 torch and against the per-GEMM path; accumulate; run-to-run bit-identical; identity operand."""
     from reed_amd import ops
-    if force_tile not in (0, 128):   # 0: with REED_WGRAD_W4=1 in the environment, 256^2 tiles with four 128x128 waves for the
-        pytest.skip("two kernels: force_tile 0 / 128")   # XL/2 block (off by default); 128: always gemm_tn.hip's grouped kernel
+    if force_tile not in (0, 128):   # 0: gemm256w.hip's one-item-per-CU form for the XL/2 block; 128: always gemm_tn.hip's grouped kernel
+        pytest.skip("two kernels: force_tile 0 / 128")
     g = torch.Generator().manual_seed(17)
     probs, refs = [], []
     for n_out, k_in in shapes:
@@ -263,9 +263,9 @@ def test_wgrad_group(dev, tokens, shapes, force_tile):
 
 def test_wgrad_group_beside_a_collective_is_the_two_workgroup_kernel(dev):
     """While gradient buckets are in flight (ops.set_concurrent_comm: the data-parallel backward) the grouped launch keeps to
-    gemm_tn.hip's half-size tiles in dynamic order — the static one-workgroup-per-CU form of gemm256w.hip takes twice as long when
-    RCCL's channels hold CUs (profiles/r4_wgrad_under_cu_hog.txt).  Seen from outside: with the flag set the default plan gives
-    force_tile 128's bits, and without it the K-cut tiles of the static form differ from them in summation order."""
+    gemm_tn.hip's half-size tiles in dynamic order — the one-workgroup-per-CU form of gemm256w.hip takes twice as long when
+    RCCL's channels hold CUs (profiles/r4_wgrad_under_cu_hog.txt).  Since round 6 both forms walk every tile's tokens as ONE
+    sequence (no K-cut pieces): the N = 1 plan and the plan beside collectives give the same bits."""
     from reed_amd import ops
     ops.set_comm_forms(True)   # (a tuner or REED_COMM_FORMS=0 may have switched them off)
     tokens, shapes = 4096, [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]
@@ -283,6 +283,7 @@ def test_wgrad_group_beside_a_collective_is_the_two_workgroup_kernel(dev):
         try:
             for q in probs:
                 q[2].fill_(float("nan"))
+                q[3].fill_(float("nan"))
             assert ops.wgrad_group(probs, tokens)
             return [(q[2].clone(), q[3].clone()) for q in probs]
         finally:
@@ -293,11 +294,51 @@ def test_wgrad_group_beside_a_collective_is_the_two_workgroup_kernel(dev):
     beside = run(0, True)
     alone = run(0, False)
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(two, beside))
-    import os
-    if os.environ.get("REED_WGRAD_W4", "") not in ("0", "1") and ops.wgrad_slots() == 512:
-        assert any(not torch.equal(a[0], b[0]) for a, b in zip(two, alone))      # the static form did run without the flag
-    for a, b in zip(two, alone):
-        torch.testing.assert_close(a[0], b[0], atol=2e-3, rtol=1e-4)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(two, alone))
+
+
+@pytest.mark.parametrize("tokens", [192, 1024, 8192])
+@pytest.mark.parametrize("bias", ["all", "none", "mixed"])
+def test_wgrad_group_items_bit_identical_to_the_two_workgroup_kernel(dev, tokens, bias):
+    """Round 6's deal of the XL/2 block (tests/test_host_cpu.py checks its cover on the host): 212 full tiles + 24 items of
+    384 x 128 + 18 of 128 x 384 + 2 bias-only items, every one a whole-K sequence — the same bits as gemm_tn.hip's grouped kernel
+    for every weight and bias gradient, with and without bias gradients (the items' fourth waves), for an odd K-tile count
+    (192 tokens = 3 K-tiles), and accumulating."""
+    from reed_amd import ops
+    shapes = [(1152, 4608), (4608, 1152), (1152, 1152), (3456, 1152)]
+    g = torch.Generator().manual_seed(29)
+    probs = []
+    for i, (n_out, k_in) in enumerate(shapes):
+        dy = _bf(torch.randn(tokens, n_out, generator=g)).to(dev)
+        x = _bf(torch.randn(tokens, k_in, generator=g)).to(dev)
+        out = torch.full((n_out * k_in + n_out,), float("nan"), device=dev)
+        has_b = bias == "all" or (bias == "mixed" and i % 2 == 0)
+        probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:] if has_b else None, n_out, k_in))
+
+    def run(tile, acc):
+        ops.gemm_force_tile(tile)
+        try:
+            for q in probs:
+                q[2].fill_(0.25 if acc else float("nan"))
+                if q[3] is not None:
+                    q[3].fill_(-0.5 if acc else float("nan"))
+            assert ops.wgrad_group(probs, tokens, accumulate=acc)
+            return [(q[2].clone(), None if q[3] is None else q[3].clone()) for q in probs]
+        finally:
+            ops.gemm_force_tile(0)
+
+    for acc in (False, True):
+        ref, got = run(128, acc), run(0, acc)
+        for (rw, rb), (gw, gb), q in zip(ref, got, probs):
+            assert torch.isfinite(gw).all()
+            assert torch.equal(rw, gw)
+            if rb is not None:
+                assert torch.equal(rb, gb)
+    # against fp32 torch
+    for (gw, gb), q in zip(got, probs):
+        torch.testing.assert_close(gw - 0.25, q[0].float().t() @ q[1].float(), atol=2e-2, rtol=1e-3)
+        if gb is not None:
+            torch.testing.assert_close(gb + 0.5, q[0].float().sum(0), atol=2e-2, rtol=1e-3)
 
 
 def test_wgrad_group_planning(dev):

@@ -643,3 +643,58 @@ def test_bench_refuses_unknown_switches():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=dict(os.environ, REED_GEMM_W4="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "REED_GEMM_W4" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.parametrize("shapes", [
+    [(1152, 4608, 1), (4608, 1152, 1), (1152, 1152, 1), (3456, 1152, 1)],     # the SiT-XL/2 block: fc2, fc1, proj, qkv
+    [(4608, 1152, 0), (1152, 4608, 1), (3456, 1152, 1), (1152, 1152, 0)],     # another order, some without a bias gradient
+    [(1024, 4096, 1), (4096, 1024, 1), (1024, 1024, 1), (3072, 1024, 1)],     # SiT-L/2: no ragged edge at all (192 full tiles)
+    [(1280, 5120, 1), (5120, 1280, 1), (1280, 1280, 1)],                      # no ragged edge; bias-only items do not all fit
+])
+def test_wgrad_group_deal_covers_every_gradient_element_once(shapes):
+    """The one-workgroup-per-CU form of reed_wgrad_group (csrc/gemm256w.hip, round 6: the ragged edges as three-unit items that
+    keep a full tile's pace instead of K-cut pieces): on the host, without a GPU — every element of every dw is written by
+    exactly one item, every row's bias gradient by exactly one item, every XCD gets a contiguous eighth of the sequence and at
+    most cus / 8 items, and an item sits on the XCD that holds full tiles of its rows (what the deal is for)."""
+    from reed_amd import ops
+    deal = ops.wgrad_group_deal(shapes, 256)
+    assert deal is not None and len(deal) == 8 and all(len(r) <= 32 for r in deal)
+    sizes = [len(r) for r in deal]
+    assert max(sizes) - min(sizes) <= 1
+    cover = [np.zeros((m // 128, n // 128), dtype=np.int32) for m, n, _ in shapes]
+    bias = [np.zeros(m // 16, dtype=np.int32) for m, _, _ in shapes]
+    for run in deal:
+        for it in run:
+            m, n, hb = shapes[it["p"]]
+            r0, c0 = it["row"] // 128, it["col"] // 128
+            assert it["row"] + it["rows"] <= m and it["col"] + it["cols"] <= n
+            if it["mode"] != 8:
+                cover[it["p"]][r0:r0 + it["rows"] // 128, c0:c0 + it["cols"] // 128] += 1
+            if it["bias"]:
+                assert hb
+                # mode 0: the first tile column's extra MFMA; 6 / 8: the fourth wave(s) over the item's rows; 7: its 128 rows
+                bias[it["p"]][it["row"] // 16:(it["row"] + it["rows"]) // 16] += 1
+    for (m, n, hb), c, bsum in zip(shapes, cover, bias):
+        assert (c == 1).all()
+        assert (bsum == (1 if hb else 0)).all()
+    # locality (the XL/2 block): a 384-row item shares an XCD with a full tile of one of its tile rows, a 384-column item with a
+    # full tile of one of its tile columns — except where an XCD boundary falls right beside it (at most one item per boundary)
+    if shapes[0] == (1152, 4608, 1):
+        assert sum(sizes) == 256 and sum(1 for r in deal for it in r if it["mode"] == 0) == 212      # every CU has an item
+        assert sum(1 for r in deal for it in r if it["mode"] == 6) == 24 and sum(1 for r in deal for it in r if it["mode"] == 7) == 18
+        assert sum(1 for r in deal for it in r if it["mode"] == 8) == 2
+        assert not any(it["bias"] for r in deal for it in r if it["mode"] == 0)      # no full tile carries a bias gradient
+        lonely = 0
+        for run in deal:
+            full = [(it["p"], it["row"] // 256, it["col"] // 256) for it in run if it["mode"] == 0]
+            for it in run:
+                if it["mode"] == 6:
+                    rows = {it["row"] // 256, (it["row"] + it["rows"] - 1) // 256}
+                    lonely += not any(p == it["p"] and r in rows for p, r, _ in full)
+                elif it["mode"] == 7:
+                    cols = {it["col"] // 256, (it["col"] + it["cols"] - 1) // 256}
+                    lonely += not any(p == it["p"] and c in cols for p, _, c in full)
+        assert lonely <= 7
+    # a CU reserve (collectives holding CUs) leaves too few CUs for one round: the form does not apply
+    assert ops.wgrad_group_deal([(1152, 4608, 1), (4608, 1152, 1), (1152, 1152, 1), (3456, 1152, 1)], 224) is None
+    assert ops.wgrad_group_deal([(384, 1536, 1), (1536, 384, 1), (384, 384, 1), (1152, 384, 1)], 256) is None    # SiT-S/2: too thin

@@ -560,12 +560,10 @@ def test_tile_choice_is_bit_invisible_at_small_local_batch(dev):
     l1, g1 = step(128)
     assert np.isfinite(l0) and float(g0.abs().max()) > 0
     assert l0 == l1
-    # every activation gradient and every weight gradient whose tile is not cut along K is the same bits; the grouped weight
-    # gradients' four-wave form (the default since round 4, csrc/gemm256w.hip) sums the ragged tiles of a weight matrix from two
-    # or three K ranges where force_tile 128 (csrc/gemm_tn.hip) runs the tokens in one sequence: fp32 summation order, nothing else
-    same = (g0 == g1).float().mean().item()
-    worst = ((g0 - g1).abs().max() / g0.abs().max()).item()
-    assert same > 0.8 and worst < 2e-6, (same, worst)
+    # every gradient is the same bits: since round 6 the grouped weight gradients' one-item-per-CU form (csrc/gemm256w.hip) walks
+    # every tile's tokens as one sequence, like force_tile 128's kernel (csrc/gemm_tn.hip) — round 4's K-cut ragged tiles had
+    # differed in fp32 summation order
+    assert torch.equal(g0, g1)
 
 
 def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
@@ -575,8 +573,7 @@ def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
     ONE step of SiT-XL/2 + 1024-d projector at local batch 256, four ways —
       bench   the heuristic plan (what bench.py times)
       A       the same with the row-kernel delta (engine.fused_delta = False)
-      B       A with every GEMM forced onto the 128^2 kernel            -> loss bit-identical; gradients too, except the K-cut ragged
-                                                                            tiles of the four-wave weight gradients (<= 1e-5)
+      B       A with every GEMM forced onto the 128^2 kernel            -> loss and every gradient bit-identical
       C       B with the per-GEMM split-K weight gradients (REED_WGRAD_GROUP=0) = the plan the goldens pin
                                                                          -> differs from B by fp32 summation order only (<= 1e-5)
     and bench vs A differs only where the last fp32 bit of delta (another summation order) flips a bf16 rounding of dS: the loss
@@ -638,11 +635,8 @@ def test_bench_plan_matches_the_golden_pinned_plan_at_b256(dev, monkeypatch):
     l3, g3 = step(128, "0", "0")
     assert np.isfinite(lb) and float(gb.abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in (ga, g2, g3))
     assert lb == la == l2 == l3, (lb, la, l2, l3)
-    # tile choice: bit-invisible at b = 256 too — except where the four-wave weight gradients (the default since round 4) sum a
-    # ragged tile of a weight matrix from two or three K ranges and force_tile 128 runs the tokens in one sequence (fp32 order)
-    w02, who02, all02 = worst_rel(ga, g2)
-    same02 = (ga == g2).float().mean().item()
-    assert same02 > 0.8 and w02 <= 1e-5 and all02 <= 1e-6, (same02, w02, who02, all02)
+    # tile choice: bit-invisible at b = 256 too (round 6: the grouped weight gradients no longer cut any tile along K)
+    assert torch.equal(ga, g2)
     w32, who32, all32 = worst_rel(g2, g3)                   # grouped vs split-K weight gradients
     wdp, whodp, alldp = worst_rel(ga, gb)                   # delta from the row kernel vs from the dO GEMM's epilogue
     print(f"b=256 plan tie: loss {lb}; split-K vs grouped: worst tensor {w32:.2e} ({who32}), arena {all32:.2e}; "

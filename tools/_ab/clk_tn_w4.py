@@ -1,3 +1,6 @@
+"""In-kernel stamps of the grouped weight-gradient launch (diagnostic build: python tools/_ab/build_variant.py clk -DREED_CLK_PROBE;
+REED_HIP_LIB=tools/_ab/libreed_clk.so python tools/_ab/clk_tn_w4.py [b]): per item MODE (0 = full 256^2 tile, 6 = 384x128, 7 = 128x384,
+8 = bias only) the clock, the cycles per K-tile and the K loop's length; per XCC when its items' K loops end (are they in step?)."""
 import ctypes, os, statistics, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -29,34 +32,19 @@ ms = e0.elapsed_time(e1) / 10
 n = 4096
 buf = (ctypes.c_ulonglong * (8 * n))()
 assert rd(buf, 8 * n) == 0
-W = [[buf[8 * i + j] for j in range(8)] for i in range(n) if buf[8 * i + 1] > 0]
-for mode in (0, 1, 2, 3, 4, 5):
+W = [[buf[8 * i + j] for j in range(8)] for i in range(2000, 2000 + 256) if buf[8 * i + 1] > 0]
+med = statistics.median
+print(f"b={b} REED_WGRAD_W4={os.environ.get('REED_WGRAD_W4')}: {ms:.4f} ms per launch, {flop/ms/1e9:.1f} TF; {len(W)} items recorded")
+t00 = min(x[4] for x in W)
+for mode in sorted(set(int(x[3]) for x in W)):
     w = [x for x in W if x[3] == mode]
-    if w:
-        print(f"MODE {mode}: {len(w)} records, clock {statistics.median([x[0]/x[1]*0.1 for x in w]):.3f} GHz, {statistics.median([x[0]/x[2] for x in w]):.1f} cycles per K-tile of 64 (MFMA floor 2048 full tile), loop {statistics.median([x[1] for x in w])/100:.1f} us")
-print(f"REED_WGRAD_W4={os.environ.get('REED_WGRAD_W4')}: {ms:.4f} ms per launch, {flop/ms/1e9:.1f} TF")
-# timeline of the last launch: loop start / end of every recorded tile on the 100 MHz clock
-t0 = min(x[4] for x in W)
-ends = sorted((x[5] - t0) / 100.0 for x in W)
-print(f"timeline: {len(W)} tiles recorded; last K loop ends {ends[-1]:.0f} us after the first one starts; K-loop start times (us): "
-      + ", ".join(f"mode {m}: " + " ".join(f"{v:.0f}" for v in sorted((x[4] - t0) / 100.0 for x in W if x[3] == m)[::max(1, len([x for x in W if x[3] == m]) // 8)]) for m in (0, 1, 2, 3, 4, 5) if any(x[3] == m for x in W)))
-print("K-loop end times (us), every 16th: " + " ".join(f"{v:.0f}" for v in ends[::16]))
-
-# static items (records 1000 + item index): per mode, cycles per K-tile and the items' K-tile counts
-items = [[buf[8 * i + j] for j in range(8)] for i in range(1000, n) if buf[8 * i + 1] > 0]
-for mode in (1, 2, 3, 4, 5):
-    w = [x for x in items if x[3] == mode]
-    if w:
-        print(f"static items MODE {mode}: {len(w)} items, {statistics.median([x[0]/x[2] for x in w]):.1f} cycles per K-tile, K-tiles per item {sorted(int(x[2]) for x in w)[:40]}, loop us {sorted(int(x[1]/100) for x in w)[:40]}")
-if items:
-    t0 = min(x[4] for x in W)
-    print("static items: K-loop end times (us): " + " ".join(f"{(x[5]-t0)/100:.0f}" for x in sorted(items, key=lambda x: x[5])[::4]))
-
-# full tiles by XCD (records 2000 + blockIdx): loop time per XCC
-full = [[buf[8 * i + j] for j in range(8)] for i in range(2000, min(n, 2000 + 300)) if buf[8 * i + 1] > 0 and buf[8 * i + 3] == 0]
-byx = {}
-for x in full:
-    byx.setdefault(int(x[6]), []).append(x[1] / 100.0)
-for k in sorted(byx):
-    v = sorted(byx[k])
-    print(f"full tiles on XCC {k}: {len(v)} tiles, K loop {v[0]:.0f} .. {v[len(v)//2]:.0f} .. {v[-1]:.0f} us (blockIdx % 8 = {sorted(set(int(x[7]) % 8 for x in full if int(x[6]) == k))})")
+    lp = sorted(x[1] / 100.0 for x in w)
+    print(f"MODE {mode}: {len(w)} items, clock {med([x[0]/x[1]*0.1 for x in w]):.3f} GHz, {med([x[0]/x[2] for x in w]):.1f} cycles per K-tile of 64 "
+          f"(MFMA floor 2048 for a full tile), K loop {lp[0]:.0f} .. {lp[len(lp)//2]:.0f} .. {lp[-1]:.0f} us")
+for k in sorted(set(int(x[6]) for x in W)):
+    w = [x for x in W if int(x[6]) == k]
+    parts = []
+    for mode in sorted(set(int(x[3]) for x in w)):
+        e = sorted((x[5] - t00) / 100.0 for x in w if x[3] == mode)
+        parts.append(f"mode {mode} x{len(e)}: {e[0]:.0f}..{e[len(e)//2]:.0f}..{e[-1]:.0f}")
+    print(f"XCC {k}: {len(w)} items (blockIdx % 8 = {sorted(set(int(x[7]) % 8 for x in w))}), K loops end (us after the first start) " + "; ".join(parts))
