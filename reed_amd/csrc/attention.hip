@@ -2078,17 +2078,10 @@ int set_lds(K kernel, int bytes) {
 
 }  // namespace
 int reed_concurrent_comm();   // gemm256.hip
+int reed_num_cus();           // gemm256.hip: the device's CUs minus the reserve (reed_set_cu_reserve) — the persistent kernels' grids
+                              // leave the reserved CUs to whatever the caller runs beside them (RCCL channels; a co-running kernel)
 namespace {
-int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+int num_cus() { return reed_num_cus(); }
 
 }  // namespace
 

@@ -47,4 +47,6 @@ for k in sorted(set(int(x[6]) for x in W)):
     for mode in sorted(set(int(x[3]) for x in w)):
         e = sorted((x[5] - t00) / 100.0 for x in w if x[3] == mode)
         parts.append(f"mode {mode} x{len(e)}: {e[0]:.0f}..{e[len(e)//2]:.0f}..{e[-1]:.0f}")
-    print(f"XCC {k}: {len(w)} items (blockIdx % 8 = {sorted(set(int(x[7]) % 8 for x in w))}), K loops end (us after the first start) " + "; ".join(parts))
+    f0 = [x for x in w if x[3] == 0]
+    print(f"XCC {k}: {len(w)} items (blockIdx % 8 = {sorted(set(int(x[7]) % 8 for x in w))}), full tiles: clock {med([x[0]/x[1]*0.1 for x in f0]):.3f} GHz, "
+          f"{med([x[0]/x[2] for x in f0]):.0f} cycles per K-tile; K loops end (us after the first start) " + "; ".join(parts))

@@ -16,11 +16,17 @@ shapes = [(D, Hm), (Hm, D), (D, D), (3 * D, D)]
 for b in [int(v) for v in sys.argv[1:]] or [256, 32]:
     M = b * T
     probs = []
-    for n_out, k_in in shapes:
-        dy = (torch.randn(M, n_out, device=dev) * 0.05).to(torch.bfloat16)
-        x = (torch.randn(M, k_in, device=dev) * 0.05).to(torch.bfloat16)
+    pad = int(os.environ.get("PAD", "0")) // 2     # PAD=<bytes>: operand j starts j * PAD bytes into its allocation (a multiple of 256)
+    nobias = os.environ.get("NOBIAS", "0") == "1"  # NOBIAS=1: no bias gradients (the items' fourth waves only stage and wait)
+
+    def operand(cols, j):
+        t = (torch.randn(M * cols + 8 * pad, device=dev) * 0.05).to(torch.bfloat16)
+        return t[j * pad:j * pad + M * cols].view(M, cols)
+
+    for j, (n_out, k_in) in enumerate(shapes):
+        dy, x = operand(n_out, 2 * j), operand(k_in, 2 * j + 1)
         out = torch.zeros(n_out * k_in + n_out, device=dev)
-        probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), out[n_out * k_in:], n_out, k_in))
+        probs.append((dy, x, out[:n_out * k_in].view(n_out, k_in), None if nobias else out[n_out * k_in:], n_out, k_in))
     flop = sum(2.0 * M * n * k for n, k in shapes)
     res = {}
     for tile in (128, 0):
