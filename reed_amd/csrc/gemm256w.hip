@@ -103,7 +103,16 @@ __device__ __forceinline__ bf16x8 wtr2(const char* a0, const char* a1) {
 // PM = 1: the persistent form (gemm256wp_kernel): the workgroup walks a list of tiles; prev_mode < 0 = this is its first tile (it
 // stages its own first two K-tiles), otherwise they were staged by the previous tile (of MODE prev_mode)'s last two K-tiles; nx_mode >= 0: a
 // next tile (nx_tm, nx_tn) of MODE nx_mode (0 / 1) follows, and this tile's last two K-tiles stage ITS first two.
-template <int LAY, int EPI, int MODE, int PM = 0>
+// DIRECT = 1 (TN, EPI_F32 without accumulation): the output leaves STRAIGHT from the accumulation registers (buffer stores with AGPR
+// data, inline asm).  Through the compiler's own epilogue a kernel whose 256 AGPRs are all live moved part of them to VGPRs via
+// scratch ("folded spills": 404-1208 bytes per lane in the grouped weight gradients since round 4) — no time in the K loop, but a
+// private segment the runtime has to provide for the dispatch, and a launch time that depended on what the queue had run before
+// (profiles/r6_wgrad_second_size_in_process.txt).
+typedef int w_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void w_store_acc(const f32x4& q, w_i32x4 rs, int voff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"a"(q), "v"(voff), "s"(rs) : "memory");
+}
+template <int LAY, int EPI, int MODE, int PM = 0, int DIRECT = 0>
 __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, const int tm, const int tn,
                                               const int prev_mode = -1, const int nx_mode = -1, const int nx_tm = 0,
                                               const int nx_tn = 0) {
@@ -295,6 +304,28 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     for (int e = 0; e < ND; ++e)
       if (e * NCH / ND == c) dma(t, cur, e);
   };
+  // the ring walk of the TN form (below): the DMA pieces of one 32-row slice that ride in chunk c, and its counted wait
+  auto dmas32 = [&](int t64, int cur, int ks, int c) {
+#pragma unroll
+    for (int e = 0; e < ND; ++e) {
+      if (((e & 3) >> 1) != ks) continue;
+      const int p = (e >> 2) * 2 + (e & 1);
+      if (p * NCH / (ND / 2) == c) dma(t64, cur, e);
+    }
+  };
+  auto ring_wait = [&](bool one) {
+    if (one) {
+      if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+  };
 
   f32x4 acc[NA][NB];
   if constexpr (PM == 0) {   // (PM: the first k-step's MFMAs take C = 0 — a zeroing pass here is loop-invariant in the
@@ -325,16 +356,12 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       do_dbias = true;
       db_par = wave & 1;
     }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!(PM == 0 && REED_TN_RING)) {   // (the ring walk keeps its bias sums inside its own loop copy: nothing of them is
+#pragma unroll                                  //  live across the other copies' loops)
+      for (int i = 0; i < NA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-  }
-  f32x4 accB[MODE >= 6 ? NBR * 8 : 1];   // the bias role's sums (VGPRs): row tile i of its half-tile h in accB[8 h + i]
-  const bool bias_on = MODE >= 6 && a.dbias != nullptr;
-  if constexpr (MODE >= 6) {
-#pragma unroll
-    for (int i = 0; i < NBR * 8; ++i) accB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   // chunk c = 4 MFMAs: row tile CI(c), column tiles CJ(c) .. + 3
@@ -418,27 +445,107 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     WSTAMP(2);                                                                             \
   } while (0)
 
-  // bias role (MODE >= 6): the column sums of slice (cur, ks) of its A half-tiles — read, waited for and added within the phase
-  // (the computing waves read a slice one phase before its MFMAs; this wave has no MFMA stream to hide a read behind and a
-  // tenth of their work)
-  auto bias_step = [&](int cur, int ks, bool on) {
+  // The bias role (MODE >= 6: wave 3 of a 384-row / 384-column item, every wave of a bias-only item), from the end of the prologue
+  // to its store: the same waits, barriers and DMA pieces per phase as the computing waves; per phase the column sums of slice
+  // (cur, ks) of its A half-tiles — read, waited for and added within the phase (the computing waves read a slice one phase before
+  // its MFMAs; this wave has no MFMA stream to hide a read behind and a tenth of their work).  Its sums and fragments live inside
+  // this lambda only: nothing of them is carried across the computing waves' loop.
+  auto bias_role = [&]() {
     if constexpr (MODE >= 6) {
-      if (!bias_on) return;
+      const bool bias_on = a.dbias != nullptr;
+      f32x4 accB[NBR * 8];   // row tile i of its half-tile h in accB[8 h + i]
 #pragma unroll
-      for (int h = 0; h < NBR; ++h) {
-        bf16x8 f[8];
+      for (int i = 0; i < NBR * 8; ++i) accB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // one phase: the reads of half-tile h + 1 are in flight while the MFMAs of half-tile h issue, and the phase's DMA pieces go out
+      // behind the first reads (at most 16 LDS instructions are counted at a time: one half-tile's); three fragment buffers, so that
+      // no read lands in registers an MFMA in flight still reads
+      auto rd_group = [&](int cur, int ks, int h, bf16x8 (&f)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const unsigned q0 = ubA0[h] ^ (unsigned)(i << 5), q1 = ubA1[h] ^ (unsigned)(i << 5);
           if (cur == 0) f[i] = ks ? wtr2u<8192>(q0, q1) : wtr2u<0>(q0, q1);
           else f[i] = ks ? wtr2u<HTW + 8192>(q0, q1) : wtr2u<HTW>(q0, q1);
         }
-        WLGKM0();
+      };
+      auto mm_group = [&](int h, const bf16x8 (&f)[8], bool on) {
         if (on) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) REED_MFMA_ACC_V(accB[h * 8 + i], ones, f[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
+      };
+      auto bias_step = [&](int cur, int ks, bool on, auto&& issue_dmas) {
+        bf16x8 fa[8], fb[8], fc[8];
+        if (bias_on) rd_group(cur, ks, 0, fa);
+        issue_dmas();
+        if (!bias_on) return;
+        WLGKM0();
+        if constexpr (NBR > 1) rd_group(cur, ks, 1, fb);
+        mm_group(0, fa, on);
+        if constexpr (NBR > 1) {
+          WLGKM0();
+          rd_group(cur, ks, 2, fc);
+          mm_group(1, fb, on);
+          WLGKM0();
+          mm_group(2, fc, on);
+        }
+      };
+      auto no_dmas = []() {};
+#ifdef REED_CLK_PROBE
+      unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+      bias_step(0, 0, true, no_dmas);
+#define WRINGB(T, CUR)                                                                       \
+  do {                                                                                       \
+    const int t_ = (T);                                                                      \
+    ring_wait(false);                                                                        \
+    WBARRIER();                                                                              \
+    bias_step((CUR), 1, true, [&]() {                                                        \
+      _Pragma("unroll") for (int c = 0; c < NCH; ++c) dmas32(t_ + 2, (CUR), 0, c);           \
+    });                                                                                      \
+    ring_wait(t_ == 0);                                                                      \
+    WBARRIER();                                                                              \
+    bias_step(1 - (CUR), 0, t_ + 1 < nt, [&]() {                                             \
+      _Pragma("unroll") for (int c = 0; c < NCH; ++c) dmas32(t_ + 2, (CUR), 1, c);           \
+    });                                                                                      \
+  } while (0)
+      int t = 0;
+      for (; t + 1 < nt; t += 2) {
+        WRINGB(t, 0);
+        WRINGB(t + 1, 1);
+      }
+      if (t < nt) WRINGB(t, 0);
+#undef WRINGB
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the MFMAs are inline asm: the sums were just written by the matrix pipe
+#ifdef REED_CLK_PROBE
+      {
+        unsigned long long ck1 = __builtin_amdgcn_s_memtime(), cr1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const int pidx = a.act_variant;
+        if (tid == 0 && pidx >= 1000 && pidx < 8192) {
+          reed_clk_buf[8 * pidx + 0] = ck1 - ck0;
+          reed_clk_buf[8 * pidx + 1] = cr1 - cr0;
+          reed_clk_buf[8 * pidx + 2] = nt;
+          reed_clk_buf[8 * pidx + 3] = MODE;
+          reed_clk_buf[8 * pidx + 4] = cr0;
+          reed_clk_buf[8 * pidx + 5] = cr1;
+          reed_clk_buf[8 * pidx + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;
+          reed_clk_buf[8 * pidx + 7] = blockIdx.x;
+        }
+      }
+#endif
+      if (bias_on && (lane >> 4) == 0) {   // the column sums, one row per lane of the first 16
+#pragma unroll
+        for (int h = 0; h < NBR; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int m = m0 + (MODE == 6 ? h : MODE == 8 ? wave : 0) * 128 + i * 16 + (lane & 15);
+            if (m < a.M) {
+              if (a.accumulate) a.dbias[m] += accB[h * 8 + i][0];
+              else a.dbias[m] = accB[h * 8 + i][0];
+            }
+          }
       }
     }
   };
@@ -463,11 +570,14 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     WBARRIER();
-    if (MODE >= 6 && brole) bias_step(0, 0, true);
-    else {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
+    if constexpr (MODE >= 6) {
+      if (brole) {   // (every item has nt >= 2: the launcher's K >= 2 * WBK)
+        bias_role();
+        return;
+      }
     }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ldfrag(0, 0, c);
   }
 #ifdef REED_CLK_PROBE
   unsigned long long ck0 = __builtin_amdgcn_s_memtime(), cr0 = __builtin_amdgcn_s_memrealtime();
@@ -484,27 +594,6 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   // wait is one counted vmcnt: the two youngest slices (ND pieces) may be outstanding — in phase 1, where the prologue's K-tile 1
   // went out with its two slices interleaved, one (ND / 2).
   if constexpr (LAY == LAY_TN && PM == 0) {
-    auto dmas32 = [&](int t64, int cur, int ks, int c) {
-#pragma unroll
-      for (int e = 0; e < ND; ++e) {
-        if (((e & 3) >> 1) != ks) continue;
-        const int p = (e >> 2) * 2 + (e & 1);
-        if (p * NCH / (ND / 2) == c) dma(t64, cur, e);
-      }
-    };
-    auto ring_wait = [&](bool one) {
-      if (one) {
-        if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        if constexpr (ND == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else if constexpr (ND == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if constexpr (ND == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      }
-    };
     // DB: this workgroup also forms the bias gradient (one more MFMA per row tile against a fragment of ones; the tiles of a problem's
     // first column block only): its own copy of the loop — as a run-time condition it was a branch in every second chunk
 #define WMMA4R(KS, C)                                                                                    \
@@ -544,36 +633,31 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
   } while (0)
     auto ring = [&](auto db_c) {
       constexpr int DB = decltype(db_c)::value;   // 0: no bias gradient, 1: every row tile, 2 / 3: the even / odd ones, 4 + q: 2 q, 2 q + 1
+      f32x4 accb[NA];   // this copy's bias sums (VGPRs; untouched where DB == 0): not live in any other copy of the loop
+      if constexpr (DB != 0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       for (; t + 1 < nt; t += 2) {
         WRING(t, 0);
         WRING(t + 1, 1);
       }
       if (t < nt) { WRING(t, 0); ++t; }
-    };
-    // the bias role's walk: the same waits, barriers and DMA pieces per phase; its reads and MFMAs are bias_step's
-#define WRINGB(T, CUR)                                                                       \
-  do {                                                                                       \
-    const int t_ = (T);                                                                      \
-    ring_wait(false);                                                                        \
-    WBARRIER();                                                                              \
-    _Pragma("unroll") for (int c = 0; c < NCH; ++c) dmas32(t_ + 2, (CUR), 0, c);             \
-    bias_step((CUR), 1, true);                                                               \
-    ring_wait(t_ == 0);                                                                      \
-    WBARRIER();                                                                              \
-    _Pragma("unroll") for (int c = 0; c < NCH; ++c) dmas32(t_ + 2, (CUR), 1, c);             \
-    bias_step(1 - (CUR), 0, t_ + 1 < nt);                                                    \
-  } while (0)
-    auto ring_bias = [&]() {
-      for (; t + 1 < nt; t += 2) {
-        WRINGB(t, 0);
-        WRINGB(t + 1, 1);
+      if constexpr (DB != 0) {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if ((lane >> 4) == 0) {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) {
+            const int m = m0 + mrow + i * 16 + (lane & 15);
+            if (m < a.M && (DB == 1 || (DB < 4 ? (i & 1) == DB - 2 : (i >> 1) == DB - 4))) {
+              if (a.accumulate) a.dbias[m] += accb[i][0];
+              else a.dbias[m] = accb[i][0];
+            }
+          }
+        }
       }
-      if (t < nt) { WRINGB(t, 0); ++t; }
     };
-#undef WRINGB
-    if constexpr (MODE == 8) ring_bias();
-    else if (MODE >= 6 && brole) ring_bias();
-    else if (!do_dbias) ring(std::integral_constant<int, 0>{});
+    if (!do_dbias) ring(std::integral_constant<int, 0>{});
     else if (db_par < 0) ring(std::integral_constant<int, 1>{});
     else if constexpr (MODE == 0) {
       if (db_par == 0) ring(std::integral_constant<int, 2>{});
@@ -646,22 +730,29 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
     }
   }
 #endif
-  if constexpr (MODE >= 6) {   // the bias role owns no output: its column sums, one row per lane of the first 16
-    if (brole) {
-      if (bias_on && (lane >> 4) == 0) {
+  if constexpr (DIRECT != 0) {
+    static_assert(LAY == LAY_TN && EPI == EPI_F32, "direct stores: the weight gradients");
+    // lane (lr, lc) owns row 16 i + lr, columns 16 j + lc .. + 3 of the wave's piece: one 16-byte store per accumulator quad; rows /
+    // columns past a.M / a.N are whole 16-row / 16-column tiles (M, N multiples of 128): wave-uniform, sent past the descriptor
+    const int lr = lane & 15, lc = 4 * (lane >> 4);
+    const unsigned long long cb = (unsigned long long)((const char*)a.C + (long)m0 * a.ldc * 4);
+    long nb = ((long)(a.M - m0 - 1) * a.ldc + a.N) * 4;
+    if (nb < 0) nb = 0;
+    if (nb > 0x7FFF0000l) nb = 0x7FFF0000l;
+    const w_i32x4 rs = {(int)(unsigned)cb, (int)((cb >> 32) & 0xFFFFu), (int)nb, 0x00020000};
+    const int ldc4 = (int)a.ldc * 4;
 #pragma unroll
-        for (int h = 0; h < NBR; ++h)
+    for (int i = 0; i < NA; ++i) {
+      const int ml = mrow + 16 * i;
+      const bool rv = m0 + ml < a.M;
+      const int ro = (ml + lr) * ldc4 + (n0 + ncol + lc) * 4;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int m = m0 + (MODE == 6 ? h : MODE == 8 ? wave : 0) * 128 + i * 16 + (lane & 15);
-            if (m < a.M) {
-              if (a.accumulate) a.dbias[m] += accB[h * 8 + i][0];
-              else a.dbias[m] = accB[h * 8 + i][0];
-            }
-          }
+      for (int j = 0; j < NB; ++j) {
+        const bool ok = rv && n0 + ncol + 16 * j < a.N;
+        w_store_acc(acc[i][j], rs, ok ? ro + 64 * j : EPI_OOB);
       }
-      return;
     }
+    return;   // (the bias gradient left from inside the ring walk's own loop copy)
   }
   // epilogue: the wave's piece in 64-column groups through gemm_common.hpp's tile_epilogue (fp32 outputs: its pointer path)
   char* stage = smem + 8 * HTW + wave * EPI_STAGE_BYTES;
@@ -674,7 +765,7 @@ __device__ __forceinline__ void gemm256w_body(const GemmArgs& a, char* smem, con
       for (int j = 0; j < 4; ++j) part[i][j] = acc[i][h * 4 + j];
     tile_epilogue<EPI, NA, REED_EPI_PF>(a, part, m0, mrow, n0 + ncol + h * 64, lane, 0, stage);
   }
-  if constexpr (LAY == LAY_TN) {
+  if constexpr (LAY == LAY_TN && !(PM == 0 && REED_TN_RING)) {   // (the ring walk stores its bias gradient itself)
     if (do_dbias && (lane >> 4) == 0) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -830,6 +921,7 @@ struct TnGroupW {
   unsigned item[256];     // p | mode << 2 | row unit << 6 | column unit << 14 | (valid units - 1) of the row range << 22, of the column
                           // range << 24 | bias gradient << 26 (units of 128; mode 0 / 6 / 7 / 8); 0xFFFFFFFF: none
 };
+template <int ACC>   // 0: plain stores (DIRECT, scratch-free: the training step); 1: dw += (gradient accumulation over micro-batches)
 __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned it = g.item[(blockIdx.x & 7) * g.wpx + (blockIdx.x >> 3)];
@@ -844,16 +936,16 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
   a.act_variant = 2000 + (int)blockIdx.x;
 #endif
   if (mode == 0) {
-    gemm256w_body<LAY_TN, EPI_F32, 0>(a, smem, mu >> 1, nu >> 1);
+    gemm256w_body<LAY_TN, EPI_F32, 0, 0, 1 - ACC>(a, smem, mu >> 1, nu >> 1);
   } else if (mode == 6) {
     a.M = min(a.M, (mu + vm) * 128);
-    gemm256w_body<LAY_TN, EPI_F32, 6>(a, smem, mu, nu);
+    gemm256w_body<LAY_TN, EPI_F32, 6, 0, 1 - ACC>(a, smem, mu, nu);
   } else if (mode == 7) {
     a.N = min(a.N, (nu + vn) * 128);
-    gemm256w_body<LAY_TN, EPI_F32, 7>(a, smem, mu, nu);
+    gemm256w_body<LAY_TN, EPI_F32, 7, 0, 1 - ACC>(a, smem, mu, nu);
   } else {
     a.M = min(a.M, (mu + vm) * 128);
-    gemm256w_body<LAY_TN, EPI_F32, 8>(a, smem, mu, 0);
+    gemm256w_body<LAY_TN, EPI_F32, 8, 0, 1 - ACC>(a, smem, mu, 0);
   }
 }
 
@@ -1097,11 +1189,15 @@ int reed_gemm256w_tn_group_launch(int n, const GemmArgs* probs, hipStream_t stre
   g.wpx = ncu / 8;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256w_tn_group_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
     if (e != hipSuccess) { reed_set_error("gemm256w: cannot reserve LDS: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  REED_KLAUNCH(gemm256w_tn_group_kernel, dim3(ncu), dim3(256), LDS_TN, stream, g);
+  bool accum = false;
+  for (int i = 0; i < n; ++i) accum = accum || probs[i].accumulate != 0;
+  if (accum) REED_KLAUNCH(gemm256w_tn_group_kernel<1>, dim3(ncu), dim3(256), LDS_TN, stream, g);
+  else REED_KLAUNCH(gemm256w_tn_group_kernel<0>, dim3(ncu), dim3(256), LDS_TN, stream, g);
   REED_LAUNCH_CHECK();
   *launched = 1;
   return REED_OK;

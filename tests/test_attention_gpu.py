@@ -222,3 +222,34 @@ def test_attention_bwd_beside_a_collective_is_the_same_bits(dev, B, T, H, hd):
         outs.append(dqkv)
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(40, 256, 16, 72), (33, 256, 12, 64), (70, 128, 16, 72)])
+@pytest.mark.parametrize("reserve", [32, 96, 200])
+def test_attention_grids_follow_the_cu_reserve_with_the_same_bits(dev, B, T, H, hd, reserve):
+    """Round 6: the persistent forward and backward size their grids by reed_planning_cus() — the device's CUs minus
+    ops.set_cu_reserve (RCCL's channels on a node; a kernel run beside them) — instead of the device's count.  The items are the same
+    and independent whatever the grid (224, 160 and 56 workgroups here): identical bits for O, lse and dqkv."""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(B + T + reserve)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g).to(torch.bfloat16).to(dev)
+    do = torch.randn(B, T, H * hd, generator=g).to(torch.bfloat16).to(dev)
+    ws = torch.empty(ops.attention_bwd_ws_floats(B, T, H), device=dev)
+    outs = []
+    for r in (0, reserve, reserve):
+        o = torch.full((B, T, H * hd), float("nan"), dtype=torch.bfloat16, device=dev)
+        lse = torch.full((B, H, T), float("nan"), device=dev)
+        dqkv = torch.full_like(qkv, float("nan"))
+        ops.set_cu_reserve(r)
+        try:
+            ops.attention_fwd(qkv, o, lse, B, T, H, hd)
+            ops.attention_bwd(qkv, o, do, lse, dqkv, B, T, H, hd, ws=ws)
+        finally:
+            ops.set_cu_reserve(0)
+        torch.cuda.synchronize()
+        outs.append((o, lse, dqkv))
+    assert all(torch.isfinite(t.float()).all() for t in outs[0])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
