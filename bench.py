@@ -43,6 +43,8 @@ def parse(argv=None):
     ap.add_argument("--mixed-precision", choices=["bf16", "fp16", "fp32"], default="bf16",
                     help="operand type of the step (BASELINE's configuration is bf16; fp16 = the reference CLI's default, IEEE-half "
                          "operands with dynamic loss scaling)")
+    ap.add_argument("--save-act-grad", choices=["auto", "0", "1"], default="auto",
+                    help="the activation backward (engine.save_act_grad): auto = by tokens per GPU, 1 = saved derivative, 0 = recomputed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the C4 (text + image alignment), C5 (sampler) and N2 (frozen encoder) legs the N = 1 run appends")
@@ -325,7 +327,7 @@ def args_D(model):
     return model.engine().D
 
 
-def c3_leg(step, dev, z_dim, b=32, steps=10, warmup=3):
+def c3_leg(step, dev, z_dim, b=32, steps=10, warmup=3, dp_world1=True):
     """The per-GPU leg of C3 on this one GPU: the same model, optimiser and step at the local batch the 8-GPU run of the
     headline configuration sees (global batch 256 / 8), no communication.  Run after the main timed region, so the driver's
     record carries the 8-GPU-shape number; 8 x this is the upper bound of the 8-GPU run before any all-reduce cost."""
@@ -344,31 +346,32 @@ def c3_leg(step, dev, z_dim, b=32, steps=10, warmup=3):
     dt = time.perf_counter() - t0
     ips = b * steps / dt
     final_loss = float(res["loss"])
-    # What the optimiser pass costs every rank of the 8-GPU run (VERDICT round 4, item 3 iv): the same steps with the pass cut to
-    # 1 / 8 of every update chunk — the sharded pass (REED_OPT_SHARD: optim.py:_shard_plan) WITHOUT its all-gather of the 16-bit
-    # shadows (1.37 GB x 7 / 8 per rank over xGMI), which one GPU cannot time.  Timing only: 7 / 8 of the parameters go stale
-    # (the model is not used again after this leg).
-    sharded = None
-    opt = getattr(step, "opt", None)
-    if opt is not None and getattr(opt, "overlap", False) and hasattr(opt, "timing_only_shard_ways"):
-        opt.timing_only_shard_ways = 8
-        for _ in range(2):
-            step(None, labels, zs, moments=moments)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(steps):
-            step(None, labels, zs, moments=moments)
-        torch.cuda.synchronize()
-        dt8 = time.perf_counter() - t1
-        opt.timing_only_shard_ways = 0
-        sharded = {"ms_per_step": round(dt8 / steps * 1e3, 3), "images_per_sec_per_gpu": round(b * steps / dt8, 2),
-                   "step_mfma_frac": round(b * steps / dt8 * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
-                   "note": "timing only: every update chunk cut to its first 1/8 (the 8-way sharded optimiser pass without its "
-                           "all-gather of the 16-bit shadows over xGMI)"}
+    # The data-parallel CODE PATH at this shape, for real, with one rank (VERDICT round 5, item 6 a): a second process runs this
+    # script with REED_FORCE_REDUCER=1 (process group on RCCL, the bucketed gradient all-reduce fired from backward on the side
+    # stream, the kernel forms beside collectives) and REED_OPT_SHARD=1 (the sharded optimiser pass with its all-gather of the
+    # 16-bit shadows) at world 1 — what every rank of the 8-GPU run executes, minus the wire and minus the 7 / 8 of the optimiser
+    # pass the other ranks would carry (one rank owns every shard).  Nothing is skipped or left stale.
+    dp1 = None
+    if dp_world1:
+        import subprocess
+        env = dict(os.environ, REED_FORCE_REDUCER="1", REED_OPT_SHARD="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
+        env.pop("REED_BENCH_TUNED", None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--global-batch", str(b), "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-kernel-table", "--no-c3-leg", "--no-vae-leg", "--no-config-legs", "--no-loss-vs-ref"]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            dp1 = {"images_per_sec_per_gpu": rec["value"], "ms_per_step": rec["ms_per_step"], "step_mfma_frac": rec["step_mfma_frac"],
+                   "final_loss": rec["final_loss"], "plan": rec.get("plans", {}).get("plain", {}).get("plan"),
+                   "data_parallel": rec.get("data_parallel"),
+                   "note": "a second process: this script at world 1 with REED_FORCE_REDUCER=1 REED_OPT_SHARD=1 — the 8-GPU run's per-rank "
+                           "code path (RCCL reducer, gradient buckets from backward, sharded optimiser pass + all-gather) with one rank"}
+        except Exception as e:  # noqa: BLE001 — a leg, not the number: report and go on
+            dp1 = {"error": f"{type(e).__name__}: {e}"[:300]}
     return {"local_batch": b, "steps": steps, "warmup": warmup, "images_per_sec_per_gpu": round(ips, 2),
             "ms_per_step": round(dt / steps * 1e3, 3), "step_mfma_frac": round(ips * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
             "x8_upper_bound_images_per_sec": round(8 * ips, 1), "final_loss": round(final_loss, 5),
-            "with_optimizer_pass_sharded_8_ways": sharded,
+            "data_parallel_code_path_at_world_1": dp1,
             "note": "one GPU, no gradient all-reduce: the compute side of the 8-GPU run (b = 256 / 8 per GPU)"}
 
 
@@ -598,6 +601,7 @@ def main():
     model = SiT_models[args.model](z_dims=[args.z_dim], z_types=["i"], encoder_depth=8).to(dev).train()
     model.precision = args.mixed_precision
     random_fill(model, 1234)  # identical on every rank (same seed); broadcast below anyway
+    model.engine().save_act_grad = {"auto": None, "0": False, "1": True}[args.save_act_grad]
     ema = copy.deepcopy(model).requires_grad_(False).eval()
     opt = FusedAdamWEMA(model, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
     reducer = None
@@ -692,8 +696,10 @@ def main():
             "step_mfma_frac": round(ips / world * FLOP_PER_IMG_STEP / PEAK_BF16, 4),
         }
 
-    # ---- the watchdog: from here to the end of the process.  If it fires before rank 0 has printed its line, rank 0 prints the
-    # plain-plan record; every rank then leaves with os._exit(0) (no exec, no teardown of a communicator that may be wedged)
+    # ---- the watchdogs (timer threads).  The first bounds the TUNED region only: if it fires, rank 0 prints the plain-plan record.  A
+    # second, longer one is armed for the diagnosis / teardown of a data-parallel run (the collectives of dp_consistency, the final
+    # barrier, destroy_process_group): if it fires before rank 0 has printed its line, rank 0 prints the record of the plan already
+    # chosen.  Either way every rank then leaves with os._exit(0) (no exec, no teardown of a communicator that may be wedged)
     import threading
     wd_lock = threading.Lock()
     wd_state = {"printed": False, "phase": "tuned plan"}
@@ -758,6 +764,24 @@ def main():
             print(f"[bench.py] rank {rank}: tuned plan failed ({e!r}) - leaving with the plain record", file=sys.stderr, flush=True)
             os._exit(0)
     wd_state["phase"] = "diagnosis / teardown"
+
+    def wd_fire_late():
+        with wd_lock:
+            if rank == 0 and not wd_state["printed"]:
+                rec = base_record(chosen)
+                rec["plans"] = plans
+                rec["plan_in_value"] = "tuned" if chosen is not plain else "plain"
+                rec["watchdog_fired"] = wd_state["phase"]
+                emit(rec)
+                wd_state["printed"] = True
+            print(f"[bench.py] rank {rank}: watchdog fired in: {wd_state['phase']} - leaving", file=sys.stderr, flush=True)
+            os._exit(0)
+
+    watchdog_late = None
+    if use_dist:
+        watchdog_late = threading.Timer(max(600.0, 2.0 * args.tuned_timeout), wd_fire_late)
+        watchdog_late.daemon = True
+        watchdog_late.start()
     dt = chosen["dt"]
     loss_val = chosen["loss"]
     dom = chosen["dom"]
@@ -807,6 +831,17 @@ def main():
 
     if rank == 0:
         out = base_record(chosen)
+        eng = model.engine()
+        # the kernel forms the engine picks by token count (engine.py): part of the plan, so part of the record
+        out["kernel_forms"] = {
+            "tokens_per_gpu": b * T_TOK,
+            "activation_backward": ("saved derivative (epilogues 14 / 16)" if (eng.save_act_grad if eng.save_act_grad is not None else b * T_TOK > eng.SAVE_ACT_GRAD_MIN_TOKENS)
+                                    else "recomputed (epilogues 1 / 4)"),
+            "activation_backward_rule": f"saved derivative above {eng.SAVE_ACT_GRAD_MIN_TOKENS} tokens per GPU (engine.save_act_grad = {eng.save_act_grad})",
+            "weight_gradients_on_a_second_stream": bool(eng.wgrad_stream if eng.wgrad_stream is not None else b * T_TOK <= eng.WGRAD_STREAM_MAX_TOKENS),
+            "weight_gradient_stream_rule": f"second stream up to {eng.WGRAD_STREAM_MAX_TOKENS} tokens per GPU (engine.wgrad_stream = {eng.wgrad_stream})",
+            "library": {k: getattr(v, "_name", None) for k, v in __import__("reed_amd._lib", fromlist=["loaded"]).loaded().items()},
+        }
         out["data_parallel"] = dp
         if reducer is not None:
             out["plans"] = plans
@@ -815,7 +850,7 @@ def main():
         # isolated kernel table, which only supplies the stand-in when the grouped launch did not run)
         n_l = sum(len(v) for v in dom.values())
         sag = model.engine().save_act_grad
-        sag = b * T_TOK > 12288 if sag is None else sag     # the engine's rule (engine.py)
+        sag = b * T_TOK > model.engine().SAVE_ACT_GRAD_MIN_TOKENS if sag is None else sag     # the engine's rule (engine.py)
         rows = time_gemms(b, D=args_D(model), Hm=model.engine().Hm, act_grad=sag) if not args.no_kernel_table else None
         if n_l or rows is not None:
             if n_l:
@@ -829,9 +864,10 @@ def main():
                     "traffic_source": TRAFFIC_SOURCE if (b == 256 and args.model == "SiT-XL/2") else None,
                     "kernel": "the grouped weight-gradient launch = the weight (+ bias) gradients of one transformer block's four "
                               "linears (fc2, fc1, proj, qkv: dW = dY^T X over the b*256 tokens) as ONE launch: gemm256w_tn_group_kernel "
-                              "(csrc/gemm256w.hip: 256^2 tiles of four 128x128 waves, one workgroup per CU, the ragged tiles cut along K "
-                              "and summed by wgrad_split_reduce_kernel, which the timing includes) or — with REED_WGRAD_W4=0, where that form "
-                              "does not apply, and beside gradient buckets in flight (N > 1) — gemm_tn_group_kernel (csrc/gemm_tn.hip: 256x128 / 128x256 tiles, two "
+                              "(csrc/gemm256w.hip, round 6: one item per CU — 212 tiles of 256^2 + 24 items of 384x128 + 18 of 128x384 whose "
+                              "fourth waves form the bias gradients + 2 bias-only items, every one a whole-K sequence at a full tile's "
+                              "pace, dealt around tile rows per XCD) or — with REED_WGRAD_W4=0, where that form does not apply, and beside "
+                              "gradient buckets in flight (N > 1) — gemm_tn_group_kernel (csrc/gemm_tn.hip: 256x128 / 128x256 tiles, two "
                               "workgroups per CU); algorithmic flop 2 * tokens * sum(n_out * k_in) per launch / event-timed duration "
                               "of every such launch INSIDE the timed region (events on the launch stream; the largest single share "
                               "of the step)",
@@ -897,6 +933,8 @@ def main():
         dist.destroy_process_group()
     if watchdog is not None:
         watchdog.cancel()
+    if watchdog_late is not None:
+        watchdog_late.cancel()
 
 
 if __name__ == "__main__":

@@ -69,7 +69,7 @@ int reed_wgrad_group(int n, const void* const* dy, const void* const* x, float* 
  * two-workgroups-per-CU kernel (csrc/gemm_tn.hip). */
 int reed_wgrad_group_deal(int n, const int* n_out, const int* k_in, const int* has_bias, int cus, unsigned* items);
 
-/* CUs the GEMM tile heuristics plan for: the device's count (or REED_GEMM_CUS) minus a reserve for kernels that hold CUs
+/* CUs the GEMM tile heuristics plan for: the device's count minus a reserve for kernels that hold CUs
  * beside the GEMMs (RCCL channels during a gradient bucket).  reed_set_cu_reserve(n): n >= 0; reed_planning_cus(): the result. */
 int reed_set_cu_reserve(int n);
 int reed_planning_cus(void);

@@ -14,7 +14,13 @@ LIB_PATH = os.environ.get("REED_HIP_LIB") or os.path.join(_HERE, "libreed_hip.so
 
 def _sibling(suffix):
     alt = LIB_PATH[:-3] + suffix + ".so" if LIB_PATH.endswith(".so") else ""
-    return alt if alt and os.path.exists(alt) else os.path.join(_HERE, "libreed_hip" + suffix + ".so")
+    if alt and os.path.exists(alt):
+        return alt
+    if os.environ.get("REED_HIP_LIB"):   # an A/B build without this sibling: say so once — the two precisions then come from two builds
+        import sys
+        print(f"[reed_amd] REED_HIP_LIB={LIB_PATH} has no {os.path.basename(alt)} beside it: the in-tree libreed_hip{suffix}.so is used "
+              f"for that operand type", file=sys.stderr)
+    return os.path.join(_HERE, "libreed_hip" + suffix + ".so")
 
 
 # the same sources built with IEEE-half operands (csrc/common.hpp, -DREED_FP16): the sampling path

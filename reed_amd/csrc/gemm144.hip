@@ -125,7 +125,7 @@ __device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&
   }
 }
 
-// LW (default; REED_GEMM144_LW=0 selects the 8-wave form): 4 extra LOADER waves (8..11, one per SIMD) issue every LDS-DMA of the workgroup;
+// LW (the form launched; the 8-wave form without them is the template's other instantiation): 4 extra LOADER waves (8..11, one per SIMD) issue every LDS-DMA of the workgroup;
 // the 8 compute waves then carry MFMAs and fragment reads only (no buffer_load ... lds issue cycles, no vmcnt waits).
 template <int LAY, int EPI, bool LW>
 __global__ __launch_bounds__(LW ? 768 : 512) void gemm144_kernel(GemmArgs a) {

@@ -382,7 +382,7 @@ int dispatch256(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-// CUs the tile heuristics plan for = the device's count (or REED_GEMM_CUS) minus a reserve (reed_set_cu_reserve).  While a
+// CUs the tile heuristics plan for = the device's count minus a reserve (reed_set_cu_reserve).  While a
 // gradient bucket is in flight RCCL's channels hold CUs, and a grid planned as exactly one round of the 256 CUs — the 256x144
 // tile at b = 32 per GPU, the grouped weight gradients' 512 slots — turns into two rounds on what is left.  The data-parallel
 // train step measures a few reserves during its first steps and keeps the fastest (reed_amd/trainer.py).

@@ -22,6 +22,15 @@ from .ops import (NT, NN, TN, EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DG
 
 
 class Engine:
+    # Kernel forms picked by the token count per GPU (both measured on MI355X with SiT-XL/2; bench.py prints them under
+    # "kernel_forms", train.py logs them): the activation backward as one multiply by a derivative the forward saved — above this
+    # many tokens (b > 48), see save_act_grad below — and the block's weight gradients on a second stream — up to this many.
+    # NOTE for comparisons across GPU counts: the two activation-backward forms differ by one bf16 rounding of the derivative, so
+    # 1 GPU x 256 and 8 GPUs x 32 of the same global batch do not give the same gradient bits unless the form is pinned
+    # (train.py --save-act-grad {auto,0,1}; bench.py --save-act-grad).
+    SAVE_ACT_GRAD_MIN_TOKENS = 12288
+    WGRAD_STREAM_MAX_TOKENS = 12288
+
     def __init__(self, model):
         self.m = model
         self.L = model._layout
@@ -54,7 +63,7 @@ class Engine:
         # True / False / None = auto: on when the local batch is small enough that one-round GEMM grids leave CUs idle
         # (measured on MI355X, SiT-XL/2: +3.7 % at b = 32, -1 % at 64, -5 % at 128 and 256)
         self.wgrad_stream = {"0": False, "1": True}.get(os.environ.get("REED_WGRAD_STREAM", "auto"))
-        self.wgrad_stream_max_tokens = 12288
+        self.wgrad_stream_max_tokens = self.WGRAD_STREAM_MAX_TOKENS
         self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
         self.table_rows = model.num_classes + (1 if model.class_dropout_prob > 0 else 0)
         self._hb = 2             # bytes per element of the current build's operand arrays (set per forward / backward)
@@ -157,7 +166,7 @@ class Engine:
         def f32(*s):
             return torch.empty(s, dtype=torch.float32, device=dev)
 
-        sag = self.save_act_grad if self.save_act_grad is not None else M > 12288
+        sag = self.save_act_grad if self.save_act_grad is not None else M > self.SAVE_ACT_GRAD_MIN_TOKENS
         self._sag = sag   # (the projector forward of this call follows it)
         tp = types.SimpleNamespace(B=B, blocks=[], proj={}, x=x, prec=prec, act_grad=sag) if need_grad else None
         # epilogues of a layer whose saved array feeds the backward (gemm.h): derivative-saving forms when there is a backward

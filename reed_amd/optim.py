@@ -32,9 +32,6 @@ class FusedAdamWEMA:
         self._want_shard = os.environ.get("REED_OPT_SHARD", "0") == "1"
         self._shard = None       # [(chunk name, [(begin, end, owner rank | -1 = every rank), ...]), ...]; False = replicated
         self._rank, self._world = 0, 1
-        # > 1 (bench.py's b = 32 leg only): a TIMING-ONLY stand-in for the sharded pass of an N-GPU run on one GPU — every update
-        # chunk is cut to its first 1 / N (the other parameters go stale: the numbers of such steps mean nothing), no all-gather
-        self.timing_only_shard_ways = 0
         self.lr, self.betas, self.weight_decay, self.eps = lr, tuple(betas), weight_decay, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.step_count = 0
@@ -121,11 +118,7 @@ class FusedAdamWEMA:
             ep = ema_buf.data_ptr() if ema_buf is not None else None
             ev = None
 
-            ways = int(self.timing_only_shard_ways)
-
             def update(b, e):
-                if ways > 1:
-                    e = b + max(4, ((e - b) // ways) & ~3)
                 nt = max(0, min(e, L.n_train) - b)
                 ops.adamw_ema(pp + 4 * b, gp + 4 * b if nt else None, mp + 4 * b if nt else None,
                               vp + 4 * b if nt else None, ep + 4 * b if ep is not None else None, sp + hb * b, nt,

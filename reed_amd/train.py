@@ -106,6 +106,10 @@ def parse_args(input_args=None):
                              "the same items as --data-dir, SURVEY.md §8f N3)")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N random latents instead of --data-dir (plumbing and throughput runs; 1 MB of encoder features per item still crosses the loader: keep --num-workers >= 4)")
     parser.add_argument("--log-every", type=int, default=1)
+    parser.add_argument("--save-act-grad", choices=["auto", "0", "1"], default="auto",
+                        help="the activation backward: 1 = one multiply by the derivative the forward saved, 0 = recomputed from the saved "
+                             "pre-activation, auto = by tokens per GPU (engine.Engine.SAVE_ACT_GRAD_MIN_TOKENS).  The two differ by one bf16 "
+                             "rounding of the derivative: pin it to compare runs of one global batch on different GPU counts bit for bit")
     parser.add_argument("--vae-ckpt", type=str, default=None,
                         help="local sd-vae-ft checkpoint (diffusers layout): turns on the reference's preview sampling at step 1 "
                              "and every --sampling-steps (train.py:431-454), written as PNG grids under <exp>/samples/")
@@ -305,6 +309,13 @@ def main(args):
     if world > 1:
         reducer = GradReducer(model, rank, world)
         reducer.broadcast_params(0)
+    model.engine().save_act_grad = {"auto": None, "0": False, "1": True}[args.save_act_grad]
+    if is_main:
+        eng = model.engine()
+        tokens = local_batch_size * eng.T // max(1, args.gradient_accumulation_steps)
+        logger.info(f"kernel forms at {tokens} tokens per GPU: activation backward "
+                    f"{'saved derivative' if (eng.save_act_grad if eng.save_act_grad is not None else tokens > eng.SAVE_ACT_GRAD_MIN_TOKENS) else 'recomputed'} "
+                    f"(--save-act-grad {args.save_act_grad}; auto = saved above {eng.SAVE_ACT_GRAD_MIN_TOKENS} tokens)")
     step_fn = TrainStep(model, loss_fn, optimizer, reducer, proj_coeff=args.proj_coeff,
                         repa_decay=args.repa_weight_decay, repa_steps=args.repa_steps,
                         start_diffusion_steps=args.start_diffusion_steps,

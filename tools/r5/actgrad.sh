@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round 5, item 1: the derivative-saving epilogues (EPI_GELU_G / EPI_SILU_G / EPI_MUL) — tests, then a same-box A/B of the step
-# against the recomputing form (REED_SAVE_ACT_GRAD=0), alternating.  Output: gpurun_out/r5_actgrad.txt
-# (Ran at commit 0a480b8, where that switch existed; it is now engine.save_act_grad — None = by token count — and bench.py refuses
-# unknown REED_* variables: to repeat the A/B, check that commit out.)
+# against the recomputing form (--save-act-grad 0), alternating.  Output: gpurun_out/r5_actgrad.txt
+# (profiles/r5_actgrad.txt was made at commit 0a480b8 through an environment switch; since round 6 the same A/B runs through
+# bench.py --save-act-grad {0,1}.)
 set -o pipefail
 O=gpurun_out/r5_actgrad.txt
 mkdir -p gpurun_out
@@ -12,8 +12,8 @@ python -m pytest tests/test_model_gpu.py -x -q -s -k "tiny_vs_reference or saved
 python -m pytest tests/test_fp32_gpu.py -x -q 2>&1 | tail -3 &&
 for rep in 1 2; do
   for v in 0 1; do
-    echo "== b=256 REED_SAVE_ACT_GRAD=$v"
-    REED_SAVE_ACT_GRAD=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config-legs --no-vae-leg --no-loss-vs-ref 2>/dev/null | python -c "
+    echo "== b=256 --save-act-grad $v"
+    python bench.py --save-act-grad $v --steps 10 --warmup 3 --no-cpu-baseline --no-config-legs --no-vae-leg --no-loss-vs-ref 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('value',d['value'],'ms',d['ms_per_step'],'dom',d['roofline']['avg_ms_per_launch'],'c3',d.get('c3_per_gpu_leg',{}).get('images_per_sec_per_gpu'))
