@@ -511,6 +511,9 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 //   Q(n) landed  <=> at most K(n+1) 5 + V(n) 5 + stores(n-1) 7 = 17 younger
 //   V(n) landed  <=> at most stores(n-1) 7 + Q(n+1) 5 = 12 younger
 //   K(n+1) landed <=> at most V(n) 5 + stores(n-1) 7 + Q(n+1) 5 + K(n+2) 5 = 22 younger
+#ifndef REED_ATTN_KSPREAD   // 1: K(n + 2)'s pieces ride in the PV product's first steps — measured equal to the burst (profiles/r6_attn_fwd_kspread.txt)
+#define REED_ATTN_KSPREAD 0
+#endif
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <int OFF>
 __device__ __forceinline__ u32x2 tr16_u(unsigned a) {
@@ -586,10 +589,13 @@ __device__ __forceinline__ void px_make(const f32x4 (&st)[2][16], int s, const f
     pb[qt] = pack2(a, b);
   }
 }
-template <int RB, int S, int NDT, bool SUM, int... DTS>
+// HOOK: called once per 32-key step with the step's index as an integral_constant, in front of the step's reads (round 6: the five
+// DMA pieces of K(n + 2) ride in steps 0..4 instead of going out as a burst in front of the product)
+template <int RB, int S, int NDT, bool SUM, typename HOOK, int... DTS>
 __device__ __forceinline__ void pvx_step(unsigned vb, const f32x4 (&st)[2][16], const float (&mneg)[2], float sc2, float (&sum)[2],
                                          bool noexp, f32x4 (&ot)[2][NDT], bf16x8 (&pc)[2], bf16x8 (&pn)[2], bf16x8 (&cur)[NDT],
-                                         bf16x8 (&nxt)[NDT], std::integer_sequence<int, DTS...> seq) {
+                                         bf16x8 (&nxt)[NDT], HOOK& hook, std::integer_sequence<int, DTS...> seq) {
+  hook(std::integral_constant<int, S>{});
   if constexpr (S + 1 < 8) {
     pvu_load<RB, S + 1, NDT>(vb, nxt, seq);
     px_make<SUM>(st, S + 1, mneg, sc2, pn, sum, noexp);
@@ -600,22 +606,22 @@ __device__ __forceinline__ void pvx_step(unsigned vb, const f32x4 (&st)[2][16], 
     ((ot[0][DTS] = MFMA(cur[DTS], pc[0], ot[0][DTS]), ot[1][DTS] = MFMA(cur[DTS], pc[1], ot[1][DTS])), ...);
   ATTN_LDS_WAIT();
 }
-template <int RB, int NDT, bool SUM>
+template <int RB, int NDT, bool SUM, typename HOOK>
 __device__ __forceinline__ void pvx_all(unsigned vb, const f32x4 (&st)[2][16], const float (&mneg)[2], float sc2, float (&sum)[2],
-                                        bool noexp, f32x4 (&ot)[2][NDT]) {
+                                        bool noexp, f32x4 (&ot)[2][NDT], HOOK hook) {
   constexpr auto seq = std::make_integer_sequence<int, NDT>{};
   bf16x8 va[NDT], vb2[NDT], pa[2], pb2[2];
   pvu_load<RB, 0, NDT>(vb, va, seq);
   px_make<SUM>(st, 0, mneg, sc2, pa, sum, noexp);
   ATTN_LDS_WAIT();
-  pvx_step<RB, 0, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
-  pvx_step<RB, 1, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
-  pvx_step<RB, 2, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
-  pvx_step<RB, 3, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
-  pvx_step<RB, 4, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
-  pvx_step<RB, 5, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
-  pvx_step<RB, 6, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, seq);
-  pvx_step<RB, 7, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, seq);
+  pvx_step<RB, 0, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, hook, seq);
+  pvx_step<RB, 1, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, hook, seq);
+  pvx_step<RB, 2, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, hook, seq);
+  pvx_step<RB, 3, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, hook, seq);
+  pvx_step<RB, 4, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, hook, seq);
+  pvx_step<RB, 5, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, hook, seq);
+  pvx_step<RB, 6, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pa, pb2, va, vb2, hook, seq);
+  pvx_step<RB, 7, NDT, SUM>(vb, st, mneg, sc2, sum, noexp, ot, pb2, pa, vb2, va, hook, seq);
 }
 
 template <int OFF>
@@ -727,6 +733,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
 #pragma unroll
     for (int j = 0; j < 5; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wave_rows + j * 1024), 16, voff[j], 0, 0, REED_ATTN_LD_AUX);
+  };
+  auto issue_piece = [&](char* wave_rows, __amdgpu_buffer_rsrc_t rs, int j) {   // j: a literal after inlining
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wave_rows + j * 1024), 16, voff[j], 0, 0, REED_ATTN_LD_AUX);
   };
   auto base_of = [&](int item) -> const bf16* {
     if (item >= nitems) return nullptr;
@@ -944,7 +953,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     if (ONES && lane < 32) *(bf16*)(Vw + lane * ROWF + HD * 2) = (bf16)1.0f;   // own rows, behind own pieces: the ones column
     ATTN_BARRIER();
     ATTN_STAMP(5);
-    issue(Kb + par * TILE_F + wave * 32 * ROWF, plus(base_of(it + 2 * G), D));
+    // K(n + 2): with the exponentials inside the PV product (PVX) its five pieces ride in the product's first five 32-key steps
+    // — as a burst here the forty pieces of the eight waves queued in front of every wave's first MFMAs (REED_ATTN_KSPREAD=0: A/B)
+    char* const k2rows = Kb + par * TILE_F + wave * 32 * ROWF;
+    const __amdgpu_buffer_rsrc_t k2rs = mk_rsrc(plus(base_of(it + 2 * G), D), win);
+    constexpr bool KSPREAD = PVX && REED_ATTN_KSPREAD;
+    if constexpr (!KSPREAD) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) issue_piece(k2rows, k2rs, j);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- O^T = V^T P^T ----------------
     f32x4 ot[2][DT];
@@ -956,7 +973,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
       } else if (FULL && !PVX) {
         pvu_all<ROWF, 8, DT>(vb, pb, ot);
       } else if (FULL) {
-        pvx_all<ROWF, DT, !ONES>(vb, st, mrow, sc2, lrow, DBGK && (dbg & 2), ot);
+        pvx_all<ROWF, DT, !ONES>(vb, st, mrow, sc2, lrow, DBGK && (dbg & 2), ot, [&](auto s_c) {
+          constexpr int S = decltype(s_c)::value;
+          if constexpr (KSPREAD && S < 5) issue_piece(k2rows, k2rs, S);
+        });
         if (!ONES) {
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
