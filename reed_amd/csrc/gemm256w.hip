@@ -954,6 +954,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w_tn_group_kernel(TnGroupW g) {
 // 0.637 -> 0.618 ms, fc1 / qkv dgrads 0.564 -> 0.546 / 0.430 -> 0.417 —, the 3456- / 4608-wide ones groups of 4 (fc1 forward
 // 0.684 vs 0.720 with 2).
 int w_tile_group_rows(const GemmArgs& a) {
+#ifdef REED_TILE_GM_ENV   // diagnostic build only (tools/r6/gm_sweep.sh): the tile rows per XCD-local group from the environment
+  if (const char* e = getenv("REED_TILE_GM")) return atoi(e) > 0 ? atoi(e) : 4;
+#endif
   if (cdiv(a.M, WBM) < 192) return 4;   // b = 128: 1157 (4 everywhere) vs 1151 images/s with the per-shape choice
   const int ntn = cdiv(a.N, WBN);
   return ntn <= 6 ? 2 : ntn >= 16 ? 5 : 4;   // (4608-wide: fc1 forward 0.688 -> 0.675, fc2 dgrad 0.727 -> 0.721 with 5)
