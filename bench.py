@@ -189,7 +189,7 @@ def random_fill(model, seed):
 TRAFFIC_B256 = None
 TRAFFIC_SOURCE = None
 try:
-    with open(os.path.join(ROOT, "profiles", "r5_traffic.json")) as _f:
+    with open(os.path.join(ROOT, "profiles", "r6_traffic.json")) as _f:
         _t = json.load(_f)
         TRAFFIC_B256, TRAFFIC_SOURCE = _t["wgrad_group_b256_bytes_per_launch"], _t["source"]
 except Exception:

@@ -29,7 +29,12 @@ class Engine:
     # 1 GPU x 256 and 8 GPUs x 32 of the same global batch do not give the same gradient bits unless the form is pinned
     # (train.py --save-act-grad {auto,0,1}; bench.py --save-act-grad).
     SAVE_ACT_GRAD_MIN_TOKENS = 12288
-    WGRAD_STREAM_MAX_TOKENS = 12288
+    # (Round 6: 0 = never by default.  With the one-item-per-CU weight-gradient launch the second stream measures equal at b = 32 —
+    # 957.1 / 965.8 images/s with it, 963.7 / 958.4 without (profiles/r6_b32_side_stream_choices.txt) — and on the timeline it only
+    # parks the main queue's row kernels behind a launch that holds every CU (ln_mod_bwd2: 131 us per launch for 30 us of work).
+    # REED_WGRAD_STREAM=1 / engine.wgrad_stream = True switch it on; rounds 2-5 used it up to 12288 tokens: + 3.7 % at b = 32 with
+    # the kernels of that time.)
+    WGRAD_STREAM_MAX_TOKENS = 0
 
     def __init__(self, model):
         self.m = model
@@ -60,8 +65,7 @@ class Engine:
         self._ws_side = None
         self.split_ada_wgrad = None   # None: per-block adaLN weight gradients iff a reducer is attached (see backward)
         self._side = None        # second HIP stream: the blocks' weight-gradient GEMMs run beside the dgrad chain
-        # True / False / None = auto: on when the local batch is small enough that one-round GEMM grids leave CUs idle
-        # (measured on MI355X, SiT-XL/2: +3.7 % at b = 32, -1 % at 64, -5 % at 128 and 256)
+        # True / False / None = by WGRAD_STREAM_MAX_TOKENS (above)
         self.wgrad_stream = {"0": False, "1": True}.get(os.environ.get("REED_WGRAD_STREAM", "auto"))
         self.wgrad_stream_max_tokens = self.WGRAD_STREAM_MAX_TOKENS
         self.grad_live = False   # True: param grads hold a previous micro-step -> accumulate
