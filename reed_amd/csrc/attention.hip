@@ -511,6 +511,9 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 //   Q(n) landed  <=> at most K(n+1) 5 + V(n) 5 + stores(n-1) 7 = 17 younger
 //   V(n) landed  <=> at most stores(n-1) 7 + Q(n+1) 5 = 12 younger
 //   K(n+1) landed <=> at most V(n) 5 + stores(n-1) 7 + Q(n+1) 5 + K(n+2) 5 = 22 younger
+#ifndef REED_ATTN_FWD_VDB_DEFAULT
+#define REED_ATTN_FWD_VDB_DEFAULT 1
+#endif
 #ifndef REED_ATTN_KSPREAD   // 1: K(n + 2)'s pieces ride in the PV product's first steps — measured equal to the burst (profiles/r6_attn_fwd_kspread.txt)
 #define REED_ATTN_KSPREAD 0
 #endif
@@ -641,11 +644,18 @@ __device__ __forceinline__ void sk_load(unsigned ka, unsigned kaw, bf16x8 (&kf)[
   kf[1] = lds_read128_off<KT * 16 * RB + 64>(ka);
   if constexpr (KS == 3) kf[2] = lds_read128_off<KT * 16 * RB + 128>(HD % 32 != 0 ? kaw : ka);
 }
-template <int HD, int RB, int KT, int NKT>
+// HOOK: called with the tile's index as an integral_constant in front of the tile's work (attn_fwd256v_kernel: the read-backs,
+// DMA pieces and stores that ride in S)
+struct SkNoHook {
+  template <typename C>
+  __device__ __forceinline__ void operator()(C) const {}
+};
+template <int HD, int RB, int KT, int NKT, typename HOOK>
 __device__ __forceinline__ void sk_step(unsigned ka, unsigned kaw, const bf16x8 (&qf)[2][Cfg<HD>::KS], f32x4 (&st)[2][16],
-                                        bf16x8 (&cur)[Cfg<HD>::KS], bf16x8 (&nxt)[Cfg<HD>::KS]) {
+                                        bf16x8 (&cur)[Cfg<HD>::KS], bf16x8 (&nxt)[Cfg<HD>::KS], HOOK& hook) {
   constexpr int KS = Cfg<HD>::KS;
   if constexpr (KT < NKT) {
+    hook(std::integral_constant<int, KT>{});
     if constexpr (KT + 1 < NKT) sk_load<HD, RB, KT + 1>(ka, kaw, nxt);
     st[0][KT] = MFMA(cur[0], qf[0][0], zero4());
     st[1][KT] = MFMA(cur[0], qf[1][0], zero4());
@@ -657,27 +667,28 @@ __device__ __forceinline__ void sk_step(unsigned ka, unsigned kaw, const bf16x8 
     ATTN_LDS_WAIT();
   }
 }
-template <int HD, int RB>
-__device__ __forceinline__ void sk_all(unsigned ka, unsigned kaw, const bf16x8 (&qf)[2][Cfg<HD>::KS], f32x4 (&st)[2][16]) {
+template <int HD, int RB, typename HOOK = SkNoHook>
+__device__ __forceinline__ void sk_all(unsigned ka, unsigned kaw, const bf16x8 (&qf)[2][Cfg<HD>::KS], f32x4 (&st)[2][16],
+                                       HOOK hook = HOOK{}) {
   bf16x8 fa[Cfg<HD>::KS], fb[Cfg<HD>::KS];
   sk_load<HD, RB, 0>(ka, kaw, fa);
   ATTN_LDS_WAIT();
-  sk_step<HD, RB, 0, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 1, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 2, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 3, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 4, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 5, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 6, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 7, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 8, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 9, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 10, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 11, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 12, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 13, 16>(ka, kaw, qf, st, fb, fa);
-  sk_step<HD, RB, 14, 16>(ka, kaw, qf, st, fa, fb);
-  sk_step<HD, RB, 15, 16>(ka, kaw, qf, st, fb, fa);
+  sk_step<HD, RB, 0, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 1, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 2, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 3, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 4, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 5, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 6, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 7, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 8, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 9, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 10, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 11, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 12, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 13, 16>(ka, kaw, qf, st, fb, fa, hook);
+  sk_step<HD, RB, 14, 16>(ka, kaw, qf, st, fa, fb, hook);
+  sk_step<HD, RB, 15, 16>(ka, kaw, qf, st, fb, fa, hook);
 }
 // two floats -> one dword of two 16-bit operands (v_cvt_pk_bf16_f32 / v_cvt_pkrtz... of the build's operand type)
 __device__ __forceinline__ unsigned pk2(float a, float b) {
@@ -1010,6 +1021,236 @@ __global__ __launch_bounds__(512, 2) void attn_fwd256p_kernel(const bf16* __rest
     for (int k = 0; k < 10; ++k) dst[k] = tacc[k];
   }
 #undef ATTN_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the T = 256 forward with the V tile DOUBLE-BUFFERED (LDS = K | V x 2 | Q instead of K x 2 | V | Q; verdict item 2: spread
+// the operand issue along the item).  attn_fwd256p_kernel ends every item with a burst — V(n+1) (five pieces) and the output of item
+// n (five row pieces + lse) per wave: 12 of the item's 22 vector-memory instructions, issued by all eight waves behind the same
+// barrier, through a memory path that takes ~12 B/clk per CU: 8.1 k of the younger waves' 21.4 k cycles per item with the matrix
+// pipes idle (profiles/r4_attn_fwd_stamps.txt).  Here nothing is issued at the end of an item:
+//   * O(n) is staged (normalised, rounded) into the wave's own 32 rows of V[n & 1] behind the barrier that ends PV(n), as before;
+//   * its read-back and stores ride in S(n+1), one piece per two key tiles, and V(n+2) piece k is issued right behind read-back k
+//     into the very bytes it freed (read-back piece k = DMA piece k: both are the k-th KiB of the wave's rows) — V(n+2) is first
+//     read two PV products later;
+//   * K is single-buffered: K(n+1) is issued behind the barrier that ends S(n) (every wave has read K(n)) and waited for behind
+//     PV(n) — a whole PV product ahead of its first read.
+// Issue order per wave and item n, [count]:  start: Q(n+1)[5] | in S(n): V(n+1)[5] interleaved with O(n-1) rows[5], lse(n-1)[2] |
+// behind barrier 2: K(n+1)[5].  Counted waits (every vector-memory instruction is issued unconditionally; past the end: empty
+// descriptors):  Q(n) landed <=> at most 12 + K(n) 5 = 17 younger;  V(n) landed <=> at most [store 1 + lse 2] + K(n) 5 + Q(n+1) 5 +
+// 12 = 25 younger;  K(n+1) landed <=> 0 younger.  The prologue issues Q, K, V of the first item and EIGHT dropped stores so that
+// the counts hold from the first item on.  T == 256, head sizes with the exponentials inside the PV product (64, 72) only.
+// KSP: K(n+1)'s pieces ride in the PV product's first five steps; QSP: Q(n+1)'s in S(n)'s last five key tiles — with both the
+// steady-state waits for Q and V are no-ops (everything was drained behind PV(n-1)); they order the first item.
+// Measured at b = 256, hd 72 (profiles/r6_attn_fwd_vdb.txt, one box, alternating): attn_fwd256p_kernel 164-165 us; this kernel with
+// the K and Q bursts kept 154-159; K spread 151-157; K and Q spread 148-150 us = 4.0-4.1 TB/s (the form launched).
+template <int HD, bool KSP = true, bool QSP = true>
+__global__ __launch_bounds__(512, 2) void attn_fwd256v_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                             float* __restrict__ lse, int H, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = 256;
+  constexpr int KS = Cfg<HD>::KS, DT = Cfg<HD>::DT, NCH = Cfg<HD>::NCH;
+  constexpr bool ONES = (HD == 72);
+  static_assert(HD == 64 || HD == 72, "attn_fwd256v_kernel: head_dim 64 or 72");
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * HD;
+  const long tok = 3l * D;
+  const int tokb = (int)(tok * 2);
+  char* const Kw = smem + wave * 32 * ROWF;                    // this wave's rows of the K tile
+  char* const Vt = smem + TILE_F;                              // V[0], V[1]
+  char* const Qw = smem + 3 * TILE_F + wave * 32 * ROWF;       // this wave's 32 query rows
+  const int q0 = wave * 32;
+  const float sc2 = rsqrtf((float)HD) * LOG2E;
+  int voff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) voff[j] = dma_voff<HD, ROWF>((wave * 5 + j) * 64 + lane0, tokb);
+  const long win = tile_window<HD>(T, tokb);
+  auto piece = [&](char* wave_rows, __amdgpu_buffer_rsrc_t rs, int j) {   // j: a literal after inlining
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wave_rows + j * 1024), 16, voff[j], 0, 0, REED_ATTN_LD_AUX);
+  };
+  auto issue = [&](char* wave_rows, const bf16* base) {
+    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(base, win);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) piece(wave_rows, rs, j);
+  };
+  auto base_of = [&](int item) -> const bf16* {
+    if (item >= nitems) return nullptr;
+    const int b = item / H, h = item - b * H;
+    return qkv + (long)b * T * tok + h * HD;
+  };
+  auto plus = [](const bf16* p_, long n) -> const bf16* { return p_ ? p_ + n : nullptr; };
+  const int G = gridDim.x;
+  constexpr int RST = ROWB;             // staging rows inside the wave's 32 V rows (attn_fwd256p_kernel: round 5)
+  constexpr int NQ = 32 * NCH;
+  float lsev[2] = {0.f, 0.f};
+  f32x4 st[2][16];
+
+  int it = xcd_contiguous(blockIdx.x, G);
+  {
+    const bf16* b0 = base_of(it);
+    issue(Qw, b0);
+    issue(Kw, plus(b0, D));
+    issue(Vt + wave * 32 * ROWF, plus(b0, 2 * D));
+    const __amdgpu_buffer_rsrc_t none = mk_rsrc(nullptr, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_buffer_store_b32((unsigned)(k + lane0), none, DMA_OOB - 256 * k, 0, 0);
+    asm volatile("s_waitcnt vmcnt(13)" ::: "memory");   // Q, K of the first item (younger: its V, the 8 stores)
+    ATTN_BARRIER();
+  }
+  int par = 0, pit = -1;   // V buffer of the item in hand; the previous item of this workgroup (its output is staged in V[par ^ 1])
+  for (; it < nitems; it += G, par ^= 1) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+    char* const Vcur = Vt + par * TILE_F;
+    char* const Vprev_w = Vt + (par ^ 1) * TILE_F + wave * 32 * ROWF;   // own rows: O(pit) staged; V(n+1) lands here
+    // ---- Q(n): own patch, own wait
+    asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 qf[2][KS];
+    {
+      const unsigned qa = lds_addr(Qw + i * ROWF + 16 * g);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bool wrap = HD % 32 != 0 && ks == KS - 1;
+          const unsigned a = qa + qt * 16 * ROWF + ks * 64 - ((wrap && g >= 2) ? 32 : 0);
+          qf[qt][ks] = lds_read128_asm(a);
+        }
+      ATTN_LDS_WAIT();
+      if (HD % 32 != 0 && g >= 2) { qf[0][KS - 1] = zero_frag(); qf[1][KS - 1] = zero_frag(); }
+    }
+    const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base_of(it + G), win);
+    if constexpr (!QSP) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) piece(Qw, rsQ, j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S(n) = K(n) Q(n)^T; in it: the previous item's output out, V(n+1) in
+    {
+      const int pb_ = pit < 0 ? 0 : pit / H, ph = pit < 0 ? 0 : pit - pb_ * H;
+      const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(pit < 0 ? nullptr : o + (long)pb_ * T * D + ph * HD, tile_window<HD>(T, D * 2));
+      const __amdgpu_buffer_rsrc_t rsL = mk_rsrc((lse && pit >= 0) ? lse + ((long)pb_ * H + ph) * T : nullptr, (long)T * 4);
+      const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(plus(base_of(it + G), 2 * D), win);
+      u32x4 pc = {0u, 0u, 0u, 0u};
+      const unsigned ka = lds_addr(smem + i * ROWF + 16 * g);
+      sk_all<HD, ROWF>(ka, ka - (g >= 2 ? 32 : 0), qf, st, [&](auto kt_c) {
+        constexpr int KT = decltype(kt_c)::value;
+        if constexpr (KT < 10 && (KT & 1) == 0) {          // read-back of row piece k (waited for at the end of this tile)
+          constexpr int k = KT / 2;
+          const int qi = min(lane + 64 * k, NQ - 1);
+          const int rr = qi / NCH, c = qi - rr * NCH;
+          pc = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vprev_w + rr * RST + c * 16)));
+        } else if constexpr (KT < 10) {                    // V(n+1) piece k into the bytes just read; the row piece out
+          constexpr int k = KT / 2;
+          piece(Vprev_w, rsV, k);
+          const int qi = lane + 64 * k;
+          const int rr = qi / NCH, c = qi - rr * NCH;
+          __builtin_amdgcn_raw_buffer_store_b128(pc, rsO, qi < NQ ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
+        } else if constexpr (KT < 12) {
+          constexpr int qt = KT - 10;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL,
+                                                g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
+        }
+        if constexpr (QSP && KT >= 11) piece(Qw, rsQ, KT - 11);
+      });
+    }
+    // ---- row maxima (the exponentials are formed inside the PV product)
+    float mrow[2], lrow[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mrow[qt] = mx * sc2;
+      lrow[qt] = 0.f;
+    }
+    // ---- V(n) landed; every wave is past S(n): K(n+1) may overwrite K(n)
+    asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (ONES && lane < 32) *(bf16*)(Vcur + (wave * 32 + lane) * ROWF + HD * 2) = (bf16)1.0f;   // own rows, behind own pieces
+    ATTN_BARRIER();
+    const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(plus(base_of(it + G), D), win);
+    if constexpr (!KSP) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) piece(Kw, rsK, j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T = V^T P^T
+    f32x4 ot[2][DT];
+    {
+      const unsigned vb = lds_addr(Vcur + (4 * g + (i >> 2)) * ROWF + (i & 3) * 8);
+      pvx_all<ROWF, DT, !ONES>(vb, st, mrow, sc2, lrow, false, ot, [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        if constexpr (KSP && S < 5) piece(Kw, rsK, S);
+      });
+      if (!ONES) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          lrow[qt] += __shfl_xor(lrow[qt], 16, 64);
+          lrow[qt] += __shfl_xor(lrow[qt], 32, 64);
+        }
+      }
+    }
+    // ---- K(n+1) landed (this wave's pieces); behind the barrier: every wave's, and every wave is past its reads of V[par]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ATTN_BARRIER();
+    // ---- O(n): normalised, rounded, into the wave's own rows of V[par]; it leaves in S of this workgroup's next item
+    {
+      char* const Vw = Vcur + wave * 32 * ROWF;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        if (ONES) l = __shfl(ot[qt][DT - 1][0], 32 + i, 64);
+        const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = 16 * dt + 4 * g;
+          const u32x2 v = {pk2(ot[qt][dt][0] * inv, ot[qt][dt][1] * inv), pk2(ot[qt][dt][2] * inv, ot[qt][dt][3] * inv)};
+          if (16 * dt + 16 <= HD || d < HD) *(u32x2*)(Vw + (16 * qt + i) * RST + d * 2) = v;
+        }
+        lsev[qt] = mrow[qt] * LN2 + __logf(l);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pit = it;
+  }
+  // the last item's output (staged in V[par ^ 1] after the loop's last flip)
+  if (pit >= 0) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int i = lane & 15, g = lane >> 4;
+    const char* const Vw = Vt + (par ^ 1) * TILE_F + wave * 32 * ROWF;
+    const int pb_ = pit / H, ph = pit - pb_ * H;
+    const __amdgpu_buffer_rsrc_t rsO = mk_rsrc(o + (long)pb_ * T * D + ph * HD, tile_window<HD>(T, D * 2));
+    const __amdgpu_buffer_rsrc_t rsL = mk_rsrc(lse ? lse + ((long)pb_ * H + ph) * T : nullptr, (long)T * 4);
+    u32x4 pcs[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int qi = min(lane + 64 * k, NQ - 1);
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      pcs[k] = __builtin_bit_cast(u32x4, lds_read128_asm(lds_addr(Vw + rr * RST + c * 16)));
+    }
+    ATTN_LDS_WAIT();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int qi = lane + 64 * k;
+      const int rr = qi / NCH, c = qi - rr * NCH;
+      __builtin_amdgcn_raw_buffer_store_b128(pcs[k], rsO, qi < NQ ? (q0 + rr) * (D * 2) + c * 16 : DMA_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lsev[qt]), rsL, g == 0 ? (q0 + 16 * qt + i) * 4 : DMA_OOB, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero fills of the items past the end: LDS stays allocated until they land
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2121,6 +2362,21 @@ extern "C" int reed_attention_fwd(const void* qkv, void* o, float* lse, int B, i
 #else
     constexpr int fdbg = 0;
 #endif
+    // T == 256, head_dim 64 / 72 (the training path): the forward with the V tile double-buffered (attn_fwd256v_kernel, round 6);
+    // -DREED_ATTN_FWD_VDB_DEFAULT=0 builds keep attn_fwd256p_kernel there (A/B), which stays the kernel of T < 256 and head_dim 80
+    if (REED_ATTN_FWD_VDB_DEFAULT && T == 256 && (hd == 64 || hd == 72) && !fdbg) {
+      if (hd == 64) {
+        static int once = set_lds(attn_fwd256v_kernel<64>, lds);
+        if (once) return once;
+        REED_KLAUNCH((attn_fwd256v_kernel<64>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, H, nitems);
+      } else {
+        static int once = set_lds(attn_fwd256v_kernel<72>, lds);
+        if (once) return once;
+        REED_KLAUNCH((attn_fwd256v_kernel<72>), grid, dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, H, nitems);
+      }
+      REED_LAUNCH_CHECK();
+      return REED_OK;
+    }
 #define LAUNCH_FWD256P(HD, FULL, DBGK)                                                                                 \
     do {                                                                                                               \
       static int once = set_lds(attn_fwd256p_kernel<HD, FULL, DBGK>, lds);                                             \

@@ -602,16 +602,17 @@ def test_bench_launcher_argv(monkeypatch):
 
 
 def test_counted_waits_of_the_attention_forward_match_the_isa():
-    """attn_fwd256p_kernel waits with s_waitcnt vmcnt(N) for immediates derived from how many vector-memory instructions a wave
-    issues per item: compile csrc/attention.hip to gfx950 ISA (hipcc cross-compiles here) and count them in every instantiation —
-    20 + 7 before the item loop, 15 + 7 per item, the waits in the expected order, no scratch traffic (tools/check_attn_isa.py; the
-    compiler once merged seven identical prologue stores into one, which left the first item's waits six operations short)."""
+    """attn_fwd256p_kernel and (round 6) attn_fwd256v_kernel wait with s_waitcnt vmcnt(N) for immediates derived from how many
+    vector-memory instructions a wave issues per item: compile csrc/attention.hip to gfx950 ISA (hipcc cross-compiles here) and count
+    them in every instantiation — 20 + 7 before the item loop and 15 + 7 per item (attn_fwd256p_kernel), 15 + 8 before, 15 + 7 per
+    item and 7 behind the loop (attn_fwd256v_kernel), the waits in the expected order, no scratch traffic (tools/check_attn_isa.py;
+    the compiler once merged seven identical prologue stores into one, which left the first item's waits six operations short)."""
     import subprocess
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_attn_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok  ") == 6 and "BAD" not in r.stdout, r.stdout   # hd 64 / 72 / 80 x (T = 256, T < 256)
+    assert r.stdout.count("ok  ") == 8 and "BAD" not in r.stdout, r.stdout   # hd 64 / 72 / 80 x (T = 256, T < 256) + the V-double-buffered 64 / 72
 
 
 def test_detfill_matches_the_fixture_recipe():
