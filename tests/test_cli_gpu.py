@@ -609,6 +609,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     assert "error" not in lv, lv
     assert lv["steps"] == 5 and lv["bar"] == 1e-3 and lv["within_bar"] is True and lv["max_abs_delta_bf16"] <= 1e-3, lv
     assert len(lv["hip_loss"]) == 5 and len(lv["reference_bf16_autocast_loss"]) == 5
+    # the legs the N = 1 run appends (C4, C5 at its real 499 evaluations, N2, N4) and the kernel forms of the plan
+    assert d["c4_per_gpu_leg"]["images_per_sec_per_gpu"] > 0 and d["c5_sampler_leg"].get("finite", True) and "error" not in d["c5_sampler_leg"]
+    assert "error" not in d["n2_encoder_leg"] and d["n4_vae_decode"]["finite"] is True
+    kf = d["kernel_forms"]
+    assert kf["tokens_per_gpu"] == 32 * 256 and kf["activation_backward"].startswith("recomputed") and kf["weight_gradients_on_a_second_stream"] is False
 
 
 def test_bench_stdout_is_one_line_under_a_reducer(dev):
@@ -616,7 +621,8 @@ def test_bench_stdout_is_one_line_under_a_reducer(dev):
     prints a version banner on stdout when the communicator is created — stdout must still be the one JSON line."""
     env = dict(os.environ, REED_FORCE_REDUCER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--global-batch", "16", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-kernel-table"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+                        "--no-cpu-baseline", "--no-kernel-table", "--no-config-legs", "--no-vae-leg", "--no-loss-vs-ref"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -635,7 +641,8 @@ def test_bench_self_launch(dev):
                        text=True, timeout=120)
     assert r.returncode == 2 and r.stdout.strip() == "" and "only 1 GPU" in r.stderr and time.time() - t0 < 60
     r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1", "--model", "SiT-XL/2", "--global-batch", "64",
-                        "--no-cpu-baseline", "--no-kernel-table"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-kernel-table", "--no-config-legs", "--no-vae-leg", "--no-loss-vs-ref"], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -643,6 +650,11 @@ def test_bench_self_launch(dev):
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["local_batch"] == 64
     leg = d["c3_per_gpu_leg"]
     assert leg["local_batch"] == 32 and leg["images_per_sec_per_gpu"] > 0 and np.isfinite(leg["final_loss"])
+    # (round 6) the leg's second process: the data-parallel code path at world 1 — reducer, buckets, kernel forms beside collectives
+    dp1 = leg["data_parallel_code_path_at_world_1"]
+    assert "error" not in dp1, dp1
+    assert dp1["images_per_sec_per_gpu"] > 0 and dp1["data_parallel"]["world"] == 1 and dp1["data_parallel"]["buckets"] > 0
+    assert "torch binding" in dp1["plan"] and "with_optimizer_pass_sharded_8_ways" not in leg
 
 
 def test_bench_two_ranks_rehearsal(dev):
