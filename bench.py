@@ -45,6 +45,8 @@ def parse(argv=None):
                          "operands with dynamic loss scaling)")
     ap.add_argument("--save-act-grad", choices=["auto", "0", "1"], default="auto",
                     help="the activation backward (engine.save_act_grad): auto = by tokens per GPU, 1 = saved derivative, 0 = recomputed")
+    ap.add_argument("--dgrad-nt", choices=["auto", "0", "1"], default="auto",
+                    help="the blocks' input gradients as NT GEMMs on a transposed copy of the weights (engine.dgrad_nt): auto = by tokens per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the C4 (text + image alignment), C5 (sampler) and N2 (frozen encoder) legs the N = 1 run appends")
@@ -605,6 +607,7 @@ def main():
     model.precision = args.mixed_precision
     random_fill(model, 1234)  # identical on every rank (same seed); broadcast below anyway
     model.engine().save_act_grad = {"auto": None, "0": False, "1": True}[args.save_act_grad]
+    model.engine().dgrad_nt = {"auto": None, "0": False, "1": True}[args.dgrad_nt]
     ema = copy.deepcopy(model).requires_grad_(False).eval()
     opt = FusedAdamWEMA(model, ema, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, max_grad_norm=1.0)
     reducer = None
@@ -841,6 +844,9 @@ def main():
             "activation_backward": ("saved derivative (epilogues 14 / 16)" if (eng.save_act_grad if eng.save_act_grad is not None else b * T_TOK > eng.SAVE_ACT_GRAD_MIN_TOKENS)
                                     else "recomputed (epilogues 1 / 4)"),
             "activation_backward_rule": f"saved derivative above {eng.SAVE_ACT_GRAD_MIN_TOKENS} tokens per GPU (engine.save_act_grad = {eng.save_act_grad})",
+            "input_gradients": ("NT GEMMs on transposed weight copies" if (eng.dgrad_nt if eng.dgrad_nt is not None else (eng.DGRAD_NT_MIN_TOKENS is not None and b * T_TOK >= eng.DGRAD_NT_MIN_TOKENS))
+                                else "NN GEMMs on the weights as they are"),
+            "input_gradient_rule": f"NT on W^T from {eng.DGRAD_NT_MIN_TOKENS} tokens per GPU (engine.dgrad_nt = {eng.dgrad_nt})",
             "weight_gradients_on_a_second_stream": bool(eng.wgrad_stream if eng.wgrad_stream is not None else b * T_TOK <= eng.WGRAD_STREAM_MAX_TOKENS),
             "weight_gradient_stream_rule": f"second stream up to {eng.WGRAD_STREAM_MAX_TOKENS} tokens per GPU (engine.wgrad_stream = {eng.wgrad_stream})",
             "library": {k: getattr(v, "_name", None) for k, v in __import__("reed_amd._lib", fromlist=["loaded"]).loaded().items()},

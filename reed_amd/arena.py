@@ -142,6 +142,16 @@ class ParamArena:
         # (reed_amd/optim.py, overlap=True). Whoever reads weights waits for the range it needs (Engine.forward,
         # per block) or for everything (state_dict, EMA forward): wait() / wait_all().
         self.pending = OrderedDict()
+        # Round 6: a TRANSPOSED 16-bit copy of the blocks' linear weights (W^T [k_in, n_out] per weight), so that the input
+        # gradients run as NT GEMMs — both operands k-contiguous: one ds_read_b128 per fragment where the k-strided weight takes
+        # two transposing reads — 3.6-5 % faster at b = 256, the same bits (profiles/r6_dgrad_nt_on_transposed_weights.txt).
+        # Built on first use (Engine.backward), kept fresh by the fused optimiser on its side stream (block by block behind the
+        # block's update chunk: it is first read a whole forward later), rebuilt here whenever it is older than the shadow.
+        self.shadow_t = None
+        self.t_seg = None          # name -> (offset in shadow_t, n_out, k_in)
+        self.shadow_gen = 0        # bumped whenever the shadow changes (a cast of the master; an optimiser step)
+        self.shadow_t_gen = -1
+        self.pending_t = None      # event behind the optimiser's transposes
 
     def wait(self, name):
         """Order the current stream after the optimiser's update of bucket `name` (no-op when none is in flight)."""
@@ -180,7 +190,52 @@ class ParamArena:
             finally:
                 ops.use(prev)
             self.shadow_version = self.master._version
+            self.shadow_gen += 1
         return self.shadow
 
     def mark_shadow_fresh(self):
         self.shadow_version = self.master._version
+        self.shadow_gen += 1
+
+    def t_names(self):
+        """The weights that have a transposed copy: the four linears of every block."""
+        return [f"blocks.{i}.{w}.weight" for i in range(self.layout.depth) for w in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")]
+
+    def transpose_block(self, i):
+        """W^T of block i's four linears from the shadow, on the current stream (the caller orders it behind the shadow's update)."""
+        from . import ops
+        es = self.shadow.element_size()
+        for w in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            name = f"blocks.{i}.{w}.weight"
+            toff, n_out, k_in = self.t_seg[name]
+            ops.transpose_bf16(self.shadow.data_ptr() + es * self.layout.off(name), self.shadow_t.data_ptr() + es * toff, n_out, k_in)
+
+    def ensure_shadow_t(self, precision="bf16"):
+        """The transposed copies, as fresh as the shadow (which the caller has ensured): allocate on first use; rebuild everything
+        on the current stream if an update happened that did not refresh them (a cast of the master, a non-overlapped optimiser
+        step); otherwise just order the current stream behind the optimiser's own transposes."""
+        from . import ops
+        if self.shadow.element_size() != 2:
+            return None
+        if self.shadow_t is None or self.shadow_t.dtype != self.shadow.dtype:
+            self.t_seg, off = {}, 0
+            for name in self.t_names():
+                n_out, k_in = self.layout.seg[name][1]
+                self.t_seg[name] = (off, int(n_out), int(k_in))
+                off += int(n_out) * int(k_in)
+            self.shadow_t = torch.empty(off, dtype=self.shadow.dtype, device=self.device)
+            self.shadow_t_gen = -1
+        if self.shadow_t_gen != self.shadow_gen:
+            self.wait_all()
+            self.pending_t = None
+            prev = ops.use(precision)
+            try:
+                for i in range(self.layout.depth):
+                    self.transpose_block(i)
+            finally:
+                ops.use(prev)
+            self.shadow_t_gen = self.shadow_gen
+        elif self.pending_t is not None:
+            torch.cuda.current_stream().wait_event(self.pending_t)
+            self.pending_t = None
+        return self.shadow_t

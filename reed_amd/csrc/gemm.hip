@@ -240,9 +240,9 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
   // stores plainly and lets reed_attention_bwd_ws form delta itself)
   const int want = epi;
   if (epi == EPI_BF16_DOT) {
-    REED_CHECK_ARG(layout == LAY_NN && a.R && a.C2 && (a.rows_per_gate == 64 || a.rows_per_gate == 72) &&
+    REED_CHECK_ARG((layout == LAY_NN || layout == LAY_NT) && a.R && a.C2 && (a.rows_per_gate == 64 || a.rows_per_gate == 72) &&
                        a.N % a.rows_per_gate == 0 && a.N % 64 == 0 && splits <= 1,
-                   "reed_gemm(epilogue 13): NN, R and C2 given, rows_per_gate = head_dim 64 or 72 dividing N");
+                   "reed_gemm(epilogue 13): NN or NT, R and C2 given, rows_per_gate = head_dim 64 or 72 dividing N");
     epi = EPI_BF16;
   }
 #define REED_ONLY_PLAIN()                                                                             \

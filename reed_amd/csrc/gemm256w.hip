@@ -1066,8 +1066,12 @@ int dispatch256w(int epi, const GemmArgs& a, hipStream_t s) {
       case EPI_LS_RES: return launch256w<LAY, EPI_LS_RES>(a, s);
       case EPI_QGELU: return launch256w<LAY, EPI_QGELU>(a, s);
       case EPI_GELU_ERF: return launch256w<LAY, EPI_GELU_ERF>(a, s);
+      // round 6: the input gradients as NT GEMMs on a transposed copy of the weights (engine.py: both operands k-contiguous)
+      case EPI_BF16_DOT: return launch256w<LAY, EPI_BF16_DOT>(a, s);
+      case EPI_DGELU: return launch256w<LAY, EPI_DGELU>(a, s);
+      case EPI_MUL: return launch256w<LAY, EPI_MUL>(a, s);
     }
-  } else {                         // input gradients
+  } else {                         // input gradients (on the weights as they are: k-strided B operand)
     switch (epi) {
       case EPI_BF16: return launch256w<LAY, EPI_BF16>(a, s);
       case EPI_BF16_DOT: return launch256w<LAY, EPI_BF16_DOT>(a, s);
@@ -1086,7 +1090,8 @@ bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits) 
   // (QuickGELU / exact-GELU epilogues stay on the 8-wave kernel: their VALU work — erff, two roundings per element — needs two
   // waves per SIMD to hide its own latency; measured 0.93 vs 0.64 ms on the ViT-L fc1 shape)
   const bool epi_ok = layout == LAY_NT ? (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_GATE_RES ||
-                                          epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_RES_BF16 || epi == EPI_LS_RES)
+                                          epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_RES_BF16 || epi == EPI_LS_RES ||
+                                          epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_MUL)
                                        : (epi == EPI_BF16 || epi == EPI_BF16_DOT || epi == EPI_DGELU || epi == EPI_DSILU || epi == EPI_MUL);
   return (layout == LAY_NT || layout == LAY_NN) && splits <= 1 && a.K % WBK == 0 && a.K >= 2 * WBK && a.N % 128 == 0 && epi_ok;
 }

@@ -504,6 +504,32 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
     if (c0 + i < C && r0 + tx < R) dst[(long)(c0 + i) * R + r0 + tx] = t[tx][i];
 }
 
+// The same for R, C multiples of 64 with 8-byte global accesses (round 6: the transposed weight copies of the input gradients' NT
+// GEMMs are rebuilt every step behind the optimiser pass — 1.8 GB per step of SiT-XL/2): a lane loads four consecutive columns of a
+// row (16 lanes = one 128-byte row segment), the tile sits in LDS with 33-word rows, and a lane gathers four consecutive ROWS of one
+// column (rows 4 rr .. 4 rr + 3: banks 4 rr + c / 2, conflict-free) into one 8-byte store (16 lanes = 128 bytes of a dst row).
+__global__ __launch_bounds__(256) void transpose_bf16_v4_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R,
+                                                                int C) {
+  __shared__ unsigned short t[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int chunk = threadIdx.x + 256 * pass, row = chunk >> 4, cq = chunk & 15;
+    const uint2 v = *(const uint2*)(src + (long)(r0 + row) * C + c0 + cq * 4);
+    *(unsigned*)&t[row][cq * 4] = v.x;
+    *(unsigned*)&t[row][cq * 4 + 2] = v.y;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int idx = threadIdx.x + 256 * pass, c = idx >> 4, rr = idx & 15;
+    uint2 v;
+    v.x = (unsigned)t[rr * 4][c] | ((unsigned)t[rr * 4 + 1][c] << 16);
+    v.y = (unsigned)t[rr * 4 + 2][c] | ((unsigned)t[rr * 4 + 3][c] << 16);
+    *(uint2*)(dst + (long)(c0 + c) * R + r0 + rr * 4) = v;
+  }
+}
+
 // out[n] (+)= sum over rows of an f32 [R, N] partial buffer (fixed order)
 __global__ __launch_bounds__(256) void rowsum_f32_kernel(const float* __restrict__ part, int R, float* __restrict__ out,
                                                          int N, int accumulate) {
@@ -696,8 +722,11 @@ extern "C" int reed_ln_modulate_bwd_gate(const void* dh, const float* x, const f
 
 extern "C" int reed_transpose_bf16(const void* src, void* dst, int R, int C, void* stream) {
   REED_CHECK_ARG(src && dst && R > 0 && C > 0, "transpose_bf16: bad args");
-  REED_KLAUNCH(transpose_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
-               (const bf16*)src, (bf16*)dst, R, C);
+  if (R % 64 == 0 && C % 64 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 8) == 0)
+    REED_KLAUNCH(transpose_bf16_v4_kernel, dim3(C / 64, R / 64), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, R, C);
+  else
+    REED_KLAUNCH(transpose_bf16_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
+                 (const bf16*)src, (bf16*)dst, R, C);
   REED_LAUNCH_CHECK();
   return REED_OK;
 }

@@ -28,6 +28,9 @@ class Engine:
     # NOTE for comparisons across GPU counts: the two activation-backward forms differ by one bf16 rounding of the derivative, so
     # 1 GPU x 256 and 8 GPUs x 32 of the same global batch do not give the same gradient bits unless the form is pinned
     # (train.py --save-act-grad {auto,0,1}; bench.py --save-act-grad).
+    # (Round 6) the blocks' input gradients as NT GEMMs on a transposed copy of the weights from this many tokens per GPU on
+    # (None: never): + 0.9 GB, kept fresh by the fused optimiser on its side stream; 3.6-5 % per dgrad GEMM at b = 256
+    DGRAD_NT_MIN_TOKENS = 12289
     SAVE_ACT_GRAD_MIN_TOKENS = 12288
     # (Round 6: 0 = never by default.  With the one-item-per-CU weight-gradient launch the second stream measures equal at b = 32 —
     # 957.1 / 965.8 images/s with it, 963.7 / 958.4 without (profiles/r6_b32_side_stream_choices.txt) — and on the timeline it only
@@ -63,6 +66,8 @@ class Engine:
         self._named = None       # [(name, parameter)] and the first trainable parameter, cached for backward
         self._sentinel = None
         self._ws_side = None
+        self._shadow_t = None
+        self.dgrad_nt = None     # True / False / None = by DGRAD_NT_MIN_TOKENS: the blocks' dgrads as NT GEMMs on transposed weights
         self.split_ada_wgrad = None   # None: per-block adaLN weight gradients iff a reducer is attached (see backward)
         self._side = None        # second HIP stream: the blocks' weight-gradient GEMMs run beside the dgrad chain
         # True / False / None = by WGRAD_STREAM_MAX_TOKENS (above)
@@ -364,10 +369,22 @@ class Engine:
         dy.record_stream(side)   # allocated on the main stream: the caching allocator must not hand these
         x.record_stream(side)    # blocks out again before the side stream's reads have finished
 
+    def WT(self, name):
+        """Device address of the transposed 16-bit copy W^T [k_in, n_out] of a block linear's weight (arena.py), or None."""
+        if self._shadow_t is None:
+            return None
+        seg = self.A.t_seg.get(name)
+        return None if seg is None else self._shadow_t.data_ptr() + self._hb * seg[0]
+
     def _dgrad(self, epi, dy, wname, Mtok, N, K, out, **kw):
-        """dx[Mtok,K] = dy[Mtok,N] W[N,K]: NN layout straight on the bf16 weight shadow (W is the k-strided operand,
-        read with transposing LDS reads) — no W^T copies to keep fresh."""
-        ops.gemm(NN, epi, dy, self.W(wname), Mtok, K, N, out, N, K, K, **kw)
+        """dx[Mtok,K] = dy[Mtok,N] W[N,K].  With the transposed copy of the weight (round 6: the blocks' linears above
+        DGRAD_NT_MIN_TOKENS) an NT GEMM on W^T — both operands k-contiguous; otherwise NN straight on the weight shadow (W is the
+        k-strided operand, read with transposing LDS reads).  The same products in the same order: the same bits."""
+        wt = self.WT(wname)
+        if wt is not None:
+            ops.gemm(NT, epi, dy, wt, Mtok, K, N, out, N, N, K, **kw)
+        else:
+            ops.gemm(NN, epi, dy, self.W(wname), Mtok, K, N, out, N, K, K, **kw)
 
     def backward(self, tp, dout, dzs):
         prec = getattr(self.m, "precision", "bf16")
@@ -396,6 +413,9 @@ class Engine:
         Nall = L.ada_rows
         hb = self._hb = hdt.itemsize
         self.A.ensure_grad()
+        # the transposed copies of the blocks' weights (the dgrads' NT operand): built on first use, then kept fresh by the optimiser
+        use_t = self.dgrad_nt if self.dgrad_nt is not None else (self.DGRAD_NT_MIN_TOKENS is not None and M >= self.DGRAD_NT_MIN_TOKENS)
+        self._shadow_t = self.A.ensure_shadow_t(tp.prec) if (use_t and hb == 2) else None
         acc = self.grad_live
         mp = tp.mod.data_ptr()
         ch = T // 16  # 16-row chunks per sample
@@ -557,7 +577,8 @@ class Engine:
             fused = False
             if dot_delta.get(dkey, True) and attn_ws is not None and T <= 256:
                 dpart = f32(M * H * (1 if hd == 64 else 2))
-                fused = dot_delta[dkey] = ops.dgrad_with_head_dots(dy1, self.W(b + "attn.proj.weight"), do, bk.o, dpart, M, D, D, hd)
+                fused = dot_delta[dkey] = ops.dgrad_with_head_dots(dy1, self.W(b + "attn.proj.weight"), do, bk.o, dpart, M, D, D, hd,
+                                                                   wt=self.WT(b + "attn.proj.weight"))
             if fused:
                 ops.attention_bwd_dp(bk.qkv_a, do, bk.lse, dpart, dqkv, attn_ws, B, T, H, hd)
             else:

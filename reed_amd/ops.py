@@ -410,12 +410,17 @@ def attention_bwd_dp(qkv, do, lse, dpart, dqkv, ws, B, T, H, hd):
     _call("reed_attention_bwd_dp", _p(qkv), _p(do), _p(lse), _p(dpart), _p(dqkv), _p(ws), B, T, H, hd, _stream())
 
 
-def dgrad_with_head_dots(dy, w, dx, o, dpart, M, N, K, hd):
+def dgrad_with_head_dots(dy, w, dx, o, dpart, M, N, K, hd, wt=None):
     """dx bf16 [M, K] = dy [M, N] @ w [N, K] and dpart = per-row, per-head partial dot products of dx with o (epilogue 13).
+    wt: the transposed copy w^T [K, N] — the same product as an NT GEMM (both operands k-contiguous).
     False (nothing launched) where this shape's GEMM kernel has no such epilogue: store plainly instead."""
     L = _lib.load(_PRECISION)
-    rc = L.reed_gemm(NN, EPI_BF16_DOT, _p(dy), N, _p(w), K, M, K, N, _p(dx), K, _p(dpart), 0, _p(o), K, None, None, 0, hd, None, 0, 1,
-                     0, _stream())
+    if wt is not None:
+        rc = L.reed_gemm(NT, EPI_BF16_DOT, _p(dy), N, _p(wt), N, M, K, N, _p(dx), K, _p(dpart), 0, _p(o), K, None, None, 0, hd, None, 0,
+                         1, 0, _stream())
+    else:
+        rc = L.reed_gemm(NN, EPI_BF16_DOT, _p(dy), N, _p(w), K, M, K, N, _p(dx), K, _p(dpart), 0, _p(o), K, None, None, 0, hd, None, 0,
+                         1, 0, _stream())
     if rc == 1002:
         return False
     _lib.check(rc, "reed_gemm", L)

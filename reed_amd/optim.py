@@ -98,6 +98,7 @@ class FusedAdamWEMA:
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
         ema_buf = self.ema._arena.master if self.ema is not None else None
+        keep_t = False
         if not self.overlap and not self._want_shard:
             ops.adamw_ema(A.master, A.grad, self.exp_avg, self.exp_avg_sq, ema_buf, A.shadow, L.n_train, L.n_total, nc,
                           self.lr, b1, b2, self.eps, self.weight_decay, bc1, bc2, self.ema_decay, scaler_state=st)
@@ -112,6 +113,9 @@ class FusedAdamWEMA:
                 self._shard = self._shard_plan(L) if self._want_shard else False
             side = self._stream
             side.wait_stream(main)  # grads, clip coefficient
+            # the transposed copies of the blocks' weights (arena.py: the input gradients' NT operand) follow each block's update on
+            # this stream where the engine has asked for them and they were fresh before this step
+            keep_t = A.shadow_t is not None and A.shadow_t_gen == A.shadow_gen and A.shadow_t.dtype == A.shadow.dtype
             pp, gp, sp = A.master.data_ptr(), A.grad.data_ptr(), A.shadow.data_ptr()
             hb = A.shadow.element_size()
             mp, vp = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
@@ -151,9 +155,18 @@ class FusedAdamWEMA:
                         ev = torch.cuda.Event()
                         ev.record(side)
                         A.pending[name] = ev
+            if keep_t:   # behind every chunk (the forward waits for none of this); first read by the next backward
+                with torch.cuda.stream(side):
+                    for i in range(L.depth):
+                        A.transpose_block(i)
+                    evt = torch.cuda.Event()
+                    evt.record(side)
+                A.pending_t = evt
             if self.ema is not None:
                 self.ema._arena.pending["all"] = ev
         A.mark_shadow_fresh()
+        if keep_t:
+            A.shadow_t_gen = A.shadow_gen
         if self.ema is not None:
             self.ema._arena.shadow_version = -1  # EMA master changed behind torch's back: re-cast on next use
 

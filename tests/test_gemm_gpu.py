@@ -603,3 +603,43 @@ def test_ragged_m_split_is_bit_invisible(dev, N, K, force_tile):
     ref = _bf(x.float() @ w.float().t() + b.float()).float()
     torch.testing.assert_close(split[0][:M].float(), ref, atol=2e-2, rtol=2e-2)
     torch.testing.assert_close(split[2][:M].float(), _bf(torch.nn.functional.gelu(ref)).float(), atol=4e-2, rtol=2e-2)   # one bf16 ulp
+
+
+@pytest.mark.parametrize("M,n_out,k_in", [(4096, 1152, 4608), (4096, 4608, 1152), (1024, 1152, 1152), (300 * 16, 3456, 1152)])
+@pytest.mark.parametrize("epi", ["plain", "mul", "dgelu", "dot"])
+def test_dgrad_as_nt_on_transposed_weights_is_bit_identical(dev, M, n_out, k_in, epi, force_tile):
+    """Round 6: the blocks' input gradients dx = dy W run as NT GEMMs on a transposed copy W^T [k_in, n_out] (both operands
+    k-contiguous) instead of NN GEMMs on W (k-strided operand, transposing LDS reads): the same products in the same order — the
+    same bits, for the plain store, the activation-backward epilogues (16: multiply by the saved derivative; 4: dGELU) and the
+    head-dot epilogue 13 (the attention backward's delta where dO is produced: NT too since round 6), on whatever tile runs."""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(M + n_out)
+    dy = _bf(torch.randn(M, n_out, generator=g)).to(dev)
+    w = _bf(torch.randn(n_out, k_in, generator=g) * 0.05).to(dev)
+    wt = w.t().contiguous()
+    r = _bf(torch.randn(M, k_in, generator=g)).to(dev)
+    outs = []
+    for use_t in (False, True):
+        dx = torch.full((M, k_in), float("nan"), dtype=torch.bfloat16, device=dev)
+        if epi == "dot":
+            if k_in % 72:
+                pytest.skip("head_dim 72 rows only")
+            dpart = torch.full((k_in // 72, 2, M), float("nan"), device=dev)
+            ok = ops.dgrad_with_head_dots(dy, w, dx, r, dpart, M, n_out, k_in, 72, wt=wt if use_t else None)
+            if not ok:
+                pytest.skip("this shape's kernel has no head-dot epilogue")
+            outs.append((dx, dpart))
+        else:
+            e = {"plain": ops.EPI_BF16, "mul": ops.EPI_MUL, "dgelu": ops.EPI_DGELU}[epi]
+            kw = {} if epi == "plain" else dict(R=r, ldr=k_in)
+            if use_t:
+                ops.gemm(ops.NT, e, dy, wt, M, k_in, n_out, dx, n_out, n_out, k_in, **kw)
+            else:
+                ops.gemm(ops.NN, e, dy, w, M, k_in, n_out, dx, n_out, k_in, k_in, **kw)
+            outs.append((dx,))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    ref = dy.float() @ w.float()
+    if epi == "plain" or epi == "dot":
+        torch.testing.assert_close(outs[1][0].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2)

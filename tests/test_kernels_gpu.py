@@ -582,3 +582,15 @@ def test_embed_and_final_layer_second_forms_bit_identical(dev, B, D, HW):
     old = run(off8(w), off8(wf))
     for a, b in zip(new, old):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("R,C", [(1152, 4608), (3456, 1152), (384, 1152), (100, 72), (64, 200)])
+def test_transpose_bf16(dev, R, C):
+    """reed_transpose_bf16 (the transposed weight copies of round 6's NT input gradients; the 8-byte-lane form for multiples of 64,
+    the 2-byte-lane form otherwise): exact."""
+    from reed_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    src = torch.randn(R, C, generator=g).to(torch.bfloat16).to(dev)
+    dst = torch.full((C, R), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.transpose_bf16(src, dst, R, C)
+    assert torch.equal(dst, src.t().contiguous())

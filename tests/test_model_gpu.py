@@ -472,6 +472,40 @@ def test_overlapped_optimizer_bit_identical(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_transposed_weight_copies_stay_fresh_and_change_no_bit(dev, overlap):
+    """Round 6: engine.dgrad_nt — the blocks' input gradients as NT GEMMs on transposed 16-bit copies of the weights
+    (arena.shadow_t), built at the first backward and refreshed by the fused optimiser on its side stream behind every update
+    (overlap=True), or rebuilt at the next backward (the single-launch optimiser).  Four steps of SiT-S/2 with alignment: the
+    trajectory, the master weights and the EMA equal the NN path's bit for bit, and after the last step every W^T is the
+    transpose of the shadow."""
+    res = {}
+    for nt in (False, True):
+        m, ema, opt, lf = _hip_trainer("SiT-S/2", dict(z_dims=[128], z_types=["i"], encoder_depth=4, projector_dim=256),
+                                       dev, ["dinov2"], [1.0], seed=3)
+        opt.overlap = overlap
+        m.engine().dgrad_nt = nt
+        rec = _run_traj(m, opt, lf, dev, 8, 4, [(128, "i")], True)
+        m.state_dict()
+        ema.state_dict()
+        A = m._arena
+        if nt:
+            assert A.shadow_t is not None and len(A.t_seg) == 4 * 12
+            if overlap:
+                assert A.shadow_t_gen == A.shadow_gen and A.pending_t is not None    # the optimiser kept them fresh
+            A.ensure_shadow_t("bf16")
+            torch.cuda.synchronize()
+            for name, (toff, n_out, k_in) in A.t_seg.items():
+                w = A.view(A.shadow, name)
+                assert torch.equal(A.shadow_t[toff:toff + n_out * k_in].view(k_in, n_out), w.t().contiguous()), name
+        else:
+            assert A.shadow_t is None
+        torch.cuda.synchronize()
+        res[nt] = (rec, A.master.clone(), ema._arena.master.clone())
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+
+
 def test_full_size_properties(dev):
     """C2 at the bench's own size (SiT-XL/2 + 1024-d projector, local batch 256: no oracle finishes there), through
     properties that hold at any size:
