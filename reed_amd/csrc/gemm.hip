@@ -31,6 +31,7 @@ int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm256w.hip: 4 waves x 128x128
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 int reed_num_cus();   // gemm256.hip
+double reed_gemm256_rate();
 bool reed_gemm_skinny_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm_skinny.hip: 16 x 64 tiles, one wave each
 int reed_gemm_skinny_launch(int epi, GemmArgs a, hipStream_t stream);
 
@@ -229,7 +230,8 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 
 }  // namespace
 
-static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 256 / 144 / 257 / 258 = force where the shape allows (tests, A/B timing)
+static const bool g_colsplit = getenv("REED_GEMM_COLSPLIT") && atoi(getenv("REED_GEMM_COLSPLIT")) != 0;   // =1: the column split (A/B runs; off by default)
+static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 256 / 144 / 257 / 258 = force where the shape allows, 259 = heuristic + column split (tests, A/B timing)
 extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
 int reed_gemm_forced_tile() { return g_force_tile; }
 
@@ -312,6 +314,67 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
         return reed_gemm_launch(layout, epi, t, splits, stream);
       }
     }
+  }
+  // Column split (round 6; OFF by default: REED_GEMM_COLSPLIT=1 or force_tile 259).  M = 8192 tokens (b = 32 per GPU) x N = 4608 (fc1
+  // forward, the fc2 input gradient) is 32 x 18 = 576 tiles of 256^2 = 2.25 rounds of 256 CUs: three rounds on the 256^2 kernels,
+  // four on 256x144 tiles (what the selection below takes).  Where a leading block of tile COLUMNS fills whole rounds exactly, that
+  // block goes out on the four-wave 256^2 kernel and the remaining columns as a second launch through the ordinary selection (here
+  // 512 columns = 256 tiles of 128^2, one per CU): the same kernels on offset pointers, every element formed by the same products
+  // in the same order (bit-identical: tests/test_gemm_gpu.py).  Measured (profiles/r6_column_split.txt): fc1 forward alone 98 -> 94
+  // us, the fc2 input gradient 98 -> 96, and the b = 32 step EQUAL (957.4 / 959.0 / 954.5 against 959.0 / 953.2 / 958.1 images/s,
+  // alternating on one box) — the second launch's prologue and epilogue eat what the saved round gives.  Kept as a switch, not
+  // as the default: it is the cheap stand-in for the 256x288 tile (two rounds of one kernel) that VERDICT round 5 asks for, and
+  // it bounds what that tile could give from below.
+  {
+    const bool epi_cols_free = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_SILU || epi == EPI_QGELU || epi == EPI_GELU_ERF ||
+                               epi == EPI_RES_BF16 || epi == EPI_GATE_RES || epi == EPI_DGELU || epi == EPI_DSILU ||
+                               epi == EPI_GELU_G || epi == EPI_SILU_G || epi == EPI_MUL;
+    if (((g_force_tile == 0 && g_colsplit) || g_force_tile == 259) && want != EPI_BF16_DOT && epi_cols_free && splits <= 1 &&
+        (layout == LAY_NT || layout == LAY_NN) && a.N % 256 == 0 && a.K >= 256) {
+      const int ncu = reed_num_cus();
+      const long tm = cdiv(a.M, 256), tn = a.N / 256;
+      const long full = tm * tn / ncu, rem = tm * tn % ncu;
+      if (full >= 1 && rem > 0 && (full * ncu) % tm == 0) {
+        const long tn1 = full * ncu / tm;
+        GemmArgs h = a, t = a;
+        h.N = (int)(tn1 * 256);
+        t.N = a.N - h.N;
+        if (reed_gemm256w_eligible(layout, epi, h, splits)) {
+          const double r256 = 4.0 / reed_gemm256_rate();
+          // the tail through the selection's own models: 256x144 tiles, 256^2 tiles in whole rounds, 128^2 tiles two per CU
+          const long t128 = cdiv(a.M, 128) * (long)(t.N / 128);
+          double ctail = (double)cdiv(t128, 2L * ncu) * 2.0;
+          ctail = fmin(ctail, (double)cdiv(tm * (tn - tn1), (long)ncu) * r256);
+          if (t.N % 144 == 0) ctail = fmin(ctail, (double)cdiv(tm * (t.N / 144), (long)ncu) * 2.25 / 0.92);
+          const double csplit = (double)full * r256 + ctail;
+          double cone = (double)(full + 1) * r256;                                                       // 256^2, whole rounds
+          cone = fmin(cone, (double)cdiv(cdiv(a.M, 128) * (long)(a.N / 128), 2L * ncu) * 2.0);          // 128^2
+          if (a.N % 144 == 0) cone = fmin(cone, (double)cdiv(tm * (a.N / 144), (long)ncu) * 2.25 / 0.92); // 256x144
+          if (csplit < 0.97 * cone) {
+            const int cb = epi == EPI_GATE_RES ? 4 : 2, rb = epi == EPI_GATE_RES ? 4 : 2;   // bytes per element of C and R
+            t.Q = layout == LAY_NT ? a.Q + (long)h.N * a.ldq : a.Q + h.N;
+            if (a.C) t.C = (char*)a.C + (long)h.N * cb;
+            if (a.C2) t.C2 = (char*)a.C2 + (long)h.N * 2;
+            if (a.R) t.R = (const char*)a.R + (long)h.N * rb;
+            if (a.bias) t.bias = a.bias + h.N;
+            if (a.gate) t.gate = a.gate + h.N;
+            const int rc = reed_gemm256w_launch(layout, epi, h, stream);
+            if (rc != REED_OK) return rc;
+            const int ft = g_force_tile;
+            g_force_tile = 0;                     // the tail through the ordinary selection
+            const int rt = reed_gemm_launch(layout, epi, t, splits, stream);
+            g_force_tile = ft;
+            return rt;
+          }
+        }
+      }
+    }
+  }
+  if (g_force_tile == 259) {   // no split for this shape: the ordinary selection
+    g_force_tile = 0;
+    const int rc = reed_gemm_launch(layout, want, a, splits, stream);
+    g_force_tile = 259;
+    return rc;
   }
   // (a 128x256 tile with two workgroups per CU — an epilogue overlapping the other workgroup's K loop — was built in round 4,
   // bit-identical and slower: its operand stream is 1.5x per flop; profiles/r4_gemm128c_*.txt, DESIGN_HISTORY.md; removed in round 5)

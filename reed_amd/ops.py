@@ -166,7 +166,7 @@ def gemm_forced_tile():
 def gemm_force_tile(tile):
     """0 = heuristic; 128 / 256 (eight waves) / 257 (four 128x128 waves, one tile per workgroup) / 258 (the same, persistent
     form wherever it applies) / 144 / 64 (the skinny one-wave tiles) = force that GEMM kernel
-    where it applies (tests and A/B timing).  Set in both builds of the library."""
+    where it applies; 259 = the heuristic plus the column split of csrc/gemm.hip (tests and A/B timing).  Set in both builds of the library."""
     global _FORCED_TILE
     _FORCED_TILE = int(tile)
     for prec in ("bf16", "fp16"):

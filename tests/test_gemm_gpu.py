@@ -643,3 +643,59 @@ def test_dgrad_as_nt_on_transposed_weights_is_bit_identical(dev, M, n_out, k_in,
     ref = dy.float() @ w.float()
     if epi == "plain" or epi == "dot":
         torch.testing.assert_close(outs[1][0].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2)
+
+
+@pytest.mark.parametrize("case", ["fc1_fwd_gelu", "fc1_fwd_gelu_g", "fc2_dgrad_mul_nn", "fc2_dgrad_dgelu_nt", "gate_res", "plain"])
+def test_column_split_is_bit_identical_to_one_launch(dev, case):
+    """Round 6 (a switch, off by default: force_tile 259 / REED_GEMM_COLSPLIT=1 — measured equal in the b = 32 step): where a leading
+    block of tile columns fills whole rounds of the chip exactly (8192 tokens x 4608 columns = 2.25 rounds of 256^2 tiles: 16 of the
+    18 tile columns are two rounds) reed_gemm sends that block to the four-wave 256^2 kernel and the remaining columns out as a
+    second launch on offset pointers (csrc/gemm.hip).  Every epilogue operand with a column index moves
+    with it — Q, C, C2, R, bias, gate — and every element is formed by the same products in the same order: the same bits as the
+    single launch on 256x144 tiles (force_tile 144) and on 256^2 tiles (257)."""
+    from reed_amd import ops
+    if ops.wgrad_slots() != 512:
+        pytest.skip("the shape is chosen for 256 CUs")
+    M, D, Hm = 8192, 1152, 4608
+    g = torch.Generator().manual_seed(len(case))
+    K = D
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(Hm, K, generator=g) * 0.05).to(dev)          # NT operand [N, K]
+    bias = _bf(torch.randn(Hm, generator=g)).to(dev)
+    r16 = _bf(torch.randn(M, Hm, generator=g)).to(dev)
+    gate = _bf(torch.randn(M // 256, Hm, generator=g)).to(dev)
+    xin = torch.randn(M, Hm, generator=g).to(dev)
+    outs = []
+    for tile in (259, 144, 257):
+        ops.gemm_force_tile(tile)
+        try:
+            c = torch.full((M, Hm), float("nan"), dtype=torch.bfloat16, device=dev)
+            c2 = torch.full((M, Hm), float("nan"), dtype=torch.bfloat16, device=dev)
+            if case in ("fc1_fwd_gelu", "fc1_fwd_gelu_g"):
+                e = ops.EPI_GELU if case == "fc1_fwd_gelu" else ops.EPI_GELU_G
+                ops.gemm(ops.NT, e, x, w, M, Hm, K, c, K, K, Hm, C2=c2, ldc2=Hm, bias=bias)
+                outs.append((c, c2))
+            elif case == "fc2_dgrad_mul_nn":
+                wn = w.t().contiguous()                                   # NN operand [K, N]
+                ops.gemm(ops.NN, ops.EPI_MUL, x, wn, M, Hm, K, c, K, Hm, Hm, R=r16, ldr=Hm)
+                outs.append((c,))
+            elif case == "fc2_dgrad_dgelu_nt":
+                ops.gemm(ops.NT, ops.EPI_DGELU, x, w, M, Hm, K, c, K, K, Hm, R=r16, ldr=Hm)
+                outs.append((c,))
+            elif case == "gate_res":
+                xo = torch.full((M, Hm), float("nan"), device=dev)
+                ops.gemm(ops.NT, ops.EPI_GATE_RES, x, w, M, Hm, K, xo, K, K, Hm, C2=c2, ldc2=Hm, R=xin, ldr=Hm, bias=bias, gate=gate,
+                         ldgate=Hm, rows_per_gate=256)
+                outs.append((xo, c2))
+            else:
+                ops.gemm(ops.NT, ops.EPI_BF16, x, w, M, Hm, K, c, K, K, Hm, bias=bias)
+                outs.append((c,))
+        finally:
+            ops.gemm_force_tile(0)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    if case == "plain":
+        ref = x.float() @ w.float().t() + bias.float()
+        torch.testing.assert_close(outs[0][0].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2)

@@ -74,3 +74,32 @@ for s, e, q, n in seg:
 print(f"kernels (main queue = {main_q}): ms per step, launches per step, avg us")
 for (m, n), (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:24]:
     print(f"  {'main' if m else 'side'} {n:48s} {d / K / 1e6:8.3f} {c / K:6.1f} {d / c / 1e3:8.1f}")
+# gaps of the MAIN queue (another queue may be running meanwhile), attributed to the main-queue kernel that ends them, with the
+# part of each gap during which a side-queue kernel was running (= the main stream waiting on the side stream's events)
+mains = [(s, e, n) for s, e, q, n in seg if q == main_q]
+sides = sorted((s, e) for s, e, q, n in seg if q != main_q)
+
+
+def side_cover(a, b):
+    c = 0
+    for s, e in sides:
+        if e <= a:
+            continue
+        if s >= b:
+            break
+        c += min(e, b) - max(s, a)
+    return c
+
+
+mg = defaultdict(lambda: [0, 0, 0])
+cur_end = mains[0][1]
+for s, e, n in mains[1:]:
+    if s > cur_end:
+        g = mg[short(n)]
+        g[0] += s - cur_end
+        g[1] += 1
+        g[2] += side_cover(cur_end, s)
+    cur_end = max(cur_end, e)
+print("main-queue gaps: us per step, count per step, of which a side-queue kernel was running (us per step)")
+for n, (g, c, sc) in sorted(mg.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {n:48s} {g / K / 1e3:9.1f} {c / K:7.1f} {sc / K / 1e3:9.1f}")
