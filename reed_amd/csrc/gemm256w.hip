@@ -847,52 +847,31 @@ __device__ __forceinline__ void w_tile_of(int b, int ntm, int ntn, int GM, int& 
   tm = first_m + (b % per_group) % gs;
   tn = (b % per_group) / gs;
 }
-// The STAGGERED deal (round 6; a.tile_gm bit 8): for an output of nfull full tile columns + one half column whose tile rows
-// divide as ntm = 8 R, R = nh wpx, XCD x owns the tile rows [x R, (x + 1) R) and each of its workgroups gets nh half tiles and
-// nf = R nfull / wpx full tiles — EVEN XCDs take their half tiles FIRST, ODD XCDs LAST.  A half tile is ~0.6 of a full tile's time,
-// so from the first hand-over to the last, half the chip runs ~0.4 tile times ahead of the other half: while one half is in its
-// epilogues (gate + residual: 640 KiB of HBM traffic per tile, 21-23 us with all 256 CUs storing at once against 14 alone:
-// DESIGN.md §3.1) the other half is in its K loops, at no cost in idle time (round 4's start DELAYS cost the delay itself).
-// Step i of workgroup s -> tile:
-__device__ __forceinline__ void w_stag_tile(int i, int x, int s, int wpx, int R, int nfull, int GM, int nh, int nf, int& tm, int& tn) {
-  const int ih = (x & 1) ? i - nf : i;
-  if (ih >= 0 && ih < nh) {
-    tm = x * R + s + wpx * ih;
-    tn = nfull;
-    return;
-  }
-  int lr, lc;
-  w_tile_of(s + wpx * ((x & 1) ? i : i - nh), R, nfull, GM, lr, lc);
-  tm = x * R + lr;
-  tn = lc;
-}
 template <int LAY, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntm = (a.M + WBM - 1) / WBM, ntn = (a.N + WBN - 1) / WBN;
   const int nwg = ntm * ntn;
   const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3, wpx = gridDim.x >> 3;
-  const int GM = a.tile_gm & 0xFF;
-  const bool stag = (a.tile_gm & 0x100) != 0;
   const int q = nwg >> 3, r = nwg & 7;
   const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, runlen = q + (xcd < r ? 1 : 0);
-  // the staggered deal's constants (unused otherwise)
-  const int sR = ntm >> 3, snh = sR / wpx, snf = sR * (ntn - 1) / wpx, nsteps = snh + snf;
-  int p = s, step = 0;
-  if (!stag && p >= runlen) return;
+  int p = s;
+  if (p >= runlen) return;
   // (Measured and dropped in round 4: starting every other workgroup of an XCD 6 / 12 / 18 us late, so that half the chip is in
   // its K loops while the other half is in its epilogues — every shape of the block slower by about the delay itself, none
-  // faster: fwd proj 0.241 -> 0.246, fc1 0.678 -> 0.694, dgrad fc2 0.709 -> 0.727 ms at 12 us; gpurun_out/r4a/stagger.txt)
+  // faster: fwd proj 0.241 -> 0.246, fc1 0.678 -> 0.694, dgrad fc2 0.709 -> 0.727 ms at 12 us; gpurun_out/r4a/stagger.txt.
+  // Round 6 tried the stagger for FREE — every XCD owning 32 tile rows of a 4.5-column output, even XCDs running their half tiles
+  // first, odd XCDs last, so that half the chip is 0.4 tile times ahead throughout — bit-identical and slower: fc2 forward 608 ->
+  // 675 us, proj 250 -> 257, step - 0.9 %: the 32 half tiles of a slot have 32 different activation panels, where this deal runs
+  // a half tile beside the full tiles of its row; profiles/r6_staggered_deal.txt, commit ffe488a)
   int tm, tn;
-  if (stag) w_stag_tile(0, xcd, s, wpx, sR, ntn - 1, GM, snh, snf, tm, tn);
-  else w_tile_of(run0 + p, ntm, ntn, GM, tm, tn);
+  w_tile_of(run0 + p, ntm, ntn, a.tile_gm, tm, tn);
   int pmode = -1;   // MODE of the previous tile of this workgroup (-1: none)
   for (;;) {
     const int pn = p + wpx;
     int nmode = -1, tmn = 0, tnn = 0;
-    if (stag ? step + 1 < nsteps : pn < runlen) {
-      if (stag) w_stag_tile(step + 1, xcd, s, wpx, sR, ntn - 1, GM, snh, snf, tmn, tnn);
-      else w_tile_of(run0 + pn, ntm, ntn, GM, tmn, tnn);
+    if (pn < runlen) {
+      w_tile_of(run0 + pn, ntm, ntn, a.tile_gm, tmn, tnn);
       nmode = (a.N - tnn * WBN <= 128) ? 1 : 0;
     }
 #ifdef REED_CLK_PROBE
@@ -916,7 +895,6 @@ __global__ __launch_bounds__(256, 1) void gemm256wp_kernel(GemmArgs a) {
 #endif
     if (nmode < 0) break;
     p = pn;
-    ++step;
     tm = tmn;
     tn = tnn;
     pmode = cmode;
@@ -1024,11 +1002,7 @@ int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
   const double total = (double)ntm * ((ntn - (rag ? 1 : 0)) + (rag ? RAG_COST : 0.0));
   const double ideal = total / (8.0 * wpx);
   if (mode == 1 && ideal < 3.0) return REED_OK;       // too few tiles per workgroup for the hand-over to matter
-  // the staggered deal (w_stag_tile): the epilogues whose cost is their HBM traffic (gate + residual); REED_W_STAGGER=0 none, =2 every epilogue
-  static const int stag_env = getenv("REED_W_STAGGER") ? atoi(getenv("REED_W_STAGGER")) : 1;
-  const bool stag = rag && a.N % WBN == 128 && ntn >= 2 && (ntm % 8) == 0 && ((ntm / 8) % wpx) == 0 && ntm / 8 >= wpx && a.M % WBM == 0 &&
-                    (stag_env == 2 || (stag_env == 1 && EPI == EPI_GATE_RES));
-  if (mode == 1 && !stag) {
+  if (mode == 1) {
     // the verdict per (tile grid, group rows, workgroups per XCD) is remembered: the walk below is ~5 k steps on the host
     static thread_local struct { int ntm, ntn, gm, wpx, ok; } memo[8];   // ntn carries the ragged flag in its sign
     static thread_local int memo_n = 0;
@@ -1053,7 +1027,7 @@ int launch256wp(const GemmArgs& a, hipStream_t stream, bool* used) {
     attr_set = true;
   }
   GemmArgs b = a;
-  b.tile_gm = GM | (stag ? 0x100 : 0);
+  b.tile_gm = GM;
   REED_KLAUNCH((gemm256wp_kernel<LAY, EPI>), dim3(8 * wpx), dim3(256), LDS_W, stream, b);
   REED_LAUNCH_CHECK();
   *used = true;

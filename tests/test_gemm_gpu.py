@@ -699,39 +699,3 @@ def test_column_split_is_bit_identical_to_one_launch(dev, case):
     if case == "plain":
         ref = x.float() @ w.float().t() + bias.float()
         torch.testing.assert_close(outs[0][0].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2)
-
-
-@pytest.mark.parametrize("K", [256, 1152])
-def test_staggered_deal_writes_every_tile_once_with_the_same_bits(dev, K):
-    """Round 6: the persistent four-wave 256^2 kernel deals the gate + residual GEMMs of b = 256 (65536 tokens x 1152 columns = 256
-    tile rows x (4 full + 1 half) tile columns) STAGGERED: every XCD owns 32 tile rows, even XCDs run their half tiles first, odd XCDs
-    last, so half the chip is in its K loops while the other half is in its HBM-bound epilogues (csrc/gemm256w.hip: w_stag_tile).
-    Every element of both outputs is written (NaN-filled before) with the bits of the one-tile-per-workgroup kernel (force_tile 257)
-    and of the 256x144 kernel."""
-    from reed_amd import ops
-    if ops.wgrad_slots() != 512:
-        pytest.skip("the deal is chosen for 256 CUs")
-    M, N = 65536, 1152
-    g = torch.Generator().manual_seed(K)
-    x = _bf(torch.randn(M, K, generator=g)).to(dev)
-    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
-    bias = _bf(torch.randn(N, generator=g)).to(dev)
-    gate = _bf(torch.randn(M // 256, N, generator=g)).to(dev)
-    xin = torch.randn(M, N, generator=g).to(dev)
-    outs = []
-    for tile in (0, 257, 144):
-        ops.gemm_force_tile(tile)
-        try:
-            xo = torch.full((M, N), float("nan"), device=dev)
-            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
-            ops.gemm(ops.NT, ops.EPI_GATE_RES, x, w, M, N, K, xo, K, K, N, C2=y, ldc2=N, R=xin, ldr=N, bias=bias, gate=gate, ldgate=N,
-                     rows_per_gate=256)
-            outs.append((xo, y))
-        finally:
-            ops.gemm_force_tile(0)
-    torch.cuda.synchronize()
-    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1].float()).all()
-    for o in outs[1:]:
-        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
-    yr = (x[:512].float() @ w.float().t() + bias.float()).to(torch.bfloat16)
-    torch.testing.assert_close(outs[0][1][:512].float(), yr.float(), atol=2e-2 * float(yr.float().abs().max()), rtol=2e-2)
