@@ -75,7 +75,6 @@ KNOWN_ENV = {
     "REED_FORCE_REDUCER",    # the N > 1 code path at world 1
     "REED_BENCH_REHEARSE",   # bench.py: gloo rehearsal of an N > 1 run on fewer GPUs
     "REED_BENCH_TUNED",      # bench.py: 0 = no second (tuned) timed region
-    "REED_ATTN_BWD_SPREAD",  # csrc/attention.hip: 0 = the ring backward's vector-memory issue as a burst in front of phase B (round 5's placement)
     "REED_ATTN_FWD_DBG", "REED_ATTN_KSP_DBG",   # diagnosis builds of csrc/attention.hip only (-DREED_ATTN_DIAG)
 }
 

@@ -2000,45 +2000,37 @@ struct RingB {
     if constexpr (NK > 1) ktf[1] = frag_trT_u<ROWF, KS * 32 * ROWF + 32>(kb);
     if constexpr (NK > 2) ktf[2] = frag_trT_u<ROWF, KS * 32 * ROWF + 64>(kb);
   }
-  // HOOK (round 6): called once per key step with the step's index as an integral_constant, behind the step's reads and in front of
-  // its MFMAs — the ring kernel's vector-memory issue (the next chunks' Q / dO pieces, K(n + 1), the next item's own rows) rides
-  // here, one or two instructions per step, instead of going out as a burst between the barrier and the product
-  template <int KS, typename HOOK>
+  template <int KS>
   static __device__ __forceinline__ void step(unsigned sb, unsigned kb, f32x4 (&dq)[NK], bf16x8& dsc, bf16x8 (&kc)[NK], bf16x8& dsn,
-                                              bf16x8 (&kn)[NK], HOOK& hook) {
+                                              bf16x8 (&kn)[NK]) {
     if constexpr (KS + 1 < 8) load<KS + 1>(sb, kb, dsn, kn);
-    hook(std::integral_constant<int, KS>{});
 #pragma unroll
     for (int k = 0; k < NK; ++k) dq[k] = (KS == 0) ? MFMA(kc[k], dsc, zero4()) : MFMA(kc[k], dsc, dq[k]);
     ATTN_LDS_WAIT();
   }
   // St / Kt: the dS^T tile (128-byte rows, swizzled 32-byte segments) and the K tile (160-byte rows); qrow0: dqkv row of the tile's first query (q part); returns after the stores
-  template <typename HOOK>
   static __device__ __forceinline__ void run(const char* St, const char* Kt, int qtile, int lane, float scale, bf16* qrow0, long tok,
-                                             bool skip, HOOK hook) {
+                                             bool skip) {
     const int i = lane & 15, g = lane >> 4;
     const unsigned sb = lds_addr(St + (4 * g + (i >> 2)) * 128 + ((qtile ^ ((2 * g + (i >> 3)) & 3)) << 5) +
                                  (((i & 3) ^ (((i >> 2) & 1) | ((g >> 1) << 1))) << 3));
     const unsigned kb = lds_addr(Kt + (4 * g + (i >> 2)) * ROWF + (16 * D0 + 4 * (i & 3)) * 2);
     f32x4 dq[NK];
-    if (skip) {   // diagnosis: no products (the hooks' issues still go out, in order)
+    if (skip) {   // diagnosis: no products
 #pragma unroll
       for (int k = 0; k < NK; ++k) dq[k] = zero4();
-      hook(std::integral_constant<int, 0>{}); hook(std::integral_constant<int, 1>{}); hook(std::integral_constant<int, 2>{});
-      hook(std::integral_constant<int, 3>{}); hook(std::integral_constant<int, 4>{}); hook(std::integral_constant<int, 5>{});
-      hook(std::integral_constant<int, 6>{}); hook(std::integral_constant<int, 7>{});
     } else {
       bf16x8 da, db, ka[NK], kb2[NK];
       load<0>(sb, kb, da, ka);
       ATTN_LDS_WAIT();
-      step<0>(sb, kb, dq, da, ka, db, kb2, hook);
-      step<1>(sb, kb, dq, db, kb2, da, ka, hook);
-      step<2>(sb, kb, dq, da, ka, db, kb2, hook);
-      step<3>(sb, kb, dq, db, kb2, da, ka, hook);
-      step<4>(sb, kb, dq, da, ka, db, kb2, hook);
-      step<5>(sb, kb, dq, db, kb2, da, ka, hook);
-      step<6>(sb, kb, dq, da, ka, db, kb2, hook);
-      step<7>(sb, kb, dq, db, kb2, da, ka, hook);
+      step<0>(sb, kb, dq, da, ka, db, kb2);
+      step<1>(sb, kb, dq, db, kb2, da, ka);
+      step<2>(sb, kb, dq, da, ka, db, kb2);
+      step<3>(sb, kb, dq, db, kb2, da, ka);
+      step<4>(sb, kb, dq, da, ka, db, kb2);
+      step<5>(sb, kb, dq, db, kb2, da, ka);
+      step<6>(sb, kb, dq, da, ka, db, kb2);
+      step<7>(sb, kb, dq, db, kb2, da, ka);
     }
     u32x2 v[NK];
 #pragma unroll
@@ -2087,7 +2079,7 @@ struct RingB {
 // fragments no longer wrap a row onto the first row's banks); the dS^T tile keeps 144-byte rows: 160 would need 4 KiB the CU
 // does not have — so it went the other way: 128-byte rows (its payload: 64 queries) with the 32-byte segments XOR-swizzled by the
 // row pair, and the dK / dV staging moved to the item's dead K tile.  LDS: Q ring 20 | dO ring 20 | K x 2 80 | dS^T 32 | lse, delta x 2 4 = 156 KiB.
-template <int HD, bool STAMPS = false, bool SPREAD = true>
+template <int HD, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16* __restrict__ dqkv, int H, int nitems, int dbg) {
@@ -2151,24 +2143,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       const int vo = dma_voff<HD, ROWF>(I * 64 + ln, tokb);   // (not inside the builtin's argument list: clang's host pass then drops the kernel)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
     }
-  };
-  // the same pieces one at a time (SPREAD: phase B's per-step hook): piece j = 0..2 of a chunk, j = 0..4 of a K tile
-  auto issue_chunk_piece = [&](const bf16* qb, const bf16* gb2, int c, int ln, int j) {
-    const int pp = wave + 8 * j;
-    if (pp >= 20) return;
-    const bool second = pp >= 10;
-    const int I = second ? pp - 10 : pp;
-    const int sb = second ? db : tokb;
-    const __amdgpu_buffer_rsrc_t rs = second ? mk_rsrc(gb2, tile_window<HD>(T, db)) : mk_rsrc(qb, tile_window<HD>(T, tokb));
-    const int vo = dma_voff<HD, ROWF>(I * 64 + ln, sb);
-    const int v2 = vo == DMA_OOB ? DMA_OOB : vo + c * 64 * sb;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)((second ? Gr : Qr) + (c & 1) * CHB + I * 1024), 16, v2, 0, 0, REED_ATTN_LD_AUX);
-  };
-  auto issue_k_piece = [&](const bf16* kb, char* dst, int ln, int j) {
-    const __amdgpu_buffer_rsrc_t rs = mk_rsrc(kb, tile_window<HD>(T, tokb));
-    const int I = wave + 8 * j;
-    const int vo = dma_voff<HD, ROWF>(I * 64 + ln, tokb);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + I * 1024), 16, vo, 0, 0, REED_ATTN_LD_AUX);
   };
   auto bases = [&](int item, const bf16*& base, const bf16*& gbase, const float*& lbase, const float*& dlbase, bf16*& dbase) {
     const int b = item / H, h = item - b * H;
@@ -2265,42 +2239,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
       RING_STAMP(1);
       ATTN_BARRIER();   // dS^T of the chunk complete; the ring slot is released
       RING_STAMP(2);
-      int lnB = lane0;
-      asm volatile("" : "+v"(lnB));   // fresh copy: piece offsets and row addresses are computed here, not kept in registers
-      // SPREAD (round 6): at ch = 0, 1, 2 the chunk pieces and K(n + 1) go out from phase B's key steps (hookB below), the same
-      // instructions in the same order; at ch = 3 they stay a burst in front of the product, because the next item's own rows must
-      // be issued behind the chunk pieces (the item-end wait counts from the last own-row load and covers everything older) and
-      // their loads write their FINAL registers from inline asm: spread over the steps' code paths the register allocator gave
-      // some of them temporaries + copies, and a copy in front of the counted wait reads a register the load has not written yet
-      // (and the load then lands in a register that has been reused) — tools/check_attn_isa.py checks the destinations
-      if (!SPREAD || ch == 3) {
-        if (ch < 2 || has_next) {
-          if (ch < 2) issue_chunk(base, gbase, ch + 2, lnB);
-          else issue_chunk(nbase, ngbase, ch - 2, lnB);
-          if (has_next && ch == 0) issue_k(nbase + D, Kb + (par ^ 1) * TILE_F, lnB);
-          if (has_next && ch == 3) own_rows(nbase, nlbase, ndlbase, lnB);   // vf of this item is dead: phase A is over
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      if (ch < 2 || has_next) {
+        int ln = lane0;
+        asm volatile("" : "+v"(ln));   // fresh copy: piece offsets and row addresses are computed here, not kept in registers
+        if (ch < 2) issue_chunk(base, gbase, ch + 2, ln);
+        else issue_chunk(nbase, ngbase, ch - 2, ln);
+        if (has_next && ch == 0) issue_k(nbase + D, Kb + (par ^ 1) * TILE_F, ln);
+        if (has_next && ch == 3) own_rows(nbase, nlbase, ndlbase, ln);   // vf of this item is dead: phase A is over
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // step S: piece S of the chunk (S < 3), at ch = 0 piece S - 3 of K(n + 1) (S >= 3)
-      auto hookB = [&](auto sc) {
-        constexpr int S = decltype(sc)::value;
-        if constexpr (SPREAD) {
-          if (ch < 3 && (ch < 2 || has_next)) {
-            if constexpr (S < 3) {
-              if (ch < 2) issue_chunk_piece(base, gbase, ch + 2, lnB, S);
-              else issue_chunk_piece(nbase, ngbase, ch - 2, lnB, S);
-            } else {
-              if (has_next && ch == 0) issue_k_piece(nbase + D, Kb + (par ^ 1) * TILE_F, lnB, S - 3);
-            }
-          }
-        }
-      };
       // ---------------- phase B: dQ^T = K^T dS^T for the chunk's 64 queries ----------------
       {
         bf16* qrow0 = dbase + (long)(ch * 64 + 16 * (wave >> 1)) * tok;
-        if (wave & 1) RingB<HD, true>::run(St, Kt, wave >> 1, lane, scale, qrow0, tok, (dbg & 2) != 0, hookB);   // dbg bit 1: no products
-        else RingB<HD, false>::run(St, Kt, wave >> 1, lane, scale, qrow0, tok, (dbg & 2) != 0, hookB);
+        if (wave & 1) RingB<HD, true>::run(St, Kt, wave >> 1, lane, scale, qrow0, tok, (dbg & 2) != 0);   // dbg bit 1: no products
+        else RingB<HD, false>::run(St, Kt, wave >> 1, lane, scale, qrow0, tok, (dbg & 2) != 0);
       }
       // the next chunk's Q / dO rows (issued one chunk ago) have landed: counted, see the table in the header
       __builtin_amdgcn_sched_barrier(0);
@@ -2541,20 +2493,14 @@ static int attention_bwd_persistent(const void* qkv, const void* o, const void* 
   } while (0)
   if (T == 256) {
     const int rlds = 4 * 64 * ROWF + 2 * TILE_F + 256 * 128 + 4096;   // 156 KiB
-    // REED_ATTN_BWD_SPREAD=0: the vector-memory issue as a burst in front of phase B (round 5's placement; same-box A/B)
-    static const bool spread = !(getenv("REED_ATTN_BWD_SPREAD") && atoi(getenv("REED_ATTN_BWD_SPREAD")) == 0);
 #define REED_BWD_RING(HD)                                                                                                 \
   do {                                                                                                                    \
-    static int once = set_lds(attn_bwd_ring_kernel<HD, false, true>, rlds) | set_lds(attn_bwd_ring_kernel<HD, false, false>, rlds); \
+    static int once = set_lds(attn_bwd_ring_kernel<HD>, rlds);                                                            \
     if (once) return once;                                                                                                \
     REED_DELTA(HD);                                                                                                       \
     REED_LAUNCH_CHECK();                                                                                                  \
-    if (spread)                                                                                                           \
-      REED_KLAUNCH((attn_bwd_ring_kernel<HD, false, true>), pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, \
-                   (const float*)ws, (bf16*)dqkv, H, nitems, dbg);                                                        \
-    else                                                                                                                  \
-      REED_KLAUNCH((attn_bwd_ring_kernel<HD, false, false>), pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, \
-                   (const float*)ws, (bf16*)dqkv, H, nitems, dbg);                                                        \
+    REED_KLAUNCH(attn_bwd_ring_kernel<HD>, pgrid, dim3(512), rlds, s, (const bf16*)qkv, (const bf16*)d_o, lse, (const float*)ws, \
+                 (bf16*)dqkv, H, nitems, dbg);                                                                            \
   } while (0)
 #ifdef REED_ATTN_DIAG
     if (hd == 72 && (dbg & 4)) {   // the stamped instantiation (diagnosis)

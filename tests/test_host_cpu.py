@@ -612,8 +612,8 @@ def test_counted_waits_of_the_attention_forward_match_the_isa():
         pytest.skip("no hipcc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_attn_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    # hd 64 / 72 / 80 x (T = 256, T < 256) + the V-double-buffered 64 / 72 + the ring backward's own-row registers (hd 64 / 72 x two issue placements)
-    assert r.stdout.count("ok  ") == 12 and "BAD" not in r.stdout, r.stdout
+    # hd 64 / 72 / 80 x (T = 256, T < 256) + the V-double-buffered 64 / 72 + the ring backward's own-row registers (hd 64 / 72)
+    assert r.stdout.count("ok  ") == 10 and "BAD" not in r.stdout, r.stdout
 
 
 def test_detfill_matches_the_fixture_recipe():
