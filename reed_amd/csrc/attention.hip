@@ -2248,6 +2248,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_ring_kernel(const bf16* __res
         if (has_next && ch == 3) own_rows(nbase, nlbase, ndlbase, ln);   // vf of this item is dead: phase A is over
         __builtin_amdgcn_sched_barrier(0);
       }
+      // (Round 6 moved the issue block above INTO phase B — one piece per key step through a hook of RingB::step, same instructions
+      // in the same order, the own rows kept as a burst at ch = 3 — and measured the kernel and the step equal: 395 / 400 / 405 us
+      // burst, 395 / 406 / 392 spread; the 14-17 k cycles of "issue + phase B" are the product's transposing LDS reads, not the
+      // issue.  profiles/r6_attn_bwd_spread.txt, commit a468645; removed.)
       // ---------------- phase B: dQ^T = K^T dS^T for the chunk's 64 queries ----------------
       {
         bf16* qrow0 = dbase + (long)(ch * 64 + 16 * (wave >> 1)) * tok;
