@@ -68,6 +68,7 @@ KNOWN_ENV = {
     "REED_HIP_LIB",          # _lib.py: another build of the library (same-box A/B)
     "REED_WGRAD_W4",         # csrc/gemm256w.hip: 0 = gemm_tn.hip's grouped weight gradients everywhere, 1 = the four-wave form beside collectives too
     "REED_GEMM_COLSPLIT",    # csrc/gemm.hip: 1 = column split of the 2.25-round GEMMs (b = 32 per GPU: fc1 forward, fc2 input gradient); measured equal, off
+    "REED_GEMM288",          # csrc/gemm288.hip: 1 = the heuristic may take the 256x288 kernel (measured equal to the 256x144 kernel: off)
     "REED_WGRAD_GROUP",      # ops.py: 0 = per-GEMM split-K weight gradients (the plan the goldens pin)
     "REED_WGRAD_STREAM",     # engine.py: 0 / 1 / auto — the weight gradients on a second stream
     "REED_OPT_OVERLAP",      # optim.py: 0 = the optimiser pass on the main stream

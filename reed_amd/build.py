@@ -16,7 +16,7 @@ LIB_F32 = os.path.join(HERE, "libreed_hip_f32.so")
 # (variant tag, extra flags, library): every variant compiles the shared sources; the MFMA-tuned 16-bit kernels are left out of
 # the fp32 build, whose own GEMM / attention sources are left out of the 16-bit builds
 VARIANTS = (("", [], LIB), ("f16", ["-DREED_FP16"], LIB_F16), ("f32", ["-DREED_FP32"], LIB_F32))
-ONLY_16BIT = {"gemm.hip", "gemm256.hip", "gemm256w.hip", "gemm144.hip", "gemm_skinny.hip", "gemm_tn.hip", "attention.hip", "conv.hip"}
+ONLY_16BIT = {"gemm.hip", "gemm256.hip", "gemm256w.hip", "gemm144.hip", "gemm288.hip", "gemm_skinny.hip", "gemm_tn.hip", "attention.hip", "conv.hip"}
 ONLY_F32 = {"gemm_f32.hip", "attention_f32.hip"}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"

@@ -28,6 +28,9 @@ bool reed_gemm256_preferred(int layout, int epi, const GemmArgs& a, int splits);
 bool reed_gemm144_eligible(int layout, int epi, const GemmArgs& a, int splits);              // gemm144.hip
 bool reed_gemm144_preferred(int layout, int epi, const GemmArgs& a, int splits);
 int reed_gemm144_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
+bool reed_gemm288_eligible(int layout, int epi, const GemmArgs& a, int splits);              // gemm288.hip: 256x288 tiles (NT)
+bool reed_gemm288_preferred(int layout, int epi, const GemmArgs& a, int splits);
+int reed_gemm288_launch(int epi, GemmArgs a, hipStream_t stream);
 bool reed_gemm256w_eligible(int layout, int epi, const GemmArgs& a, int splits);   // gemm256w.hip: 4 waves x 128x128
 int reed_gemm256w_launch(int layout, int epi, GemmArgs a, hipStream_t stream);
 int reed_num_cus();   // gemm256.hip
@@ -231,7 +234,7 @@ int dispatch_epi(int epi, const GemmArgs& a, int splits, hipStream_t s) {
 }  // namespace
 
 static const bool g_colsplit = getenv("REED_GEMM_COLSPLIT") && atoi(getenv("REED_GEMM_COLSPLIT")) != 0;   // =1: the column split (A/B runs; off by default)
-static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 256 / 144 / 257 / 258 = force where the shape allows, 259 = heuristic + column split (tests, A/B timing)
+static int g_force_tile = 0;  // 0 = heuristic, 64 / 128 / 256 / 144 / 288 / 257 / 258 = force where the shape allows, 259 = heuristic + column split (tests, A/B timing)
 extern "C" int reed_gemm_force_tile(int tile) { g_force_tile = tile; return 0; }
 int reed_gemm_forced_tile() { return g_force_tile; }
 
@@ -382,6 +385,11 @@ int reed_gemm_launch(int layout, int epi, GemmArgs a, int splits, hipStream_t st
     return reed_gemm_skinny_launch(epi, a, stream);   // tests: the skinny kernel on any shape it accepts
   if ((g_force_tile == 257 || g_force_tile == 258) && reed_gemm256w_eligible(layout, epi, a, splits))
     return reed_gemm256w_launch(layout, want, a, stream);   // 257: one-shot form, 258: persistent form wherever it applies
+  if ((g_force_tile == 288 && reed_gemm288_eligible(layout, epi, a, splits)) ||
+      (g_force_tile == 0 && reed_gemm288_preferred(layout, epi, a, splits))) {
+    REED_ONLY_PLAIN();
+    return reed_gemm288_launch(epi, a, stream);
+  }
   if (can144 && (g_force_tile == 144 || a.N % BN != 0 || (g_force_tile == 0 && reed_gemm144_preferred(layout, epi, a, splits)))) {
     REED_ONLY_PLAIN();
     return reed_gemm144_launch(layout, epi, a, stream);

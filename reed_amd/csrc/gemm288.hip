@@ -1,0 +1,283 @@
+// 256x288x64 bf16 MFMA GEMM for gfx950 (NT) — the tile that makes the 4608-wide outputs of SiT-XL/2 exactly TWO rounds of the chip at
+// 8192 tokens (b = 32 per GPU, the 8-GPU shape; reference: the fc1 forward and the fc2 input gradient of a block,
+// image/models/sit.py:121-124 through timm's Mlp).  M = 8192 x N = 4608 is 2.25 rounds of 256^2 tiles (three rounds run) and four
+// rounds of 256x144 tiles, whose K loop is bound by the L2 -> LDS operand stream (50 KiB per K-tile and CU: gemm144.hip); a 256x288
+// tile moves 68 KiB per K-tile for twice the products — 1.47 x the FLOP per operand byte — and 4608 = 16 x 288, 8192 = 32 x 256:
+// 512 workgroups.  BUILT AS VERDICT round 5 ASKED (item 3a), BIT-IDENTICAL TO THE 256x144 KERNEL, AND MEASURED NOT FASTER: see "Selection"
+// at the end of this file and profiles/r6_gemm288.txt — the heuristic does not take it.
+//
+// 8 waves = 4 (rows) x 2 (columns): wave (wr, wc) owns rows 64 wr .. + 63 and columns 144 wc .. + 143 = 4 x 9 MFMA tiles (144
+// accumulator registers).  Two waves per SIMD (w and w + 4) and 256 registers each leave no room for double-buffered fragments of a
+// whole k-step (2 x 13 x 4 registers), so the product is pipelined in GROUPS of three column tiles: the three B fragments of group
+// g + 1 (and, with the last group of a k-step, the four A fragments of the next step) are read while the 12 MFMAs of group g issue.
+// LDS: a ring of FOUR stages of one 32-wide k-step each — A [256][32] 16 KiB | B [288][32] 18 KiB = 34 KiB, 136 KiB — in plain
+// 64-byte rows with the 16-byte chunks XOR-swizzled by the row quad (conflict-free ds_read_b128: see the fragment addresses); an
+// LDS-DMA piece (1 KiB) is 16 whole rows.  DMA runs THREE k-steps ahead (1.5 K-tiles of 64: the first form of this
+// kernel — two 68 KiB stages, one K-tile ahead, every wave's nine DMAs issued in one burst behind the barrier — took 2.3 us per
+// K-tile for 1.2 us of MFMA work: a buffer_load ... lds costs its wave ~100 issue cycles and both waves of a SIMD paid them at the
+// same time).  Here a wave's 4 | 5 pieces per k-step (34 pieces: A 16 + B 18; waves 0, 1 take a fifth) ride between the reads and
+// the MFMAs of groups 0 and 1, where the SIMD's other wave can hold the matrix pipe:
+//   k-step h:  g0: read B g1 | 2 DMA of step h+3 | MFMA g0      g1: read B g2 | 2-3 DMA | MFMA g1
+//              g2: wait own DMA(h+1) | barrier | read A, B g0 of step h+1 | MFMA g2
+// One barrier per k-step; it also frees step h's stage for DMA(h+4).  Epilogue: the two 64-column halves of a wave's 128 leading
+// columns through tile_epilogue's LDS patch (overlaid on the ring behind a barrier), the 16-column strip straight from the MFMA layout.
+#include <math.h>
+#include <stdlib.h>
+
+#include "gemm_common.hpp"
+
+namespace {
+using namespace gemm_detail;
+
+constexpr int BM8 = 256, BN8 = 288, BK8 = 64, KS8 = 32;
+constexpr int A8 = BM8 * KS8 * 2, B8 = BN8 * KS8 * 2;   // 16384, 18432: one k-step
+constexpr int STAGE8 = A8 + B8;                        // 34816
+constexpr int LDS8 = 4 * STAGE8;                       // 136 KiB
+
+#define RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define LDS_WAIT0()                                        \
+  do {                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm288_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave & 3, wc = wave >> 2;
+  const bool extra = wave < 2;   // waves 0, 1 stage a fifth piece per k-step (B's rows 256 .. 287)
+
+  // ---- block -> tile (XCD-aware, grouped along M; as gemm144.hip) ----
+  const int ntm = (a.M + BM8 - 1) / BM8, ntn = a.N / BN8;
+  int tm, tn;
+  {
+    const int nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {
+      int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 4;
+    const int per_group = GM * ntn;
+    const int group = bid / per_group, first_m = group * GM;
+    const int gs = min(ntm - first_m, GM);
+    tm = first_m + (bid % per_group) % gs;
+    tn = (bid % per_group) / gs;
+  }
+  const int m0 = tm * BM8, n0 = tn * BN8;
+  const int nt = a.K / BK8;
+
+  const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.P + (long)m0 * a.ldp, ((long)(a.M - m0) * a.ldp) * 2);
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(a.Q + (long)n0 * a.ldq, ((long)(a.N - n0) * a.ldq) * 2);
+
+  // ---- staging: a piece = 16 rows x 64 bytes; lane (r = lane >> 2, c = lane & 3) moves chunk c of the piece's row r ----
+  // chunk c of row r sits at position c ^ f(r), f(r) = (-(r >> 2)) & 3 (see the fragment addresses below)
+  const int dsw = (-(lane >> 4)) & 3;   // f of the piece's row lane >> 2
+  const int vA = (int)(((long)(lane >> 2) * a.ldp + (((lane & 3) ^ dsw) << 3)) * 2);
+  const int vB = (int)(((long)(lane >> 2) * a.ldq + (((lane & 3) ^ dsw) << 3)) * 2);
+  const int pcA = (int)(16 * a.ldp * 2), pcB = (int)(16 * a.ldq * 2);   // bytes between pieces
+  // piece J of this wave's list for k-step h: J = 0, 1: A pieces wave, wave + 8; J = 2, 3: B pieces wave, wave + 8; J = 4 (waves 0, 1): B piece wave + 16
+  auto piece = [&](int h, auto jc) {
+    constexpr int J = decltype(jc)::value;
+    char* sb = smem + (h & 3) * STAGE8;
+    const int kk = h * (KS8 * 2);
+    if constexpr (J < 2) {
+      const int p = wave + 8 * J;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)(sb + p * 1024), 16, vA, kk + p * pcA, 0, 0);
+    } else {
+      const int p = wave + 8 * (J - 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_ptr_t)(sb + A8 + p * 1024), 16, vB, kk + p * pcB, 0, 0);
+    }
+  };
+  auto issue_all = [&](int h) {
+    piece(h, std::integral_constant<int, 0>{});
+    piece(h, std::integral_constant<int, 1>{});
+    piece(h, std::integral_constant<int, 2>{});
+    piece(h, std::integral_constant<int, 3>{});
+    if (extra) piece(h, std::integral_constant<int, 4>{});
+  };
+
+  // ---- fragment addresses (LDS byte offsets inside a stage) ----
+  const int li = lane & 15, lg = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(const char __attribute__((address_space(3)))*)smem;
+  // 64-byte rows: the bank space (256 B) holds four rows, and a ds_read_b128 is served in four groups of 16 lanes — lane rows
+  // {0-3, 12-15} at chunk lg and {4-11} at chunk lg ^ 1 (MI355X_MICROARCH.md, LDS).  Unswizzled, rows r and r + 4 k share banks
+  // (measured: 45 % of the LDS cycles were conflict cycles); with chunk c of row r at position c ^ f(r), f = 0, 3, 2, 1 for
+  // (r >> 2) & 3 = 0 .. 3, the four rows of a residue class mod 4 inside every group land on four different positions
+  const int fsw = (-(li >> 2)) & 3;
+  const unsigned aA = lds0 + (wr * 64 + li) * 64 + ((lg ^ fsw) << 4);            // row tile i: + 1024 i
+  const unsigned bR = lds0 + A8 + (wc * 144 + li) * 64 + ((lg ^ fsw) << 4);      // column tile j: + 1024 j
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragments live in integer vectors (gemm144.hip: with bf16 vector types the compiler re-packs loop-carried fragments right behind
+  // the asm read that defines them, before the data has arrived)
+  u32x4 A0[4], A1[4], Bx[3], By[3];
+#define LOADA(so, Af)                                                                                      \
+  do {                                                                                                     \
+    const unsigned pa_ = aA + (so);                                                                        \
+    RD128(Af[0], pa_, 0); RD128(Af[1], pa_, 1024); RD128(Af[2], pa_, 2048); RD128(Af[3], pa_, 3072);       \
+  } while (0)
+#define LOADB(G, so, Bf)                                                                                   \
+  do {                                                                                                     \
+    const unsigned pb_ = bR + (so);                                                                        \
+    RD128(Bf[0], pb_, (G) * 3072); RD128(Bf[1], pb_, (G) * 3072 + 1024); RD128(Bf[2], pb_, (G) * 3072 + 2048); \
+  } while (0)
+#define MMA3(Af, Bf, G)                                                                                    \
+  do {                                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+      acc[i][3 * (G) + j] = REED_MFMA_16x16x32(__builtin_bit_cast(bf16x8, Bf[j]), __builtin_bit_cast(bf16x8, Af[i]), acc[i][3 * (G) + j]); \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+  } while (0)
+  // one k-step h on (Acur, B0 = group 0's fragments, landed); leaves (Anxt, B1 = group 0 of step h + 1, landed).  NH = number of k-steps
+#define KSTEP(h, Acur, Anxt, B0, B1)                                                                       \
+  do {                                                                                                     \
+    const unsigned so_ = (unsigned)((h) & 3) * STAGE8, sn_ = (unsigned)(((h) + 1) & 3) * STAGE8;           \
+    const bool more_ = (h) + 3 < NH;                                                                       \
+    LOADB(1, so_, B1);                                                                                     \
+    if (more_) { piece((h) + 3, std::integral_constant<int, 0>{}); piece((h) + 3, std::integral_constant<int, 1>{}); } \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    MMA3(Acur, B0, 0);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    LDS_WAIT0();                                                                                           \
+    LOADB(2, so_, B0);                                                                                     \
+    if (more_) {                                                                                           \
+      piece((h) + 3, std::integral_constant<int, 2>{}); piece((h) + 3, std::integral_constant<int, 3>{});  \
+      if (extra) piece((h) + 3, std::integral_constant<int, 4>{});                                         \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    MMA3(Acur, B1, 1);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    LDS_WAIT0();                       /* every read of this wave from step h's stage has landed */        \
+    if ((h) + 1 < NH) {                                                                                    \
+      /* this wave's pieces of step h + 1 have landed; younger: those of steps h + 2, h + 3 (where they exist) */ \
+      if ((h) + 3 < NH) { if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } \
+      else if ((h) + 2 < NH) { if (extra) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+      __builtin_amdgcn_s_barrier();    /* ... everyone's; and everyone is done with step h's stage */      \
+      asm volatile("" ::: "memory");                                                                       \
+      LOADA(sn_, Anxt);                                                                                    \
+      LOADB(0, sn_, B1);                                                                                   \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    MMA3(Acur, B0, 2);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    LDS_WAIT0();                                                                                           \
+  } while (0)
+
+  const int NH = 2 * nt;   // k-steps (K is a multiple of 64: always even, >= 4)
+  // prologue: k-steps 0, 1, 2 in flight; wait for step 0
+  issue_all(0);
+  issue_all(1);
+  issue_all(2);
+  if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  LOADA(0u, A0);
+  LOADB(0, 0u, Bx);
+  LDS_WAIT0();
+
+  for (int t = 0; t < nt; ++t) {
+    const int h0 = 2 * t;
+    KSTEP(h0, A0, A1, Bx, By);        // B0 = Bx -> leaves group 0 of the next step in By
+    KSTEP(h0 + 1, A1, A0, By, Bx);
+  }
+  __syncthreads();   // every wave is done with the stages: the epilogue's patches overlay stage 0
+
+  char* patch = smem + wave * EPI_STAGE_BYTES;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 part[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[i][j] = acc[i][4 * h + j];
+    tile_epilogue<EPI, 4>(a, part, m0, wr * 64, n0 + wc * 144 + 64 * h, lane, 0, patch);
+  }
+  {
+    f32x4 strip[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) strip[i] = acc[i][8];
+    strip_epilogue<EPI>(a, strip, m0 + wr * 64, n0 + wc * 144 + 128, lane);
+  }
+#undef KSTEP
+#undef LOADA
+#undef LOADB
+#undef MMA3
+}
+
+template <int EPI>
+int launch288(const GemmArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm288_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+    if (e != hipSuccess) { reed_set_error("gemm288: cannot reserve 136 KiB LDS: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM8) * (a.N / BN8), 1, 1);
+  REED_KLAUNCH((gemm288_kernel<EPI>), grid, dim3(512), LDS8, stream, a);
+  REED_LAUNCH_CHECK();
+  return REED_OK;
+}
+
+}  // namespace
+
+// shapes the 256x288 kernel can take: NT, one of its epilogues, N a multiple of 288, K of 64, no split-K
+bool reed_gemm288_eligible(int layout, int epi, const GemmArgs& a, int splits) {
+  const bool epi_ok = epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_GELU_G || epi == EPI_DGELU || epi == EPI_MUL;
+  return layout == LAY_NT && epi_ok && splits <= 1 && a.N % BN8 == 0 && a.K % BK8 == 0 && a.K >= 2 * BK8;   // (>= 4 k-steps: the prologue stages three)
+}
+
+int reed_num_cus();   // gemm256.hip
+double reed_gemm256_rate();
+
+// Selection.  MEASURED (profiles/r6_gemm288.txt): the kernel is bit-identical to the 256x144 kernel and NOT faster — 8192 tokens x 4608
+// columns 99-101 us (two rounds) against 97-100 (four rounds of 256x144) and 100 (three of 256^2); one round (4096 tokens) 46-52 us
+// against 51-53.  With its parts switched off, one round of plain stores: launch + prologue 5.8 us, epilogue 6.3, the K loop 30 (MFMAs
+// alone 17.3 = the matrix pipe's floor at the 2.4 GHz the chip holds under this kernel; the loop with nothing in it 6.3: 36 barriers;
+// the DMAs alone 12; the fragment reads 4.4) — the parts add up instead of overlapping, and what the tile saves in operand bytes it
+// pays back: a ring deep enough to run ahead needs k-steps of 32, whose 64-byte row pieces are HALF cache lines (the L2 -> LDS stream
+// then delivers ~7 TB/s chip-wide instead of the ~12 of 128-byte rows: 34 KiB per k-step and CU in 0.34 us), and with whole 128-byte
+// rows only two 68 KiB stages fit the 160 KiB (the first form: the same 50 us per round).  So the heuristic does NOT take it
+// (REED_GEMM288=1 does, in gemm144.hip's units: 4.5 of area at REED_GEMM288_ETA of the 128^2 kernel's rate); force_tile 288 runs it
+// on any shape it accepts (tests, tools/r6/t288.py).
+#ifndef REED_GEMM288_ETA
+#define REED_GEMM288_ETA 1.10
+#endif
+bool reed_gemm288_preferred(int layout, int epi, const GemmArgs& a, int splits) {
+  static const bool on = getenv("REED_GEMM288") && atoi(getenv("REED_GEMM288")) != 0;
+  if (!on || !reed_gemm288_eligible(layout, epi, a, splits) || a.K < 256) return false;
+  const int ncu = reed_num_cus();
+  const long tm = cdiv(a.M, 256), tn = cdiv(a.N, 256);
+  const double c288 = (double)cdiv((long)cdiv(a.M, BM8) * (a.N / BN8), (long)ncu) * 4.5 / REED_GEMM288_ETA;
+  double best = (double)cdiv(tm * tn, (long)ncu) * 4.0 / reed_gemm256_rate();
+  if ((a.N % 256) != 0 && (a.N % 256) <= 128) {
+    const double w = (double)tm * (tn - 1) + 0.6 * tm;
+    if (w >= 2.0 * ncu) best = ceil(2.0 * w / ncu) / 2.0 * 4.0 / reed_gemm256_rate();
+  }
+  best = fmin(best, (double)cdiv((long)cdiv(a.M, 128) * cdiv(a.N, 128), 2L * ncu) * 2.0);
+  if (a.N % 144 == 0) best = fmin(best, (double)cdiv((long)cdiv(a.M, 256) * (a.N / 144), (long)ncu) * 2.25 / 0.92);
+  return c288 < best;
+}
+
+int reed_gemm288_launch(int epi, GemmArgs a, hipStream_t stream) {
+  switch (epi) {
+    case EPI_BF16: return launch288<EPI_BF16>(a, stream);
+    case EPI_GELU: return launch288<EPI_GELU>(a, stream);
+    case EPI_GELU_G: return launch288<EPI_GELU_G>(a, stream);
+    case EPI_DGELU: return launch288<EPI_DGELU>(a, stream);
+    case EPI_MUL: return launch288<EPI_MUL>(a, stream);
+  }
+  reed_set_error("reed_gemm(256x288): epilogue %d has no instantiation", epi);
+  return REED_ERR_ARG;
+}

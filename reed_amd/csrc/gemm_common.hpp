@@ -555,4 +555,77 @@ __device__ __forceinline__ void tile_epilogue_ptr(const GemmArgs& a, const f32x4
   }
 }
 
+// The 16-column strip (columns 64..79 of a tile, held by the wave-column-0 waves as one extra MFMA tile per 16 rows)
+// straight from the MFMA layout: lane (r = lane & 15, g = lane >> 4) owns row 16 i + r, columns 4 g .. 4 g + 3, i.e.
+// 8-byte bf16 / 16-byte fp32 accesses, four lanes per 32 / 64 contiguous bytes of a row.  It is a ninth of the
+// output; sending it through tile_epilogue's 64-column LDS round trip (lane-masked) doubled those waves' epilogue.
+// Same arithmetic and rounding points as tile_epilogue.
+template <int EPI>
+__device__ __forceinline__ void strip_epilogue(const GemmArgs& a, const f32x4 (&acc)[4], int mbase, int nbase, int lane) {
+  const int n = nbase + 4 * (lane >> 4);
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+    const bf16x4 b = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs[e] = bf2f(b[e]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mbase + 16 * i + (lane & 15);
+    if (m >= a.M) continue;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[i][e] + bs[e];
+    if constexpr (EPI == EPI_BF16) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+      *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_SILU || EPI == EPI_QGELU || EPI == EPI_GELU_ERF || EPI == EPI_GELU_G ||
+                         EPI == EPI_SILU_G) {
+      bf16x4 pre, act;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pre[e] = f2bf(v[e]);
+        const float x = bf2f(pre[e]);
+        if constexpr (EPI == EPI_GELU_G || EPI == EPI_SILU_G) {   // the saved array carries the derivative (gemm.h)
+          float av, gv;
+          if constexpr (EPI == EPI_GELU_G) gelu_tanh_both(x, av, gv);
+          else silu_both(x, av, gv);
+          pre[e] = f2bf(gv);
+          act[e] = f2bf(av);
+        } else if constexpr (EPI == EPI_QGELU) act[e] = f2bf(x * bfround(sigmoid_f(bfround(1.702f * x))));
+        else if constexpr (EPI == EPI_GELU_ERF) act[e] = f2bf(gelu_erf_f(x));
+        else act[e] = f2bf(EPI == EPI_GELU ? gelu_tanh_f(x) : silu_f(x));
+      }
+      if (a.C) *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = pre;
+      *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = act;
+    } else if constexpr (EPI == EPI_GATE_RES) {
+      const bf16x4 g = *(const bf16x4*)(a.gate + (long)(m / a.rows_per_gate) * a.ldgate + n);
+      const f32x4 xin = *(const f32x4*)((const float*)a.R + (long)m * a.ldr + n);
+      bf16x4 y;
+      f32x4 xo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = f2bf(v[e]);
+        xo[e] = xin[e] + bfround(bf2f(g[e]) * bf2f(y[e]));
+      }
+      if (a.C2) *(bf16x4*)((bf16*)a.C2 + (long)m * a.ldc2 + n) = y;
+      *(f32x4*)((float*)a.C + (long)m * a.ldc + n) = xo;
+    } else {  // EPI_DGELU / EPI_DSILU / EPI_RES_BF16
+      const bf16x4 pre = *(const bf16x4*)((const bf16*)a.R + (long)m * a.ldr + n);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float du = bfround(v[e]);
+        const float x = bf2f(pre[e]);
+        if constexpr (EPI == EPI_RES_BF16) o[e] = f2bf(du + x);
+        else if constexpr (EPI == EPI_MUL) o[e] = f2bf(du * x);
+        else o[e] = f2bf(du * (EPI == EPI_DGELU ? gelu_tanh_grad_f(x) : silu_grad_f(x)));
+      }
+      *(bf16x4*)((bf16*)a.C + (long)m * a.ldc + n) = o;
+    }
+  }
+}
+
 }  // namespace gemm_detail

@@ -699,3 +699,64 @@ def test_column_split_is_bit_identical_to_one_launch(dev, case):
     if case == "plain":
         ref = x.float() @ w.float().t() + bias.float()
         torch.testing.assert_close(outs[0][0].float(), ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2)
+
+
+@pytest.mark.parametrize("epi", ["plain", "gelu", "gelu_g", "dgelu", "mul"])
+@pytest.mark.parametrize("M,N,K", [(256, 288, 128), (300, 576, 192), (8, 288, 256), (1000, 1152, 1152), (8192, 4608, 1152),
+                                   (512, 4608, 64 * 5)])
+def test_tile288(dev, M, N, K, epi, force_tile):
+    """gemm288.hip (round 6; NT, 256x288 tile, 4 x 2 waves of 64x144, two 68 KiB LDS stages, the product pipelined in groups of three
+    column tiles): 2, 3, 5 and 18 K-tiles, ragged M, the 16-column strip of each wave column, every epilogue it builds — the bits of
+    the 256x144 kernel (same products, same k order inside a lane, same epilogue arithmetic) and close to an fp32 reference."""
+    from reed_amd import ops
+    if force_tile != 0:
+        pytest.skip("runs once, forcing the tiles itself")
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = _bf(torch.randn(N, generator=g)).to(dev)
+    r = _bf(torch.randn(M, N, generator=g)).to(dev)
+
+    def run(tile):
+        ops.gemm_force_tile(tile)
+        try:
+            c = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            c2 = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            if epi == "plain":
+                ops.gemm(ops.NT, ops.EPI_BF16, x, w, M, N, K, c, K, K, N, bias=b)
+                return (c,)
+            if epi in ("gelu", "gelu_g"):
+                ops.gemm(ops.NT, ops.EPI_GELU if epi == "gelu" else ops.EPI_GELU_G, x, w, M, N, K, c, K, K, N, C2=c2, ldc2=N, bias=b)
+                return (c, c2)
+            ops.gemm(ops.NT, ops.EPI_DGELU if epi == "dgelu" else ops.EPI_MUL, x, w, M, N, K, c, K, K, N, R=r, ldr=N)
+            return (c,)
+        finally:
+            ops.gemm_force_tile(0)
+
+    o288, o144 = run(288), run(144)
+    torch.cuda.synchronize()
+    for a, bb in zip(o288, o144):
+        assert torch.isnan(a[M]).all() and not torch.isnan(a[:M].float()).any()
+        assert torch.equal(a[:M], bb[:M])
+    if epi == "plain":
+        ref = x.float() @ w.float().t() + b.float()
+        err = (o288[0][:M].float() - ref).abs().max().item()
+        assert err <= ref.abs().max().item() * 2 ** -7, err
+
+
+def test_tile288_identity(dev, force_tile):
+    """A = I against an asymmetric B on the 256x288 tile: exact fragment / piece maps, both wave columns, both tile columns, the
+    fifth DMA piece (the last 32 rows of the B stage) and the chunk swizzle of the 64-byte rows."""
+    from reed_amd import ops
+    if force_tile != 0:
+        pytest.skip("runs once")
+    M, N, K = 256, 576, 256
+    x = torch.eye(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.arange(N * K, device=dev).reshape(N, K) % 251).float().to(torch.bfloat16)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm_force_tile(288)
+    try:
+        ops.gemm(ops.NT, ops.EPI_BF16, x, w, M, N, K, out, K, K, N)
+    finally:
+        ops.gemm_force_tile(0)
+    assert torch.equal(out.float(), w.float().t().contiguous())
