@@ -245,9 +245,8 @@ double reed_gemm256_rate();
 // columns 99-101 us (two rounds) against 97-100 (four rounds of 256x144) and 100 (three of 256^2); one round (4096 tokens) 46-52 us
 // against 51-53.  With its parts switched off, one round of plain stores: launch + prologue 5.8 us, epilogue 6.3, the K loop 30 (MFMAs
 // alone 17.3 = the matrix pipe's floor at the 2.4 GHz the chip holds under this kernel; the loop with nothing in it 6.3: 36 barriers;
-// the DMAs alone 12; the fragment reads 4.4) — the parts add up instead of overlapping, and what the tile saves in operand bytes it
-// pays back: a ring deep enough to run ahead needs k-steps of 32, whose 64-byte row pieces are HALF cache lines (the L2 -> LDS stream
-// then delivers ~7 TB/s chip-wide instead of the ~12 of 128-byte rows: 34 KiB per k-step and CU in 0.34 us), and with whole 128-byte
+// the DMAs alone 12; the fragment reads 4.4) — with two waves per SIMD running the same program between barriers the parts add up
+// more than they overlap.  The ring that lets the DMA run ahead costs a barrier per 32-wide k-step, and with whole K-tiles of 128-byte
 // rows only two 68 KiB stages fit the 160 KiB (the first form: the same 50 us per round).  So the heuristic does NOT take it
 // (REED_GEMM288=1 does, in gemm144.hip's units: 4.5 of area at REED_GEMM288_ETA of the 128^2 kernel's rate); force_tile 288 runs it
 // on any shape it accepts (tests, tools/r6/t288.py).
