@@ -200,6 +200,53 @@ except Exception:
     pass
 
 
+def time_attention(b, H=16, hd=72, T=256, iters=10):
+    """The attention kernels of a block at the step's shape, launched in isolation after the timed region: us per launch, algorithmic
+    TFLOP/s (4 T^2 hd forward, 10 T^2 hd backward per head) and the HBM roofline that bounds them — forward reads qkv and writes o
+    (4 M D bf16), the backward in the step's form (delta = rowsum(dO o) taken from the dO GEMM's epilogue 13) reads qkv and dO and
+    writes dqkv (7 M D bf16) — as TB/s and the fraction of 8 TB/s."""
+    from reed_amd import ops
+    dev = torch.device("cuda")
+    M, D = b * T, H * hd
+    qkv = (torch.randn(M, 3 * D, device=dev) * 0.5).to(torch.bfloat16)
+    o = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+    do = torch.randn(M, D, device=dev).to(torch.bfloat16)
+    dqkv = torch.empty(M, 3 * D, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(b, H, T, device=dev)
+    ws = torch.empty(ops.attention_bwd_ws_floats(b, T, H), device=dev)
+    dpart = torch.empty(H, 2 if hd == 72 else 1, M, device=dev)
+    w = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
+    dy = torch.randn(M, D, device=dev).to(torch.bfloat16)
+    ops.attention_fwd(qkv, o, lse, b, T, H, hd)
+    step_form = bool(ops.dgrad_with_head_dots(dy, w, do, o, dpart, M, D, D, hd))
+
+    def t(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    tf = t(lambda: ops.attention_fwd(qkv, o, lse, b, T, H, hd))
+    if step_form:
+        tb = t(lambda: ops.attention_bwd_dp(qkv, do, lse, dpart, dqkv, ws, b, T, H, hd))
+    else:
+        tb = t(lambda: ops.attention_bwd(qkv, o, do, lse, dqkv, b, T, H, hd, ws=ws))
+    bf_, bb_ = 4.0 * M * D * 2, (7.0 if step_form else 8.0) * M * D * 2
+    ff, fb = 4.0 * T * T * hd * b * H, 10.0 * T * T * hd * b * H
+    rec = lambda sec, byt, fl: {"us": round(sec * 1e6, 1), "bytes": int(byt), "TB_per_s": round(byt / sec / 1e12, 3),  # noqa: E731
+                                "frac_of_8_TB_per_s": round(byt / sec / 8e12, 4), "tflops": round(fl / sec / 1e12, 1)}
+    return {"shape": {"batch": b, "tokens": T, "heads": H, "head_dim": hd}, "bound": "hbm", "peak_TB_per_s": 8.0,
+            "forward": rec(tf, bf_, ff), "backward": rec(tb, bb_, fb),
+            "backward_form": "delta from the dO GEMM's epilogue 13 (the step's form)" if step_form else "delta by a row kernel",
+            "measured": "launched in isolation after the timed region; in-step launch times: profiles/r6_bench_n1_kernel_stats.csv"}
+
+
 def time_gemms(b, D=1152, Hm=4608, T=256, iters=8, act_grad=True):
     """Per-shape timing of the block GEMMs through the SAME entry points and kernel-selection logic the engine uses
     (events on the launch stream): forward NT with fused epilogues, dgrad NN on the weight shadow, wgrad TN through
@@ -905,6 +952,11 @@ def main():
                                            "ms_per_block": round(tot, 4), "table": rows,
                                            "activation_backward": "saved derivative (fc1 epilogue 14, fc2 dgrad epilogue 16)"
                                            if sag else "recomputed (epilogues 1 / 4)"}
+        if rows is not None and world == 1 and args.model == "SiT-XL/2":
+            try:
+                out["attention"] = time_attention(b)
+            except Exception as e:   # a reported leg, never a reason to lose the headline line
+                out["attention"] = {"error": repr(e)}
         if world == 1 and not args.no_c3_leg and b != 32 and args.model == "SiT-XL/2":
             try:
                 out["c3_per_gpu_leg"] = c3_leg(step, dev, args.z_dim)

@@ -719,3 +719,16 @@ def test_bench_keeps_the_plain_record_when_the_tuner_fails(dev, fail):
     assert ("timeout" in err) if fail == "hang" else ("--test-tuner-fail" in err), err
     assert ("watchdog_fired" in d) == (fail == "hang")
 
+
+
+def test_bench_attention_record(dev):
+    """The bench record's `attention` entry: forward and backward of a block's attention at the step's head
+    shape against the HBM roofline that bounds them — bytes, us, TB/s, the fraction of 8 TB/s."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = bench.time_attention(8, iters=3)
+    assert rec["bound"] == "hbm" and rec["shape"] == {"batch": 8, "tokens": 256, "heads": 16, "head_dim": 72}
+    for k in ("forward", "backward"):
+        r = rec[k]
+        assert r["us"] > 0 and r["bytes"] > 0 and 0 < r["frac_of_8_TB_per_s"] < 1 and abs(r["TB_per_s"] / 8 - r["frac_of_8_TB_per_s"]) < 1e-3
+    assert rec["forward"]["bytes"] == 4 * 8 * 256 * 1152 * 2
